@@ -1,0 +1,120 @@
+"""Pin the numpy oracle (oracle/pyhillfit_oracle.py) to vectors produced by the reference itself.
+
+Golden files come from tests/golden/make_golden.py (reference executed in memory)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import pyhillfit_oracle as orc
+
+
+def _same(a, b, rtol=1e-13):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    inf = np.isinf(a) | np.isinf(b) | np.isnan(a) | np.isnan(b)
+    assert np.array_equal(a[inf], b[inf], equal_nan=True)
+    np.testing.assert_allclose(a[~inf], b[~inf], rtol=rtol, atol=0)
+
+
+def test_pairs_match_reference_loader(g4_pairs, oracle_pair):
+    assert len(g4_pairs) == 210
+    for (d, c), g in g4_pairs.items():
+        p = oracle_pair(d, c)
+        assert np.array_equal(p.concs, g["concs"]) and np.array_equal(p.responses, g["responses"])
+        assert (int(p.is0.sum()), int(p.is100.sum()), int(p.other.sum())) == (g["n0"], g["n100"], g["n_other"])
+        assert p.pi_bit == g["pi_bit"]
+        assert [len(e) for e in p.experiments] == g["expt_sizes"]
+
+
+def test_hill_curve_values():
+    g = np.load(os.path.join(GOLDEN, "g1_log_target.npz"))
+    for (pic50, hill), want in zip(g["curve_in"], g["curve_out"]):
+        got = orc.hill_curve(g["curve_doses"], hill, orc.ic50_of(pic50))
+        assert np.array_equal(got, want)
+
+
+def test_log_target_single_level(golden_meta, oracle_pair):
+    """G1: dr.log_target / log_data_likelihood / log_priors, models 1 and 2, 4 temperatures, 10 pairs."""
+    g = np.load(os.path.join(GOLDEN, "g1_log_target.npz"))
+    pairs = [oracle_pair(m["drug"], m["channel"]) for m in golden_meta["g1_pairs"]]
+    n = len(g["target"])
+    lik, pri, tgt = np.empty(n), np.empty(n), np.empty(n)
+    for k in range(n):
+        model, t, th = int(g["model"][k]), float(g["t"][k]), g["theta"][k]
+        params = th if model == 2 else th[[0, 2]]
+        p = pairs[int(g["pair"][k])]
+        with np.errstate(all="ignore"):
+            lik[k] = orc.log_likelihood(model, p, params, t)
+            pri[k] = orc.log_prior(model, params)
+        tgt[k] = orc.log_target(model, p, params, t)
+    assert np.isinf(g["target"]).sum() > 100          # the edge rows are really exercised
+    _same(lik, g["lik"]); _same(pri, g["prior"]); _same(tgt, g["target"])
+    # the survey's probe values
+    amio = pairs[0]
+    assert orc.log_target(2, amio, np.array([6., 1., 5.]), 1) == pytest.approx(-58.39140921642633, rel=1e-14)
+    assert orc.log_target(2, amio, np.array([6., 1., 5.]), 0) == pytest.approx(1.9037293660251158, rel=1e-14)
+
+
+def test_hierarchical_prior_params():
+    g = np.load(os.path.join(GOLDEN, "g2_hier_target.npz"))
+    shapes, scales, locs = orc.hierarchical_prior_params()
+    assert np.array_equal(shapes, g["shapes"]) and np.array_equal(scales, g["scales"]) and np.array_equal(locs, g["locs"])
+
+
+def test_hierarchical_log_target(golden_meta, oracle_pair):
+    """G2: PyHillFit.log_target_distribution incl. support edges, Ne = 3..6 and synthetic Ne = 5, 50."""
+    g = np.load(os.path.join(GOLDEN, "g2_hier_target.npz"))
+    shapes, scales, locs = orc.hierarchical_prior_params()
+    for ip, m in enumerate(golden_meta["g2_pairs"]):
+        p = oracle_pair(m["drug"], m["channel"], m["file"])
+        assert len(p.experiments) == m["Ne"]
+        got = np.array([orc.hier_log_target(p.experiments, th, shapes, scales, locs) for th in g["theta_%d" % ip]])
+        _same(got, g["target_%d" % ip], rtol=1e-12)
+    amio = oracle_pair("Amiodarone", "hERG")
+    v = orc.hier_log_target(amio.experiments, [1, 5, 6, .3, 6, .8, 6.1, .7, 5.9, .9, 8], shapes, scales, locs)
+    assert v == pytest.approx(-28.722039448904166, rel=1e-13)
+
+
+@pytest.mark.parametrize("run", ["amio_m2_t1", "amio_m1_t1", "amio_m2_t0125", "amio_m2_t0", "bepr_m2_t1", "moxi_m1_t1"])
+def test_loop_trace_recorded_draws(run, golden_meta, oracle_pair):
+    """G3: replay the reference do_mcmc draw by draw (recorded theta*, u): identical accept sequence,
+    chain and adaptation (scaled covariance handed to the proposal) at every iteration."""
+    g = np.load(os.path.join(GOLDEN, "g3_traces.npz"))
+    m = next(r for r in golden_meta["g3_runs"] if r["name"] == run)
+    p = oracle_pair(m["drug"], m["channel"])
+    trace = {}
+    chain, fin = orc.tempered_chain(m["model"], p, m["temperature"], m["iterations"], 1,
+                                    orc.RecordedDraws(g[run + "_star"], g[run + "_u"]), trace=trace)
+    want = g[run + "_chain"]
+    assert np.array_equal(np.diff(chain[:, 0]) != 0, np.diff(want[:, 0]) != 0)     # accept sequence
+    _same(chain, want, rtol=1e-13)
+    covs = np.array(trace["cov"])
+    np.testing.assert_allclose(covs[::20], g[run + "_cov_every20"], rtol=1e-11)
+    np.testing.assert_allclose(covs[-1], g[run + "_cov_last"], rtol=1e-11)
+    assert (np.diff(want[:, 0]) != 0).sum() > 100
+
+
+def test_loop_trace_numpy_legacy_rng(golden_meta, oracle_pair):
+    """Same loop, but drawing from numpy's legacy RandomState(1) like the reference (PyHillTemp.py:16-17):
+    reproduces the reference chain draw-for-draw on this platform's LAPACK."""
+    g = np.load(os.path.join(GOLDEN, "g3_traces.npz"))
+    m = next(r for r in golden_meta["g3_runs"] if r["name"] == "amio_m2_t1")
+    p = oracle_pair(m["drug"], m["channel"])
+    chain, _ = orc.tempered_chain(2, p, 1.0, 2000, 1, orc.LegacyNumpyDraws(1))
+    _same(chain, g["amio_m2_t1_chain"][:2001], rtol=1e-9)
+
+
+def test_thinning_and_burn_in(golden_meta, oracle_pair):
+    g = np.load(os.path.join(GOLDEN, "g3_traces.npz"))
+    p = oracle_pair("Amiodarone", "hERG")
+    chain, _ = orc.tempered_chain(2, p, 1.0, 1000, 5, orc.LegacyNumpyDraws(1))
+    out = orc.drop_burn_in(chain, 4)
+    assert out.shape == g["thin5_burn4_chain"].shape == (151, 4)
+    _same(out, g["thin5_burn4_chain"], rtol=1e-9)
+
+
+def test_temperature_ladder():
+    lad = orc.temperature_ladder()
+    assert len(lad) == 41 and lad[0] == 0 and lad[-1] == 1 and lad[1] == (1 / 40) ** 3
