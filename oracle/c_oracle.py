@@ -1,0 +1,123 @@
+"""ctypes binding of oracle/_build/libphf_oracle.so — TEST INFRASTRUCTURE (see phf_oracle.c)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libphf_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+class Problem(C.Structure):
+    _fields_ = [("model", C.c_int32), ("n_other", C.c_int32), ("n_zero", C.c_int32), ("n_hundred", C.c_int32),
+                ("ln_conc", C.c_void_p), ("response", C.c_void_p), ("pi_bit", C.c_double), ("temperature", C.c_double)]
+
+
+class Run(C.Structure):
+    _fields_ = [("t_begin", C.c_int64), ("t_end", C.c_int64), ("thinning", C.c_int32), ("reset_mean", C.c_int32),
+                ("adapt_start", C.c_int64), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+                ("chain_id", C.c_uint32), ("problem_id", C.c_uint32), ("gamma", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.phfo_log_target.restype = C.c_double
+        L.phfo_log_likelihood.restype = C.c_double
+        L.phfo_log_prior.restype = C.c_double
+        L.phfo_state_size.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def gamma_table(n):
+    """gamma[s] = 1/(s+1)**0.6 evaluated like the reference does (Python float pow), s = 0..n."""
+    return np.array([1.0 / (s + 1.0) ** 0.6 for s in range(n + 1)], dtype=np.float64)
+
+
+class PackedPair:
+    """One pair in the kernel's order: 'other' points, then y==0 points, then y==100 points."""
+
+    def __init__(self, concs, responses, model, temperature=1.0):
+        concs = np.asarray(concs, float); y = np.asarray(responses, float)
+        other = (0 < y) & (y < 100); zero = y == 0; hund = y == 100
+        order = np.concatenate([np.nonzero(other)[0], np.nonzero(zero)[0], np.nonzero(hund)[0]])
+        with np.errstate(divide="ignore"):
+            self.ln_conc = np.ascontiguousarray(np.log(concs[order]))
+        self.response = np.ascontiguousarray(y[order])
+        self.pb = Problem(model, int(other.sum()), int(zero.sum()), int(hund.sum()), _p(self.ln_conc),
+                          _p(self.response), 0.5 * len(y) * np.log(2 * np.pi), float(temperature))
+        self.d = 2 if model == 1 else 3
+
+    def log_target(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        return lib().phfo_log_target(C.byref(self.pb), _p(th))
+
+    def log_likelihood(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        return lib().phfo_log_likelihood(C.byref(self.pb), _p(th))
+
+    def log_prior(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        return lib().phfo_log_prior(self.pb.model, _p(th))
+
+    def init_state(self, theta0, cov_identity, cov_scale):
+        st = np.zeros(lib().phfo_state_size(self.d))
+        th = np.ascontiguousarray(theta0, dtype=np.float64)
+        lib().phfo_init_state(C.byref(self.pb), int(cov_identity), C.c_double(cov_scale), _p(th), _p(st))
+        return st
+
+    def advance(self, st, t_begin, t_end, thinning, adapt_start, reset_mean, gamma, seed=25, chain_id=0, problem_id=0,
+                star_replay=None, u_replay=None, trace_cov=False):
+        rows = t_end // thinning - t_begin // thinning
+        out = np.zeros((rows, self.d + 1))
+        run = Run(t_begin, t_end, thinning, int(reset_mean), adapt_start, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF,
+                  chain_id, problem_id, _p(gamma))
+        sr = np.ascontiguousarray(star_replay, dtype=np.float64) if star_replay is not None else None
+        ur = np.ascontiguousarray(u_replay, dtype=np.float64) if u_replay is not None else None
+        tr = np.zeros((t_end - t_begin, self.d, self.d)) if trace_cov else None
+        lib().phfo_advance(C.byref(self.pb), C.byref(run), _p(st), _p(out), _p(sr) if sr is not None else None,
+                           _p(ur) if ur is not None else None, _p(tr) if tr is not None else None)
+        return (out, tr) if trace_cov else out
+
+
+def vec(name, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    getattr(lib(), "phfo_vec_" + name)(C.c_int64(x.size), _p(x), _p(out))
+    return out
+
+
+def sincos(w):
+    w = np.ascontiguousarray(w, dtype=np.uint32)
+    s = np.empty(w.size); c = np.empty(w.size)
+    lib().phfo_vec_sincos(C.c_int64(w.size), _p(w), _p(s), _p(c))
+    return s, c
+
+
+def philox(ctr_key):
+    ck = np.ascontiguousarray(ctr_key, dtype=np.uint32).reshape(-1, 6)
+    out = np.empty((ck.shape[0], 4), dtype=np.uint32)
+    lib().phfo_philox(C.c_int64(ck.shape[0]), _p(ck), _p(out))
+    return out
+
+
+def draws(d, chain_id, problem_id, t, seed=25):
+    z = np.zeros(4); u = C.c_double()
+    lib().phfo_draws(d, chain_id, problem_id, t, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, _p(z), C.byref(u))
+    return z, u.value

@@ -1,0 +1,40 @@
+/* phf_philox.h — Philox4x32-10 counter-based generator (Salmon et al., SC'11), one block of
+ * four 32-bit words per (counter, key).  Stateless: the MH kernels address the stream as
+ *   counter = (chain index within problem, global problem id, MH iteration, draw block)
+ *   key     = (seed low word, seed high word)
+ * so a chain's random numbers do not depend on which GPU, block or launch segment runs it
+ * (needed for the 1/2/4/8-GPU parity check and for resume).  Plays the role of the
+ * reference's global numpy RandomState (python/PyHillFit.py:825,831,834).
+ * Checked against the Random123 known-answer vectors in tests/test_math_philox.py.          */
+#ifndef PHF_PHILOX_H
+#define PHF_PHILOX_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PHF_PHILOX_HD static __host__ __device__ __forceinline__
+#else
+#define PHF_PHILOX_HD static inline
+#endif
+
+typedef struct { uint32_t w[4]; } phf_u32x4;
+
+PHF_PHILOX_HD phf_u32x4 phf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                          uint32_t k0, uint32_t k1) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  phf_u32x4 out;
+  out.w[0] = c0; out.w[1] = c1; out.w[2] = c2; out.w[3] = c3;
+  return out;
+}
+
+#endif /* PHF_PHILOX_H */

@@ -1,0 +1,87 @@
+"""Leaf numerics shared by the HIP kernels and the C twin (pyhillfit_amd/csrc/phf_math.h, phf_philox.h),
+checked on the host build against numpy / scipy / mpmath and the Random123 known-answer vectors."""
+import mpmath as mp
+import numpy as np
+import scipy.special as sp
+
+from oracle import c_oracle as co
+
+RNG = np.random.default_rng(7)
+
+
+def _ulps(got, want):
+    want = np.asarray(want, float)
+    return np.max(np.abs(got - want) / np.spacing(np.abs(want)))
+
+
+def test_philox_known_answers():
+    kat = [([0, 0, 0, 0, 0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 6, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ck, want in kat:
+        assert co.philox([ck])[0].tolist() == want
+
+
+def test_exp_log_within_one_ulp_of_libm():
+    x = np.concatenate([RNG.uniform(-745, 709.7, 100000), RNG.uniform(-2, 2, 100000), [0.0, -0.0, 1.0, 709.782712893384]])
+    assert _ulps(co.vec("exp", x), np.exp(x)) <= 1.0
+    assert np.array_equal(co.vec("exp", [np.inf, -np.inf, 710.0, -746.0, -800.0]), [np.inf, 0, np.inf, 0, 0])
+    assert np.isnan(co.vec("exp", [np.nan])[0])
+    x = np.concatenate([np.exp(RNG.uniform(-700, 700, 100000)), RNG.uniform(0.5, 2, 100000), [5e-324, 1e-310, 1.0]])
+    assert _ulps(co.vec("log", x), np.log(x)) <= 1.0
+    out = co.vec("log", [0.0, -0.0, -1.0, np.inf, np.nan])
+    assert out[0] == -np.inf and out[1] == -np.inf and np.isnan(out[2]) and out[3] == np.inf and np.isnan(out[4])
+
+
+def test_exp_log_against_mpmath():
+    mp.mp.dps = 40
+    for x in [-700.3, -37.2, -1e-5, 0.3, 1.0, 55.5, 709.7]:
+        assert abs(mp.mpf(float(co.vec("exp", [x])[0])) / mp.exp(mp.mpf(x)) - 1) < 2.3e-16
+    for x in [1e-300, 0.7071, 0.99999, 1.00001, 1.4143, 3.0, 1e300]:
+        assert abs(mp.mpf(float(co.vec("log", [x])[0])) / mp.log(mp.mpf(x)) - 1) < 2.3e-16
+
+
+def test_erfcx_and_normal_cdf():
+    mp.mp.dps = 40
+    for y in [0.0, 0.3, 1.0, 3.3, 10.0, 1e3, 7e4, 1e120]:
+        ex = mp.exp(mp.mpf(y) ** 2) * mp.erfc(mp.mpf(y)) if y < 1e3 else None
+        if ex is None:  # asymptotic series, exact enough at these sizes
+            yy = mp.mpf(y); ex = 1 / (yy * mp.sqrt(mp.pi)) * (1 - 1 / (2 * yy * yy) + 3 / (4 * yy ** 4))
+        assert abs(mp.mpf(float(co.vec("erfcx", [y])[0])) / ex - 1) < 6e-16
+    y = np.concatenate([np.exp(RNG.uniform(-20, 12, 100000)), RNG.uniform(0, 8, 100000)])
+    assert np.max(np.abs(co.vec("erfcx", y) / sp.erfcx(y) - 1)) < 4e-15
+    # log Phi on the branch the censored likelihood uses (x <= 0), down to -1e5 (sigma = 1e-3)
+    x = np.concatenate([-np.exp(RNG.uniform(-20, 11.6, 100000)), RNG.uniform(-40, 0, 100000), [0.0, -1e5]])
+    assert np.max(np.abs(co.vec("log_ndtr", x) / sp.log_ndtr(x) - 1)) < 6e-15
+    x = RNG.uniform(0, 38, 50000)
+    assert np.max(np.abs(co.vec("log_ndtr", x) - sp.log_ndtr(x))) < 4e-15
+    x = RNG.uniform(-38, 10, 100000)
+    got, want = co.vec("ndtr", x), sp.ndtr(x)
+    assert np.max(np.abs(got - want)) < 1e-15
+    assert np.max(np.abs(got / want - 1)[want > 0]) < 1e-12     # scipy's own tail error is ~x^2/2 ulp
+    for xv in [-37.0, -20.5, -8.25, -3.0, -0.5, 0.7, 4.0]:         # the tail itself, against mpmath
+        ex = mp.erfc(-mp.mpf(xv) / mp.sqrt(2)) / 2
+        assert abs(mp.mpf(float(co.vec("ndtr", [xv])[0])) / ex - 1) < 1e-15
+
+
+def test_sincos_octants():
+    w = RNG.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32)
+    w[:10] = [0, 1, 2 ** 28 - 1, 2 ** 28, 2 ** 29, 2 ** 31, 2 ** 32 - 1, 2 ** 32 - 2 ** 28, 2 ** 32 - 2 ** 28 - 1, 3 * 2 ** 29]
+    s, c = co.sincos(w)
+    ang = 2 * np.pi * w.astype(float) / 2 ** 32
+    assert np.max(np.abs(s - np.sin(ang))) < 1.5e-15 and np.max(np.abs(c - np.cos(ang))) < 1.5e-15
+    assert s[0] == 0 and c[0] == 1 and c[4] == np.sqrt(0.5) and s[5] == 0 and c[5] == -1
+
+
+def test_draw_distributions():
+    """Box-Muller normals and the accept uniform drawn exactly as the sampler draws them."""
+    z = np.array([co.draws(3, 0, 0, t)[0] for t in range(1, 20001)])
+    u = np.array([co.draws(3, 0, 0, t)[1] for t in range(1, 20001)])
+    zz = z[:, :3].ravel()
+    assert abs(zz.mean()) < 0.02 and abs(zz.std() - 1) < 0.02 and abs((zz ** 3).mean()) < 0.06 and abs((zz ** 4).mean() - 3) < 0.15
+    assert np.abs(np.corrcoef(z[:, :3].T) - np.eye(3)).max() < 0.03
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.003 and u.min() >= 0 and u.max() < 1
+    z2, u2 = co.draws(2, 5, 9, 77)
+    z3, _ = co.draws(3, 5, 9, 77)
+    assert np.array_equal(z2[:2], z3[:2]) and z2[2] == 0       # model 1 uses one Philox block
