@@ -101,12 +101,15 @@ def test_posterior_matches_reference_long_run(oracle_pair):
             continue
         p = oracle_pair(want["drug"], want["channel"])
         pk = co.PackedPair(p.concs, p.responses, want["model"], want["temperature"])
-        s = _run_chains(pk, np.ones(pk.d), 32, 60000, 5, 1000 * pk.d, True, True, 1.0)
+        s = _run_chains(pk, np.ones(pk.d), 16, 200000, 5, 1000 * pk.d, True, True, 1.0)
         # the reference figure is ONE chain of 30 001 autocorrelated rows: allow 1 % plus 3 of its own
         # Monte-Carlo standard errors (ESS ~ rows/20, measured spread of single-chain means)
         ref_se = np.array(want["sd"][:pk.d]) / np.sqrt(want["rows"] / 20.0)
         assert np.all(np.abs(s.mean(0)[:pk.d] - want["mean"][:pk.d]) <= 0.01 * np.abs(want["mean"][:pk.d]) + 3 * ref_se)
-        np.testing.assert_allclose(s.std(0)[:pk.d], want["sd"][:pk.d], rtol=0.05)
+        # quantiles are the robust shape check; a single chain's sd moves by +-5..25 % with rare Hill excursions
+        for q, key in ((0.05, "q05"), (0.5, "q50"), (0.95, "q95")):
+            np.testing.assert_allclose(np.quantile(s[:, :pk.d], q, axis=0), want[key][:pk.d], rtol=0.02)
+        np.testing.assert_allclose(s.std(0)[:pk.d], want["sd"][:pk.d], rtol=0.2)
         assert s.mean(0)[pk.d] == pytest.approx(want["mean"][pk.d], abs=0.08)
 
 
