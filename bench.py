@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: MH samples/sec of the HIP sampler (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3] [--iters-per-step I]
+
+A "step" is ONE launch of the sampler kernel advancing every chain of the batch by I Metropolis-Hastings
+iterations (thinned samples of all chains written to HBM).  N=1 workload = BASELINE.json configs[1]:
+Amiodarone-hERG, model 2, 65 536 chains.  With N>1 (launched by torch.distributed.run, one rank per GPU) every
+rank runs its own 65 536-chain shard of the chain batch (weak scaling, no collective in the data path; the
+Philox chain ids continue across ranks), timing is barrier + synchronize on both sides, MAX over ranks.
+Rank 0 prints ONE JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 64 fp64 FMA lanes x 2 x 2.4 GHz (vector, non-MFMA)
+
+
+def cpu_baseline(iterations=15000):
+    """rank 0 only, N=1 only: the oracle timed on the host.  'port' = the numpy/scipy restatement of the reference
+    loop (python/PyHillTemp.py:57-125 with numpy's legacy RNG, like the reference), one core, same pair/model.
+    The scalar C twin's rate is reported next to it."""
+    from oracle import pyhillfit_oracle as orc
+    from oracle import c_oracle as co
+    from pyhillfit_amd import doseresponse as dr
+    ne, _, ex = dr.load_crumb_data("Amiodarone", "hERG")
+    concs, y = dr.concatenate_experiments(ne, ex)
+    pair = orc.PairData(concs, y)
+    t0 = time.perf_counter()
+    orc.single_level_chain(2, pair, [6.0, 0.8, 8.0], iterations, 5, orc.LegacyNumpyDraws(25))
+    dt = time.perf_counter() - t0
+    pk = co.PackedPair(concs, y, 2, 1.0)
+    st = pk.init_state([6.0, 0.8, 8.0], False, 0.05)
+    n_c = 2000000
+    gam = co.gamma_table(n_c)
+    t0 = time.perf_counter()
+    pk.advance(st, 0, n_c, 5, 3000, False, gam, seed=25)
+    dtc = time.perf_counter() - t0
+    return {"value": iterations / dt, "unit": "MH samples/s", "cores": 1, "kind": "port",
+            "sample": "%d iterations of 1 chain, Amiodarone-hERG model 2, numpy/scipy restatement of the reference loop "
+                      "(oracle/pyhillfit_oracle.py), %.1f s" % (iterations, dt),
+            "c_twin_value": n_c / dtc, "c_twin_sample": "%d iterations, scalar C twin (oracle/phf_oracle.c), 1 core, %.1f s" % (n_c, dtc),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--iters-per-step", type=int, default=2000)
+    ap.add_argument("--chains", type=int, default=None, help="chains per problem (default: 65536 for c2, 4096 for c3)")
+    ap.add_argument("--thinning", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the sampler has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pyhillfit_amd import doseresponse as dr
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    dr.define_model(2)
+    if a.workload == "c2":
+        names = [("Amiodarone", "hERG")]
+        C = a.chains or 65536
+        label = "Amiodarone-hERG, non-hierarchical model 2 (pIC50, Hill, sigma), %d chains per GPU (BASELINE configs[1])" % C
+    else:
+        names = [(d, c) for d in dr.drugs for c in dr.channels]
+        C = a.chains or 4096
+        label = "all %d Crumb drug x channel pairs, non-hierarchical model 2, %d chains each per GPU (BASELINE configs[2])" % (len(names), C)
+    packed = dr.pack_single_level(names)
+    Q = len(names)
+    # weak scaling: rank r owns chains [r*C, (r+1)*C) of every problem
+    s = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, C, thinning=a.thinning, seed=25,
+                           chain_id_base=rank * C, device=dev)
+    s.init([6.0, 0.8, 8.0], cov_identity=False, cov_scale=0.05)      # PyHillFit.py:748-751 start
+    I = a.iters_per_step
+    s.reserve((a.warmup + a.steps) * I)
+    rows = torch.empty((s.rows_between(0, I), Q, s.d + 1, C), dtype=torch.float64, device=dev)
+
+    for _ in range(a.warmup):
+        s.advance(I, out=rows)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record()
+        s.advance(I, out=rows)
+        ev[k][1].record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kernel_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))   # HIP events on the launch stream
+    assert torch.isfinite(rows).all()
+
+    if rank == 0:
+        samples_per_step = float(Q) * C * I * world
+        value = samples_per_step * a.steps / dt
+        alg_bytes = float(Q) * C * I * 8 * (s.d + 1) / a.thinning      # 8(d+1)/thin B per iteration
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        flop_per_iter = 2.0 * float(os.environ.get("PHF_FP64_OPS_PER_ITER", "1250"))  # see DESIGN.md (static count)
+        tflops = float(Q) * C * I * flop_per_iter / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "MCMC samples/sec (whole node)", "value": value, "unit": "MH samples/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "real Crumb dose-response rows (data/crumb_dataset.json), synthetic chain batch",
+            "config": {"workload": label, "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": Q * C,
+                       "adaptation": "on (steps start after iteration %d > adapt_start %d)" % (a.warmup * I, s.adapt_start)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "mh_advance_kernel<2>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "fp64-VALU-bound scalar-per-chain arithmetic; the HBM fraction is reported as BASELINE asks, the binding roof is fp64_valu"},
+            "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                          "flop_per_iteration": flop_per_iter},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

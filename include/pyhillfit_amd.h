@@ -1,0 +1,127 @@
+/* pyhillfit_amd.h — C ABI of the MI355X-native Metropolis-Hastings engine for PyHillFit's sampling step.
+ *
+ * The reference (mirams/PyHillFit) has no FFI: its hot path is a Python loop.  These entry points are
+ * what a ctypes binding inside the reference would call instead of that loop; each cites the reference
+ * code it replaces (file:line into the reference repository).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer marked "device" is a HIP device pointer owned by the caller
+ *     (the Python host passes torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default)
+ *   - every function returns PHF_OK (0) or a negative error code and never throws or exits; the message is
+ *     available from phf_last_error() (thread-local).  The reference's sys.exit() on NaN
+ *     (python/PyHillFit.py:126-131,188-191) becomes: NaN proposals are rejected, nothing aborts.
+ *   - launches are asynchronous on `stream`; the library allocates nothing and keeps no global state, so one
+ *     host thread/process per GPU may call it concurrently.
+ *   - all arithmetic is IEEE fp64.  Chain-major arrays are struct-of-arrays with the chain index fastest
+ *     ("[f][chain]"), so that the 64 lanes of a wavefront touch 512 contiguous bytes.
+ */
+#ifndef PYHILLFIT_AMD_H
+#define PYHILLFIT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHF_ABI_VERSION 1
+
+enum {
+  PHF_OK = 0,
+  PHF_ERR_INVALID_ARGUMENT = -1,
+  PHF_ERR_HIP = -2,
+  PHF_ERR_UNSUPPORTED = -3
+};
+
+/* Dose-response points of P (drug, channel) pairs for the single-level (non-hierarchical) models.
+ * Replaces the per-pair arrays built at python/PyHillFit.py:661-683 (concs, responses, the three boolean
+ * masks and pi_bit).  Points of a pair are stored masked-group by masked-group: first the n_other points with
+ * 0 < y < 100 (where_r_other), then the n_zero points with y == 0 (where_r_0), then the n_hundred points with
+ * y == 100 (where_r_100), each group in file order; points outside [0,100] belong to no mask and are dropped,
+ * exactly as the reference ignores them.                                                                      */
+typedef struct phf_points {
+  int32_t num_pairs;        /* P */
+  int32_t stride;           /* doubles per pair row in ln_conc/response (>= n_other+n_zero+n_hundred) */
+  const double* ln_conc;    /* device [P][stride]  natural log of the dose in uM (-inf for dose 0) */
+  const double* response;   /* device [P][stride]  percent inhibition */
+  const int32_t* counts;    /* device [P][4]       n_other, n_zero, n_hundred, n_total (incl. dropped points) */
+  const double* pi_bit;     /* device [P]          0.5*n_total*ln(2 pi), python/doseresponse.py:299-301 */
+} phf_points;
+
+/* The batch of independent Markov chains one call advances: Q problems x C chains.
+ * A problem = (pair, temperature): python/PyHillFit.py runs one per pair at temperature 1
+ * (:57,978-981); python/PyHillTemp.py runs one per rung of the ladder (:151-161).
+ * problem_id / chain_id_base feed the Philox counter so that a chain's random stream is the same whichever
+ * GPU or launch runs it.                                                                                      */
+typedef struct phf_problems {
+  int32_t num_problems;          /* Q */
+  int32_t chains_per_problem;    /* C */
+  const int32_t* pair_index;     /* device [Q]  row of phf_points */
+  const double* temperature;     /* device [Q]  power the likelihood is raised to */
+  const uint32_t* problem_id;    /* device [Q]  global problem number (Philox counter word 1) */
+  uint32_t chain_id_base;        /* global number of local chain 0 (Philox counter word 0) */
+  uint32_t reserved;
+} phf_problems;
+
+/* Adaptive-Metropolis schedule: python/PyHillFit.py:787-848 / python/PyHillTemp.py:76-123. */
+typedef struct phf_mh_config {
+  int32_t model;                 /* 1: (pIC50, sigma), Hill fixed to 1;  2: (pIC50, Hill, sigma); doseresponse.py:250-279 */
+  int32_t thinning;              /* save every thinning-th iteration (-t) */
+  int64_t adapt_start;           /* when_to_adapt: 1000*d (PyHillFit.py:787, PyHillTemp.py:83) */
+  int32_t reset_mean_at_adapt_start; /* PyHillTemp.py:114-115 */
+  int32_t reserved;
+  uint64_t seed;                 /* Philox key (the reference seeds numpy with 25: PyHillFit.py:824-825) */
+  const double* gamma;           /* device [>= t_end-adapt_start+1]  gamma[s] = 1/(s+1)**0.6 (PyHillFit.py:841-842), gamma[0] unused */
+} phf_mh_config;
+
+int phf_version(void);
+const char* phf_last_error(void);
+
+/* doubles of per-chain state for the single-level sampler: theta[d], log-target, mean[d], cov[d(d+1)/2]
+ * (packed lower triangle, row-major), loga, accepted-count  ->  2d + d(d+1)/2 + 3.                          */
+int phf_single_level_state_size(int model);
+
+/* Start Q*C chains.  Replaces python/PyHillFit.py:748-751,789,796-798,814 (PyHillTemp.py:63-80):
+ *   theta = mean = theta0;  cov = cov_scale*diag(|theta0|) (cov_identity == 0; PyHillFit 0.05) or
+ *   cov_scale*I (cov_identity != 0; PyHillTemp);  log-target of theta0;  loga = 0;  acceptance = 0.
+ *   theta0    device [d][Q*C]
+ *   state     device [S][Q*C]   (S = phf_single_level_state_size)
+ *   row0      device [Q][d+1][C] or NULL: receives chain row 0 = (theta0, log-target)                      */
+int phf_single_level_init(const phf_points* pts, const phf_problems* prob, int model, int cov_identity,
+                          double cov_scale, const double* theta0, double* state, double* row0, void* stream);
+
+/* Run MH iterations t_begin+1 .. t_end for every chain, in lock-step.  Replaces the loop
+ * python/PyHillFit.py:830-856 (python/PyHillTemp.py:87-123).
+ *   state     device [S][Q*C]   read, advanced, written back (so calls can be chained; also the checkpoint)
+ *   rows      device [R][Q][d+1][C] or NULL, R = t_end/thinning - t_begin/thinning: the saved samples
+ *             (theta, log-target) of iterations t with t % thinning == 0, in order (PyHillFit.py:847-848)
+ *   moments   device [2(d+1)][Q*C] or NULL: running sums of x and x*x over the saved samples with
+ *             t > moments_after (on-device replacement for reading the chain file back to get posterior
+ *             means/variances); accumulated into, never zeroed.                                              */
+int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg,
+                             int64_t t_begin, int64_t t_end, double* state, double* rows,
+                             double* moments, int64_t moments_after, void* stream);
+
+/* Batch evaluation of the single-level log-likelihood and log-prior at M parameter vectors.
+ * Replaces calls of dr.log_data_likelihood / dr.log_priors / dr.log_target
+ * (python/doseresponse.py:187-189,203-248,166-184), e.g. the Bayes-factor sweep
+ * python/compute_bayes_factors.py:18-21.
+ *   pair_index  device [M], temperature device [M], theta device [d][M]
+ *   out_lik, out_prior  device [M] (either may be NULL);  log_target = out_lik + out_prior                   */
+int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, const int32_t* pair_index,
+                                const double* temperature, const double* theta, double* out_lik,
+                                double* out_prior, void* stream);
+
+/* Evaluate one of the device elementary functions on an array (parity tests: the device must reproduce the
+ * host build of pyhillfit_amd/csrc/phf_math.h bit for bit).
+ * fn: 0 exp, 1 log, 2 erfcx(y>=0), 3 log_ndtr, 4 ndtr, 5 sqrt, 6 reciprocal, 7 sin(2 pi w/2^32), 8 cos(...)
+ * (for 7/8 the input doubles hold integer values w in [0, 2^32)).                                           */
+int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream);
+
+/* The four Philox words of n (counter, key) tuples: in device uint32 [n][6], out device uint32 [n][4]. */
+int phf_debug_philox(int64_t n, const uint32_t* counter_key, uint32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYHILLFIT_AMD_H */

@@ -1,0 +1,455 @@
+// phf_single_level.hip — gfx950 kernels for PyHillFit's single-level (non-hierarchical) sampler.
+//
+// One lane = one Markov chain.  A 64-lane wavefront advances 64 chains of the SAME (pair, temperature)
+// problem in lock-step, so the dose/response points are wave-uniform: they are staged once per block into
+// LDS and every per-point branch (censored / uncensored) is uniform.  Chain state lives in registers for
+// the whole launch (loaded/stored once, struct-of-arrays, 512 B per wave-instruction); the only traffic
+// inside the loop is the thinned sample store.  No MFMA: this is scalar-per-chain fp64 arithmetic.
+//
+// Arithmetic follows the reference exactly where it defines the result (python/doseresponse.py:84-88,
+// 151-189,203-248,304-317; python/PyHillFit.py:830-848) and uses phf_math.h's fixed-order elementary
+// functions so that the host twin in oracle/ reproduces every chain bit for bit (compile with
+// -ffp-contract=off: every fma below is explicit).
+#include <hip/hip_runtime.h>
+
+#include "../../include/pyhillfit_amd.h"
+#include "phf_common.h"
+#include "phf_math.h"
+#include "phf_philox.h"
+
+namespace {
+
+constexpr double kSigmaFloor = 1e-3;                  // doseresponse.py:12
+constexpr double kPic50Rate = 0.2;                    // doseresponse.py:14
+constexpr double kPic50Lower = -3.0;                  // doseresponse.py:16
+constexpr double kHillUpper = 10.0;                   // doseresponse.py:18
+constexpr double kSigmaLoc = 1e-3;                    // doseresponse.py:24
+constexpr double kSigmaShapeM1 = 4.0;                 // doseresponse.py:22
+constexpr double kSigmaInvScale = 4.0 / (6.0 - 1e-3); // doseresponse.py:25
+
+constexpr int kBlock = 64;
+
+template <int MODEL> struct Dim { static constexpr int d = (MODEL == 1) ? 2 : 3; };
+
+// doseresponse.py:84-85, with (dose/IC50)^hill = exp(hill (ln dose - ln IC50))
+template <int MODEL>
+__device__ __forceinline__ double hill_percent(double ln_conc, double hill, double ln_ic50) {
+  const double a = (MODEL == 1) ? (ln_conc - ln_ic50) : hill * (ln_conc - ln_ic50);
+  const double x = phf_exp(a);
+  const double w = 1.0 / (1.0 + x);
+  return phf_fma(-100.0, w, 100.0);
+}
+
+// doseresponse.py:166-184 (+ :151-156, :304-317)
+template <int MODEL>
+__device__ __forceinline__ double log_prior(const double* th) {
+  const double pic50 = th[0];
+  const double sigma = th[Dim<MODEL>::d - 1];
+  double lp = -kPic50Rate * pic50;
+  if (pic50 < kPic50Lower) lp = -PHF_INF;
+  const double sl = sigma - kSigmaLoc;
+  double g = phf_fma(kSigmaShapeM1, phf_log(sl), -sl * kSigmaInvScale);
+  if (sigma < kSigmaLoc) g = -PHF_INF;
+  lp = lp + g;
+  if (MODEL == 2 && (th[1] < 0.0 || th[1] > kHillUpper)) lp = -PHF_INF;
+  return lp;
+}
+
+// doseresponse.py:203-226 (model 1) / :229-248 (model 2); points grouped other | zero | hundred
+template <int MODEL>
+__device__ __forceinline__ double log_likelihood(const double* lc, const double* y, int n_other, int n_zero,
+                                                 int n_hundred, double pi_bit, double temperature,
+                                                 const double* th) {
+  const double pic50 = th[0];
+  const double hill = (MODEL == 1) ? 1.0 : th[1];
+  const double sigma = th[Dim<MODEL>::d - 1];
+  const double ln_ic50 = PHF_LN10 * (6.0 - pic50);
+  const double inv_s = 1.0 / sigma;
+  double sse = 0.0, lo = 0.0, hi = 0.0;
+  int j = 0;
+  for (int k = 0; k < n_other; ++k, ++j) {
+    const double r = y[j] - hill_percent<MODEL>(lc[j], hill, ln_ic50);
+    sse = phf_fma(r, r, sse);
+  }
+  for (int k = 0; k < n_zero; ++k, ++j)
+    lo += phf_log_ndtr(-hill_percent<MODEL>(lc[j], hill, ln_ic50) * inv_s);
+  for (int k = 0; k < n_hundred; ++k, ++j)
+    hi += phf_log_ndtr((hill_percent<MODEL>(lc[j], hill, ln_ic50) - 100.0) * inv_s);
+  double a = (lo + hi) - pi_bit;
+  a = phf_fma(-(double)n_other, phf_log(sigma), a);
+  a = phf_fma(-sse, 0.5 * inv_s * inv_s, a);
+  double lik = temperature * a;
+  if (sigma <= kSigmaFloor) lik = -PHF_INF;
+  if (temperature == 0.0) lik = 0.0;
+  return lik;
+}
+
+// packed lower-triangular Cholesky, D <= 3, fully unrolled; non-positive pivot -> zero column
+template <int D>
+__device__ __forceinline__ void chol_packed(const double* c, double* l) {
+  double inv[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = c[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s = phf_fma(-l[i * (i + 1) / 2 + k], l[j * (j + 1) / 2 + k], s);
+      if (i == j) {
+        const double r = (s > 0.0) ? phf_sqrt(s) : 0.0;
+        l[i * (i + 1) / 2 + i] = r;
+        inv[i] = (s > 0.0) ? 1.0 / r : 0.0;
+      } else {
+        l[i * (i + 1) / 2 + j] = s * inv[j];
+      }
+    }
+  }
+}
+
+struct AdvanceArgs {
+  phf_points pts;
+  phf_problems prob;
+  phf_mh_config cfg;
+  int64_t t_begin, t_end;
+  double* state;
+  double* rows;
+  double* moments;
+  int64_t moments_after;
+  int32_t blocks_per_problem;
+};
+
+// stage one pair's points into LDS (lc = s_pts, y = s_pts + stride); returns counts
+__device__ __forceinline__ void stage_points(const phf_points& pts, int pair, double* s_pts, int& n_other,
+                                             int& n_zero, int& n_hundred) {
+  const int32_t* cnt = pts.counts + 4 * pair;
+  n_other = cnt[0]; n_zero = cnt[1]; n_hundred = cnt[2];
+  const int n = n_other + n_zero + n_hundred;
+  for (int j = threadIdx.x; j < n; j += kBlock) {
+    s_pts[j] = pts.ln_conc[(size_t)pair * pts.stride + j];
+    s_pts[pts.stride + j] = pts.response[(size_t)pair * pts.stride + j];
+  }
+  __syncthreads();
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a) {
+  constexpr int D = Dim<MODEL>::d;
+  constexpr int NTRI = D * (D + 1) / 2;
+  extern __shared__ double s_pts[];
+  const int q = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - q * a.blocks_per_problem;
+  const int C = a.prob.chains_per_problem;
+  const int c = chunk * kBlock + threadIdx.x;
+  int n_other, n_zero, n_hundred;
+  const int pair = a.prob.pair_index[q];
+  stage_points(a.pts, pair, s_pts, n_other, n_zero, n_hundred);
+  if (c >= C) return;
+  const double* lc = s_pts;
+  const double* yv = s_pts + a.pts.stride;
+  const double pi_bit = a.pts.pi_bit[pair];
+  const double temperature = a.prob.temperature[q];
+  const uint32_t pid = a.prob.problem_id[q];
+  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
+  const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
+  const size_t nchains = (size_t)a.prob.num_problems * C;
+  const size_t g = (size_t)q * C + c;
+
+  // ---- load state (SoA, coalesced) ----
+  double th[D], mean[D], cov[NTRI], L[NTRI];
+  double* sp = a.state + g;
+#pragma unroll
+  for (int i = 0; i < D; ++i) th[i] = sp[(size_t)i * nchains];
+  double lt = sp[(size_t)D * nchains];
+#pragma unroll
+  for (int i = 0; i < D; ++i) mean[i] = sp[(size_t)(D + 1 + i) * nchains];
+#pragma unroll
+  for (int i = 0; i < NTRI; ++i) cov[i] = sp[(size_t)(2 * D + 1 + i) * nchains];
+  double loga = sp[(size_t)(2 * D + 1 + NTRI) * nchains];
+  double nacc = sp[(size_t)(2 * D + 2 + NTRI) * nchains];
+  chol_packed<D>(cov, L);
+  double sc = phf_exp(0.5 * loga);
+
+  double m1[D + 1], m2[D + 1];
+  const bool want_moments = a.moments != nullptr;
+  if (want_moments) {
+#pragma unroll
+    for (int i = 0; i <= D; ++i) {
+      m1[i] = a.moments[(size_t)i * nchains + g];
+      m2[i] = a.moments[(size_t)(D + 1 + i) * nchains + g];
+    }
+  }
+
+  const int thin = a.cfg.thinning;
+  int until_save = thin - (int)(a.t_begin % thin);   // iterations until the next t with t % thin == 0
+  // rows[r][q][f][c]
+  double* out = a.rows ? a.rows + ((size_t)q * (D + 1)) * C + c : nullptr;
+  const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
+
+  for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
+    // ---- proposal: theta* = theta + e^(loga/2) L z  (PyHillFit.py:831) ----
+    double z[4], u;
+    const phf_u32x4 b0 = phf_philox4x32_10(cid, pid, (uint32_t)t, 0u, seed_lo, seed_hi);
+    phf_box_muller(b0.w[0], b0.w[1], &z[0], &z[1]);
+    if (D == 2) {
+      u = phf_uniform53(b0.w[2], b0.w[3]);
+    } else {
+      phf_box_muller(b0.w[2], b0.w[3], &z[2], &z[3]);
+      const phf_u32x4 b1 = phf_philox4x32_10(cid, pid, (uint32_t)t, 1u, seed_lo, seed_hi);
+      u = phf_uniform53(b1.w[0], b1.w[1]);
+    }
+    double star[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double v = L[i * (i + 1) / 2 + i] * z[i];
+#pragma unroll
+      for (int k = i - 1; k >= 0; --k) v = phf_fma(L[i * (i + 1) / 2 + k], z[k], v);
+      star[i] = phf_fma(sc, v, th[i]);
+    }
+    // ---- target and accept test (PyHillFit.py:833-838) ----
+    const double lt_star = log_likelihood<MODEL>(lc, yv, n_other, n_zero, n_hundred, pi_bit, temperature, star) +
+                           log_prior<MODEL>(star);
+    const bool acc = phf_log(u) < lt_star - lt;
+    if (acc) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) th[i] = star[i];
+      lt = lt_star;
+    }
+    nacc += acc ? 1.0 : 0.0;
+    // ---- adaptation (PyHillFit.py:840-846; PyHillTemp.py:114-122) ----
+    if (a.cfg.reset_mean_at_adapt_start && t == a.cfg.adapt_start) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) mean[i] = th[i];
+    }
+    if (t > a.cfg.adapt_start) {
+      const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
+      const double omg = 1.0 - gs;
+      double v[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) v[i] = th[i] - mean[i];
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+          cov[i * (i + 1) / 2 + j] = phf_fma(gs, v[i] * v[j], omg * cov[i * (i + 1) / 2 + j]);
+#pragma unroll
+      for (int i = 0; i < D; ++i) mean[i] = phf_fma(gs, th[i], omg * mean[i]);
+      loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
+      chol_packed<D>(cov, L);
+      sc = phf_exp(0.5 * loga);
+    }
+    // ---- thinning + sample store (PyHillFit.py:847-848) ----
+    if (--until_save == 0) {
+      until_save = thin;
+      if (out) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) out[(size_t)i * C] = th[i];
+        out[(size_t)D * C] = lt;
+        out += row_stride;
+      }
+      if (want_moments && t > a.moments_after) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) { m1[i] += th[i]; m2[i] = phf_fma(th[i], th[i], m2[i]); }
+        m1[D] += lt; m2[D] = phf_fma(lt, lt, m2[D]);
+      }
+    }
+  }
+
+  // ---- store state ----
+#pragma unroll
+  for (int i = 0; i < D; ++i) sp[(size_t)i * nchains] = th[i];
+  sp[(size_t)D * nchains] = lt;
+#pragma unroll
+  for (int i = 0; i < D; ++i) sp[(size_t)(D + 1 + i) * nchains] = mean[i];
+#pragma unroll
+  for (int i = 0; i < NTRI; ++i) sp[(size_t)(2 * D + 1 + i) * nchains] = cov[i];
+  sp[(size_t)(2 * D + 1 + NTRI) * nchains] = loga;
+  sp[(size_t)(2 * D + 2 + NTRI) * nchains] = nacc;
+  if (want_moments) {
+#pragma unroll
+    for (int i = 0; i <= D; ++i) {
+      a.moments[(size_t)i * nchains + g] = m1[i];
+      a.moments[(size_t)(D + 1 + i) * nchains + g] = m2[i];
+    }
+  }
+}
+
+struct InitArgs {
+  phf_points pts;
+  phf_problems prob;
+  int32_t cov_identity;
+  double cov_scale;
+  const double* theta0;
+  double* state;
+  double* row0;
+  int32_t blocks_per_problem;
+};
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
+  constexpr int D = Dim<MODEL>::d;
+  constexpr int NTRI = D * (D + 1) / 2;
+  extern __shared__ double s_pts[];
+  const int q = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - q * a.blocks_per_problem;
+  const int C = a.prob.chains_per_problem;
+  const int c = chunk * kBlock + threadIdx.x;
+  int n_other, n_zero, n_hundred;
+  const int pair = a.prob.pair_index[q];
+  stage_points(a.pts, pair, s_pts, n_other, n_zero, n_hundred);
+  if (c >= C) return;
+  const size_t nchains = (size_t)a.prob.num_problems * C;
+  const size_t g = (size_t)q * C + c;
+  double th[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
+  const double lt = log_likelihood<MODEL>(s_pts, s_pts + a.pts.stride, n_other, n_zero, n_hundred, a.pts.pi_bit[pair],
+                                          a.prob.temperature[q], th) + log_prior<MODEL>(th);
+  double* sp = a.state + g;
+#pragma unroll
+  for (int i = 0; i < D; ++i) { sp[(size_t)i * nchains] = th[i]; sp[(size_t)(D + 1 + i) * nchains] = th[i]; }
+  sp[(size_t)D * nchains] = lt;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j)
+      sp[(size_t)(2 * D + 1 + i * (i + 1) / 2 + j) * nchains] =
+          (i != j) ? 0.0 : (a.cov_identity ? a.cov_scale : a.cov_scale * __builtin_fabs(th[i]));
+  sp[(size_t)(2 * D + 1 + NTRI) * nchains] = 0.0;
+  sp[(size_t)(2 * D + 2 + NTRI) * nchains] = 0.0;
+  if (a.row0) {
+    double* o = a.row0 + ((size_t)q * (D + 1)) * C + c;
+#pragma unroll
+    for (int i = 0; i < D; ++i) o[(size_t)i * C] = th[i];
+    o[(size_t)D * C] = lt;
+  }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, int64_t m, const int32_t* pair_index,
+                                                          const double* temperature, const double* theta,
+                                                          double* out_lik, double* out_prior) {
+  constexpr int D = Dim<MODEL>::d;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const int pair = pair_index[i];
+  const int32_t* cnt = pts.counts + 4 * pair;
+  double th[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
+  if (out_lik)
+    out_lik[i] = log_likelihood<MODEL>(pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride,
+                                       cnt[0], cnt[1], cnt[2], pts.pi_bit[pair], temperature[i], th);
+  if (out_prior) out_prior[i] = log_prior<MODEL>(th);
+}
+
+__global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = in[i];
+  double r, s, c;
+  switch (fn) {
+    case 0: r = phf_exp(x); break;
+    case 1: r = phf_log(x); break;
+    case 2: r = phf_erfcx_nonneg(x); break;
+    case 3: r = phf_log_ndtr(x); break;
+    case 4: r = phf_ndtr(x); break;
+    case 5: r = phf_sqrt(x); break;
+    case 6: r = 1.0 / x; break;
+    case 7: phf_sincos_2pi_u32((uint32_t)x, &s, &c); r = s; break;
+    default: phf_sincos_2pi_u32((uint32_t)x, &s, &c); r = c; break;
+  }
+  out[i] = r;
+}
+
+__global__ void debug_philox_kernel(int64_t n, const uint32_t* ck, uint32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* c = ck + 6 * i;
+  const phf_u32x4 r = phf_philox4x32_10(c[0], c[1], c[2], c[3], c[4], c[5]);
+  for (int k = 0; k < 4; ++k) out[4 * i + k] = r.w[k];
+}
+
+int check_common(const phf_points* pts, const phf_problems* prob, int model) {
+  if (!pts || !prob) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null points/problems");
+  if (model != 1 && model != 2) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "model must be 1 or 2");
+  if (pts->num_pairs <= 0 || pts->stride <= 0 || !pts->ln_conc || !pts->response || !pts->counts || !pts->pi_bit)
+    return phf_fail(PHF_ERR_INVALID_ARGUMENT, "incomplete phf_points");
+  if (prob->num_problems <= 0 || prob->chains_per_problem <= 0 || !prob->pair_index || !prob->temperature || !prob->problem_id)
+    return phf_fail(PHF_ERR_INVALID_ARGUMENT, "incomplete phf_problems");
+  if ((size_t)pts->stride * 16 > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "pair does not fit in LDS");
+  const int64_t bpp = (prob->chains_per_problem + kBlock - 1) / kBlock;
+  if (bpp * prob->num_problems > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
+  return PHF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int phf_version(void) { return PHF_ABI_VERSION; }
+
+int phf_single_level_state_size(int model) {
+  if (model == 1) return 2 * 2 + 3 + 3;
+  if (model == 2) return 2 * 3 + 6 + 3;
+  return phf_fail(PHF_ERR_INVALID_ARGUMENT, "model must be 1 or 2");
+}
+
+int phf_single_level_init(const phf_points* pts, const phf_problems* prob, int model, int cov_identity,
+                          double cov_scale, const double* theta0, double* state, double* row0, void* stream) {
+  if (int rc = check_common(pts, prob, model)) return rc;
+  if (!theta0 || !state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null theta0/state");
+  InitArgs a{*pts, *prob, cov_identity, cov_scale, theta0, state, row0, 0};
+  a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
+  const dim3 grid((unsigned)(a.blocks_per_problem * prob->num_problems)), block(kBlock);
+  const size_t lds = (size_t)pts->stride * 16;
+  if (model == 1) hipLaunchKernelGGL(mh_init_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mh_init_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+  return phf_check_launch("phf_single_level_init");
+}
+
+int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg,
+                             int64_t t_begin, int64_t t_end, double* state, double* rows, double* moments,
+                             int64_t moments_after, void* stream) {
+  if (!cfg) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null config");
+  if (int rc = check_common(pts, prob, cfg->model)) return rc;
+  if (!state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null state");
+  if (cfg->thinning <= 0) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "thinning must be positive");
+  if (t_begin < 0 || t_end < t_begin || t_end > 0xffffffffLL) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad iteration range");
+  if (t_end > cfg->adapt_start && !cfg->gamma) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "gamma table required once adapting");
+  if (t_end == t_begin) return PHF_OK;
+  AdvanceArgs a{*pts, *prob, *cfg, t_begin, t_end, state, rows, moments, moments_after, 0};
+  a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
+  const dim3 grid((unsigned)(a.blocks_per_problem * prob->num_problems)), block(kBlock);
+  const size_t lds = (size_t)pts->stride * 16;
+  if (cfg->model == 1) hipLaunchKernelGGL(mh_advance_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mh_advance_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+  return phf_check_launch("phf_single_level_advance");
+}
+
+int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, const int32_t* pair_index,
+                                const double* temperature, const double* theta, double* out_lik,
+                                double* out_prior, void* stream) {
+  if (!pts || (model != 1 && model != 2) || m < 0 || !pair_index || !temperature || !theta)
+    return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_single_level_log_target");
+  if (m == 0) return PHF_OK;
+  const dim3 grid((unsigned)((m + 255) / 256)), block(256);
+  if (model == 1) hipLaunchKernelGGL(log_target_kernel<1>, grid, block, 0, (hipStream_t)stream, *pts, m, pair_index, temperature, theta, out_lik, out_prior);
+  else hipLaunchKernelGGL(log_target_kernel<2>, grid, block, 0, (hipStream_t)stream, *pts, m, pair_index, temperature, theta, out_lik, out_prior);
+  return phf_check_launch("phf_single_level_log_target");
+}
+
+int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream) {
+  if (fn < 0 || fn > 8 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
+  if (n == 0) return PHF_OK;
+  hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, n, in, out);
+  return phf_check_launch("phf_debug_math");
+}
+
+int phf_debug_philox(int64_t n, const uint32_t* counter_key, uint32_t* out, void* stream) {
+  if (n < 0 || !counter_key || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_philox");
+  if (n == 0) return PHF_OK;
+  hipLaunchKernelGGL(debug_philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, counter_key, out);
+  return phf_check_launch("phf_debug_philox");
+}
+
+}  // extern "C"

@@ -1,0 +1,235 @@
+"""Host driver of the HIP Metropolis-Hastings kernels (single-level / tempered models).
+
+PyTorch is used for device memory and streams only; every number is produced by the kernels behind
+include/pyhillfit_amd.h.  Mirrors the state machine of the reference loops
+(python/PyHillFit.py:748-856, python/PyHillTemp.py:57-125) for Q problems x C chains at once."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .doseresponse import PackedPoints
+
+_GAMMA_CACHE = {}
+
+
+def gamma_table(n):
+    """gamma[s] = 1/(s+1)**0.6, s = 0..n, evaluated with Python float pow exactly like the reference
+    (PyHillFit.py:842 `1/(s+1)**0.6`, PyHillTemp.py:117) — so the adaptation weights are the reference's."""
+    n = int(n)
+    have = _GAMMA_CACHE.get("t")
+    if have is None or len(have) < n + 1:
+        size = max(n + 1, 1024)
+        have = np.array([1.0 / (s + 1.0) ** 0.6 for s in range(size)], dtype=np.float64)
+        _GAMMA_CACHE["t"] = have
+    return have[:n + 1]
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DevicePoints(object):
+    """PackedPoints resident in HBM + the ctypes `phf_points` view of it."""
+
+    def __init__(self, packed, device):
+        self.packed = packed
+        self.device = torch.device(device)
+        self.ln_conc = torch.from_numpy(packed.ln_conc).to(self.device)
+        self.response = torch.from_numpy(packed.response).to(self.device)
+        self.counts = torch.from_numpy(packed.counts).to(self.device)
+        self.pi_bit = torch.from_numpy(packed.pi_bit).to(self.device)
+        self.struct = _lib.Points(packed.num_pairs, packed.stride, self.ln_conc.data_ptr(), self.response.data_ptr(),
+                                  self.counts.data_ptr(), self.pi_bit.data_ptr())
+
+
+def log_target_batch(packed, model, pair_index, temperature, theta, device="cuda"):
+    """(log-likelihood, log-prior) of M parameter vectors on the GPU (phf_single_level_log_target).
+    theta: [M][d] host array.  Returns two numpy arrays [M]."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    pts = packed if isinstance(packed, DevicePoints) else DevicePoints(packed, dev)
+    theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
+    m, d = theta.shape
+    if d != (2 if model == 1 else 3):
+        raise ValueError("theta must have %d columns for model %d" % (2 if model == 1 else 3, model))
+    th = torch.from_numpy(np.ascontiguousarray(theta.T)).to(dev)              # [d][M]
+    pi = torch.from_numpy(np.ascontiguousarray(pair_index, dtype=np.int32)).to(dev)
+    tt = torch.from_numpy(np.ascontiguousarray(temperature, dtype=np.float64)).to(dev)
+    lik = torch.empty(m, dtype=torch.float64, device=dev)
+    pri = torch.empty(m, dtype=torch.float64, device=dev)
+    _lib.check(lib.phf_single_level_log_target(C.byref(pts.struct), model, m, _ptr(pi), _ptr(tt), _ptr(th), _ptr(lik),
+                                               _ptr(pri), _stream_ptr(dev)), "phf_single_level_log_target")
+    return lik.cpu().numpy(), pri.cpu().numpy()
+
+
+class SingleLevelSampler(object):
+    """Q problems x C chains of the adaptive-Metropolis sampler, advanced in lock-step on one GPU.
+
+    problem q = (pair_index[q], temperature[q]); global ids (problem_ids, chain_id_base) select the Philox
+    streams, so a shard of the batch draws the same numbers as the same chains in a bigger launch."""
+
+    def __init__(self, points, model, pair_index, temperature, chains_per_problem, thinning=5, seed=25,
+                 adapt_start=None, reset_mean_at_adapt_start=False, problem_ids=None, chain_id_base=0, device="cuda"):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PhfError("pyhillfit_amd samplers run on a HIP device only (got %s)" % self.device)
+        self.points = points if isinstance(points, DevicePoints) else DevicePoints(points, self.device)
+        self.model = int(model)
+        self.d = 2 if self.model == 1 else 3
+        self.Q = len(pair_index)
+        self.C = int(chains_per_problem)
+        self.thinning = int(thinning)
+        self.seed = int(seed)
+        self.adapt_start = 1000 * self.d if adapt_start is None else int(adapt_start)   # PyHillFit.py:787
+        self.reset_mean = bool(reset_mean_at_adapt_start)
+        dev = self.device
+        self.pair_index = torch.tensor(np.asarray(pair_index, dtype=np.int32), device=dev)
+        self.temperature = torch.tensor(np.asarray(temperature, dtype=np.float64), device=dev)
+        ids = np.arange(self.Q) if problem_ids is None else np.asarray(problem_ids)
+        self.problem_ids = torch.tensor(ids.astype(np.int64), device=dev).to(torch.int32)   # bit pattern of uint32
+        self.prob = _lib.Problems(self.Q, self.C, self.pair_index.data_ptr(), self.temperature.data_ptr(),
+                                  self.problem_ids.data_ptr(), int(chain_id_base) & 0xFFFFFFFF, 0)
+        self.S = self.lib.phf_single_level_state_size(self.model)
+        self.state = torch.zeros((self.S, self.Q * self.C), dtype=torch.float64, device=dev)
+        self.moments = None
+        self.moments_after = 0
+        self.t = 0
+        self.row0 = None
+        self._gamma = None
+
+    # -- start: PyHillFit.py:748-751,789,814 / PyHillTemp.py:63-80 --------------------------------------------
+    def init(self, theta0, cov_identity=False, cov_scale=0.05):
+        """theta0: [d] (every chain), [Q][d] (per problem) or [Q][C][d]."""
+        th = torch.as_tensor(np.asarray(theta0, dtype=np.float64), device=self.device)
+        if th.dim() == 1:
+            th = th.view(1, 1, self.d).expand(self.Q, self.C, self.d)
+        elif th.dim() == 2:
+            th = th.view(self.Q, 1, self.d).expand(self.Q, self.C, self.d)
+        th = th.permute(2, 0, 1).reshape(self.d, self.Q * self.C).contiguous()             # SoA [d][Q*C]
+        self.row0 = torch.empty((self.Q, self.d + 1, self.C), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.phf_single_level_init(C.byref(self.points.struct), C.byref(self.prob), self.model,
+                                                  int(bool(cov_identity)), float(cov_scale), _ptr(th), _ptr(self.state),
+                                                  _ptr(self.row0), _stream_ptr(self.device)), "phf_single_level_init")
+        self.t = 0
+        return self.row0
+
+    def enable_moments(self, after_iteration=0):
+        """accumulate sum x, sum x^2 of the saved samples with t > after_iteration, per chain, on the device"""
+        self.moments = torch.zeros((2 * (self.d + 1), self.Q * self.C), dtype=torch.float64, device=self.device)
+        self.moments_after = int(after_iteration)
+
+    def _config(self, t_end):
+        need = max(0, t_end - self.adapt_start)
+        if self._gamma is None or self._gamma.numel() < need + 1:
+            self._gamma = torch.from_numpy(gamma_table(max(need, 1))).to(self.device)
+        return _lib.MhConfig(self.model, self.thinning, self.adapt_start, int(self.reset_mean), 0, self.seed,
+                             self._gamma.data_ptr())
+
+    def reserve(self, total_iterations):
+        """size the gamma table once for a whole run (keeps advance() free of allocations)"""
+        self._config(int(total_iterations))
+
+    def rows_between(self, t_begin, t_end):
+        return t_end // self.thinning - t_begin // self.thinning
+
+    def advance(self, n_iterations, out=None, save=True):
+        """Run n_iterations more MH iterations on every chain.  Returns the saved rows [R][Q][d+1][C]
+        (None if save=False).  `out` may be a preallocated tensor of that shape."""
+        t_end = self.t + int(n_iterations)
+        cfg = self._config(t_end)
+        rows = None
+        if save:
+            r = self.rows_between(self.t, t_end)
+            shape = (r, self.Q, self.d + 1, self.C)
+            if out is None:
+                rows = torch.empty(shape, dtype=torch.float64, device=self.device)
+            else:
+                if tuple(out.shape) != shape or not out.is_contiguous():
+                    raise ValueError("out must be contiguous with shape %s" % (shape,))
+                rows = out
+        _lib.check(self.lib.phf_single_level_advance(C.byref(self.points.struct), C.byref(self.prob), C.byref(cfg),
+                                                     self.t, t_end, _ptr(self.state), _ptr(rows), _ptr(self.moments),
+                                                     self.moments_after, _stream_ptr(self.device)),
+                   "phf_single_level_advance")
+        self.t = t_end
+        return rows
+
+    def run(self, iterations, segment=None):
+        """Whole chain like the reference keeps it: [iterations/thinning + 1][Q][d+1][C], row 0 = start point."""
+        if iterations % self.thinning:
+            raise ValueError("iterations must be a multiple of thinning (PyHillFit.py:805)")
+        self.reserve(self.t + iterations)
+        n_rows = iterations // self.thinning + 1
+        chain = torch.empty((n_rows, self.Q, self.d + 1, self.C), dtype=torch.float64, device=self.device)
+        chain[0] = self.row0
+        seg = iterations if segment is None else int(segment)
+        seg = max(self.thinning, seg - seg % self.thinning)
+        done, r = 0, 1
+        while done < iterations:
+            k = min(seg, iterations - done)
+            nr = self.rows_between(self.t, self.t + k)
+            self.advance(k, out=chain[r:r + nr])
+            done += k; r += nr
+        return chain
+
+    # -- views of the state ---------------------------------------------------------------------------------
+    def theta(self):
+        return self.state[:self.d].view(self.d, self.Q, self.C)
+
+    def log_target(self):
+        return self.state[self.d].view(self.Q, self.C)
+
+    def loga(self):
+        return self.state[2 * self.d + 1 + self.d * (self.d + 1) // 2].view(self.Q, self.C)
+
+    def acceptance(self):
+        """running acceptance rate (PyHillFit.py:839) per chain"""
+        return self.state[-1].view(self.Q, self.C) / max(self.t, 1)
+
+    def posterior_moments(self):
+        """(mean, variance, n) per chain from the on-device accumulators: [d+1][Q][C]"""
+        if self.moments is None:
+            raise _lib.PhfError("enable_moments() was not called")
+        n = self.t // self.thinning - self.moments_after // self.thinning
+        k = self.d + 1
+        s1 = self.moments[:k].view(k, self.Q, self.C); s2 = self.moments[k:].view(k, self.Q, self.C)
+        mean = s1 / n
+        var = (s2 - s1 * mean) / max(n - 1, 1)
+        return mean, var, n
+
+    def state_dict(self):
+        """checkpoint: everything needed to continue bit-identically"""
+        return {"state": self.state.clone(), "t": self.t, "moments": None if self.moments is None else self.moments.clone(),
+                "moments_after": self.moments_after, "seed": self.seed}
+
+    def load_state_dict(self, sd):
+        self.state.copy_(sd["state"]); self.t = int(sd["t"]); self.seed = int(sd["seed"])
+        if sd.get("moments") is not None:
+            self.moments = sd["moments"].clone().to(self.device); self.moments_after = int(sd["moments_after"])
+
+
+def debug_math(fn, x, device="cuda"):
+    lib = _lib.load()
+    dev = torch.device(device)
+    xin = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
+    out = torch.empty_like(xin)
+    _lib.check(lib.phf_debug_math(int(fn), xin.numel(), _ptr(xin), _ptr(out), _stream_ptr(dev)), "phf_debug_math")
+    return out.cpu().numpy()
+
+
+def debug_philox(counter_key, device="cuda"):
+    lib = _lib.load()
+    dev = torch.device(device)
+    ck = np.ascontiguousarray(counter_key, dtype=np.uint32).reshape(-1, 6)
+    cin = torch.from_numpy(ck.view(np.int32)).to(dev)
+    out = torch.empty((ck.shape[0], 4), dtype=torch.int32, device=dev)
+    _lib.check(lib.phf_debug_philox(ck.shape[0], _ptr(cin), _ptr(out), _stream_ptr(dev)), "phf_debug_philox")
+    return out.cpu().numpy().view(np.uint32)

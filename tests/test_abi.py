@@ -1,0 +1,77 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every
+function include/pyhillfit_amd.h declares; argument validation works without touching a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from pyhillfit_amd import _lib
+    return _lib.load()
+
+
+def _declared():
+    with open(os.path.join(REPO, "include", "pyhillfit_amd.h")) as f:
+        src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(phf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from pyhillfit_amd import _lib
+    names = _declared()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_version_and_state_sizes(lib):
+    assert lib.phf_version() == 1
+    assert lib.phf_single_level_state_size(1) == 10      # 2+1+2+3+1+1
+    assert lib.phf_single_level_state_size(2) == 15      # 3+1+3+6+1+1
+    assert lib.phf_single_level_state_size(3) < 0
+    assert b"model" in lib.phf_last_error()
+
+
+def test_argument_validation_without_gpu(lib):
+    from pyhillfit_amd import _lib
+    rc = lib.phf_single_level_advance(None, None, None, 0, 10, None, None, None, 0, None)
+    assert rc == -1 and b"null" in lib.phf_last_error()
+    pts = _lib.Points(1, 16, 1, 1, 1, 1)
+    prob = _lib.Problems(1, 64, 1, 1, 1, 0, 0)
+    cfg = _lib.MhConfig(5, 5, 3000, 0, 0, 25, None)
+    assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
+    cfg.model = 2; cfg.thinning = 0
+    assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
+    cfg.thinning = 5
+    assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 4000, 1, None, None, 0, None) == -1
+    assert b"gamma" in lib.phf_last_error()
+    pts.stride = 20000                                    # 320 KB of points cannot be staged in a CU's LDS
+    assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -3
+    with pytest.raises(_lib.PhfError):
+        _lib.check(-1, "x")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from pyhillfit_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpyhillfit_amd.so")
+    with pytest.raises(_lib.PhfError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_sampler_refuses_cpu_device(lib):
+    import numpy as np
+    from pyhillfit_amd.doseresponse import PackedPoints
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    from pyhillfit_amd._lib import PhfError
+    packed = PackedPoints([(np.array([0.1, 1.0]), np.array([10.0, 60.0]))])
+    with pytest.raises(PhfError, match="HIP device only"):
+        SingleLevelSampler(packed, 2, [0], [1.0], 64, device="cpu")

@@ -1,0 +1,232 @@
+"""GPU parity tests proper (-m gpu): the HIP path, through the C ABI, against the oracle.
+
+Bar: bit-exact against the scalar CPU twin (same Philox stream, same fixed-order fp64 arithmetic); <= 1e-12
+relative against the reference's golden log-targets; posterior means within 1 % of the reference's long runs."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pyhillfit_amd import _lib
+    _lib.load()                      # fails loudly if the HIP library is missing
+    return "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def dr(gpu):
+    from pyhillfit_amd import doseresponse as d
+    d.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    return d
+
+
+def _pair_arrays(dr, drug, channel):
+    ne, _, ex = dr.load_crumb_data(drug, channel)
+    return dr.concatenate_experiments(ne, ex)
+
+
+# ------------------------------------------------------------------------------------------------- leaf numerics
+def test_device_math_bit_identical_to_host_build(gpu):
+    from oracle import c_oracle as co
+    from pyhillfit_amd.sampler import debug_math
+    rng = np.random.default_rng(11)
+    n = 400000
+    cases = {
+        0: ("exp", np.concatenate([rng.uniform(-746, 710, n), rng.uniform(-3, 3, n), [0.0, -0.0, 709.782712893384, -745.13, -745.2, -744.4, np.inf, -np.inf]])),
+        1: ("log", np.concatenate([np.exp(rng.uniform(-744, 709, n)), rng.uniform(0.4, 2.2, n), [0.0, 5e-324, 2.2e-308, 1.0, np.inf, -1.0]])),
+        2: ("erfcx", np.concatenate([np.exp(rng.uniform(-30, 12, n)), rng.uniform(0, 10, n), [0.0, 4.0, 1e99, 1e101, 1e300]])),
+        3: ("log_ndtr", np.concatenate([-np.exp(rng.uniform(-30, 12, n)), rng.uniform(-40, 40, n), [0.0, -1e5, 38.5]])),
+        4: ("ndtr", rng.uniform(-40, 40, n)),
+        5: ("sqrt", np.concatenate([np.exp(rng.uniform(-700, 700, n)), rng.uniform(0, 4, n), [0.0, 5e-324, 1e-310]])),
+    }
+    for fn, (name, x) in cases.items():
+        got, want = debug_math(fn, x, gpu), co.vec(name, x)
+        assert np.array_equal(got, want, equal_nan=True), "%s: %d mismatches" % (name, int((got != want).sum()))
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, n)), -np.exp(rng.uniform(-5, 5, n))])
+    assert np.array_equal(debug_math(6, x, gpu), 1.0 / x)                      # IEEE division
+    w = rng.integers(0, 2 ** 32, n, dtype=np.uint64)
+    w[:6] = [0, 2 ** 28 - 1, 2 ** 28, 2 ** 31, 2 ** 32 - 1, 2 ** 32 - 2 ** 28]
+    s, c = co.sincos(w.astype(np.uint32))
+    assert np.array_equal(debug_math(7, w.astype(np.float64), gpu), s)
+    assert np.array_equal(debug_math(8, w.astype(np.float64), gpu), c)
+
+
+def test_device_philox_known_answers(gpu):
+    from oracle import c_oracle as co
+    from pyhillfit_amd.sampler import debug_philox
+    ck = np.random.default_rng(5).integers(0, 2 ** 32, (10000, 6), dtype=np.uint64).astype(np.uint32)
+    ck[0] = 0; ck[1] = 0xffffffff
+    ck[2] = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0]
+    got = debug_philox(ck, gpu)
+    assert got[0].tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert got[1].tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert got[2].tolist() == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert np.array_equal(got, co.philox(ck))
+
+
+# ------------------------------------------------------------------------------------------------- log-target
+def test_log_target_batch_vs_reference_golden_and_twin(gpu, dr, golden_meta):
+    from oracle import c_oracle as co
+    from pyhillfit_amd.sampler import log_target_batch
+    g = np.load(os.path.join(GOLDEN, "g1_log_target.npz"))
+    names = [(m["drug"], m["channel"]) for m in golden_meta["g1_pairs"]]
+    packed = dr.pack_single_level(names)
+    for model in (1, 2):
+        sel = g["model"] == model
+        th = g["theta"][sel] if model == 2 else g["theta"][sel][:, [0, 2]]
+        lik, pri = log_target_batch(packed, model, g["pair"][sel], g["t"][sel], th, gpu)
+        for got, want in ((lik, g["lik"][sel]), (pri, g["prior"][sel]), (lik + pri, g["target"][sel])):
+            bad = ~np.isfinite(want)
+            assert np.array_equal(got[bad], want[bad], equal_nan=True)
+            np.testing.assert_allclose(got[~bad], want[~bad], rtol=1e-12, atol=0)
+        # and bit-identical to the CPU twin
+        packs = {}
+        tw = np.empty(sel.sum())
+        for k, (ip, t, row) in enumerate(zip(g["pair"][sel], g["t"][sel], th)):
+            key = (int(ip), float(t))
+            if key not in packs:
+                packs[key] = co.PackedPair(*_pair_arrays(dr, *names[int(ip)]), model, float(t))
+            tw[k] = packs[key].log_target(row)
+        assert np.array_equal(lik + pri, tw, equal_nan=True)
+
+
+def test_reference_signature_log_target(gpu, dr):
+    """dr.log_target(y, where_y_0, where_y_100, where_y_other, concs, params, t, pi_bit) as the reference's
+    callers use it (doseresponse.py:187-189); probe values from SURVEY.md section 8c."""
+    concs, y = _pair_arrays(dr, "Amiodarone", "hERG")
+    w0, w100, wo = dr.response_masks(y)
+    pi_bit = dr.compute_pi_bit_of_log_likelihood(wo)
+    assert pi_bit == 11.027262398456072
+    dr.define_model(2)
+    probes = [((6, 1, 5), 1, -58.39140921642633), ((6.2, 0.7, 8), 1, -38.16481071511112),
+              ((1, 1, 1), 1, -12946.405169647265), ((6, 1, 5), 0.125, -5.633162956781316), ((6, 1, 5), 0, 1.9037293660251158)]
+    for th, t, want in probes:
+        assert dr.log_target(y, w0, w100, wo, concs, np.array(th, float), t, pi_bit) == pytest.approx(want, rel=1e-12)
+    for th in [(5.5, 11, 3), (-3.5, 1, 2), (6, 1, 5e-4)]:
+        assert dr.log_target(y, w0, w100, wo, concs, np.array(th, float), 1, pi_bit) == -np.inf
+    dr.define_model(1)
+    assert np.isfinite(dr.log_target(y, w0, w100, wo, concs, np.array([6., 5.]), 1, pi_bit))
+
+
+# ------------------------------------------------------------------------------------------------- the MH loop
+CASES = [  # (model, pairs, temps-per-pair, chains, iterations, thinning, adapt_start, reset_mean, cov_identity, cov_scale, theta0)
+    (2, [("Amiodarone", "hERG"), ("Bepridil", "hERG"), ("Moxifloxacin", "KvLQT1/mink")], [1.0, 0.125], 192, 1500, 5, 400, False, False, 0.05, [6.0, 0.8, 8.0]),
+    (1, [("Amiodarone", "hERG"), ("Rufinamide", "Kir2.1")], [1.0, 0.0], 70, 1200, 3, 300, True, True, 1.0, [1.0, 1.0]),
+    (2, [("Amitriptyline", "Kv4.3"), ("Lidocaine", "KvLQT1/mink")], [1.0], 64, 900, 1, 200, True, True, 1.0, [1.0, 1.0, 1.0]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_chains_bit_identical_to_cpu_twin(case, gpu, dr):
+    """same seed => same accept sequence, same samples, same log-targets, same final state, bit for bit;
+    the GPU run is cut into uneven launches to cover the state hand-over between kernels."""
+    from oracle import c_oracle as co
+    from pyhillfit_amd.sampler import SingleLevelSampler, gamma_table
+    model, names, temps, C, T, thin, adapt, reset, cov_id, cov_scale, theta0 = CASES[case]
+    packed = dr.pack_single_level(names)
+    pair_index = [p for p in range(len(names)) for _ in temps]
+    temperature = [t for _ in names for t in temps]
+    s = SingleLevelSampler(packed, model, pair_index, temperature, C, thinning=thin, seed=1234567890123, adapt_start=adapt,
+                           reset_mean_at_adapt_start=reset, chain_id_base=1000, problem_ids=np.arange(len(pair_index)) + 7,
+                           device=gpu)
+    s.init(theta0, cov_identity=cov_id, cov_scale=cov_scale)
+    row0 = s.row0.cpu().numpy()
+    parts = [s.advance(k).cpu().numpy() for k in (adapt - 7, 8, 1, T - adapt - 2)]
+    chain = np.concatenate(parts)                                  # [T/thin][Q][d+1][C]
+    assert chain.shape == (T // thin, len(pair_index), s.d + 1, C)
+    state = s.state.cpu().numpy().reshape(s.S, len(pair_index), C)
+    gam = gamma_table(T)
+    rng = np.random.default_rng(case)
+    for q in range(len(pair_index)):
+        pk = co.PackedPair(*_pair_arrays(dr, *names[pair_index[q]]), model, temperature[q])
+        for c in [0, C - 1] + rng.integers(0, C, 2).tolist():
+            st = pk.init_state(theta0, cov_id, cov_scale)
+            assert np.array_equal(row0[q, :, c], np.concatenate([theta0, [st[s.d]]]))
+            rows = pk.advance(st, 0, T, thin, adapt, reset, gam, seed=1234567890123, chain_id=1000 + c, problem_id=7 + q)
+            assert np.array_equal(chain[:, q, :, c], rows), (q, c)
+            assert np.array_equal(state[:, q, c], st), (q, c)
+    assert 0.01 < float(s.acceptance().mean()) < 0.95
+
+
+def test_shard_invariance_and_resume_full_width(gpu, dr):
+    """BASELINE config 2 width (65 536 chains of Amiodarone-hERG): the same chains computed (a) in one launch,
+    (b) as two half-batches with chain_id_base — the multi-GPU partition — and (c) through a checkpoint/restore
+    give identical bits (size-independent property; the twin covers correctness at small sizes)."""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    packed = dr.pack_single_level([("Amiodarone", "hERG")])
+    C, T = 65536, 60
+    kw = dict(thinning=5, seed=25, adapt_start=20, device=gpu)
+    full = SingleLevelSampler(packed, 2, [0], [1.0], C, **kw)
+    full.init([6.0, 0.8, 8.0])
+    a = full.run(T)
+    halves = []
+    for h in range(2):
+        s = SingleLevelSampler(packed, 2, [0], [1.0], C // 2, chain_id_base=h * (C // 2), **kw)
+        s.init([6.0, 0.8, 8.0])
+        halves.append(s.run(T))
+    assert torch.equal(a, torch.cat(halves, dim=3))
+    r = SingleLevelSampler(packed, 2, [0], [1.0], C, **kw)
+    r.init([6.0, 0.8, 8.0])
+    first = r.advance(35)
+    sd = r.state_dict()
+    r2 = SingleLevelSampler(packed, 2, [0], [1.0], C, **kw)
+    r2.load_state_dict(sd)
+    second = r2.advance(25)
+    assert torch.equal(a[1:], torch.cat([first, second]))
+    assert torch.isfinite(a).all()
+    # distinct chains really are distinct streams
+    assert torch.unique(a[-1, 0, 0, :]).numel() > 0.9 * C
+
+
+# ------------------------------------------------------------------------------------------------- statistics
+def test_posterior_means_within_one_percent_of_reference(gpu, dr):
+    """north-star tolerance: posterior means within 1 % of the CPU reference (tests/golden/g5_posteriors.json,
+    reference do_mcmc 200k iterations) — 2 048 chains x 200k iterations per problem (as long as the reference run:
+    Hill has rare long excursions), pooled, moments accumulated on the device."""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    with open(os.path.join(GOLDEN, "g5_posteriors.json")) as f:
+        g5 = json.load(f)
+    for model in (1, 2):
+        want = [w for w in g5 if w["model"] == model and w["temperature"] in (1.0, 0.125)]
+        names = [(w["drug"], w["channel"]) for w in want]
+        packed = dr.pack_single_level(names)
+        s = SingleLevelSampler(packed, model, list(range(len(names))), [w["temperature"] for w in want], 2048, thinning=5,
+                               seed=25, reset_mean_at_adapt_start=True, device=gpu)
+        s.init(np.ones(s.d), cov_identity=True, cov_scale=1.0)      # PyHillTemp start
+        s.enable_moments(after_iteration=50000)
+        s.advance(200000, save=False)
+        mean, var, n = s.posterior_moments()
+        pooled = mean.mean(dim=2).cpu().numpy()                      # [d+1][Q]
+        pooled_sd = torch.sqrt(var.mean(dim=2) + mean.var(dim=2)).cpu().numpy()
+        for q, w in enumerate(want):
+            ref_se = np.array(w["sd"][:s.d]) / np.sqrt(w["rows"] / 20.0)     # the reference is ONE chain
+            err = np.abs(pooled[:s.d, q] - w["mean"][:s.d])
+            assert np.all(err <= 0.01 * np.abs(w["mean"][:s.d]) + 3 * ref_se), (w["drug"], model, pooled[:, q], w["mean"])
+            np.testing.assert_allclose(pooled_sd[:s.d, q], w["sd"][:s.d], rtol=0.2)
+
+
+def test_prior_only_rung_known_answer(gpu, dr):
+    """t = 0 (first rung of the ladder): chains must sample the prior — pIC50 ~ -3+Exp(mean 5), Hill ~ U(0,10),
+    sigma ~ 1e-3+Gamma(5, 1.49975): means (2, 5, 7.49975), sds (5, 2.887, 3.354)."""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    packed = dr.pack_single_level([("Amiodarone", "hERG")])
+    s = SingleLevelSampler(packed, 2, [0], [0.0], 4096, thinning=5, seed=3, reset_mean_at_adapt_start=True, device=gpu)
+    s.init(np.ones(3), cov_identity=True, cov_scale=1.0)
+    s.enable_moments(after_iteration=20000)
+    s.advance(100000, save=False)
+    mean, var, n = s.posterior_moments()
+    m = mean.mean(dim=2).cpu().numpy()[:3, 0]
+    sd = torch.sqrt(var.mean(dim=2) + mean.var(dim=2)).cpu().numpy()[:3, 0]
+    np.testing.assert_allclose(m, [2.0, 5.0, 7.49975], rtol=0.03)
+    np.testing.assert_allclose(sd, [5.0, 10 / np.sqrt(12), np.sqrt(5) * 1.49975], rtol=0.04)

@@ -1,0 +1,97 @@
+"""Host-side logic (no GPU): data loading/packing mirror of python/doseresponse.py against the reference's
+own loader output (tests/golden/g4_pairs.json), path helpers, gamma table."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def dr():
+    from pyhillfit_amd import doseresponse as d
+    d.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    return d
+
+
+def test_setup_and_load_match_reference_loader(dr, g4_pairs):
+    assert len(dr.drugs) == 30 and len(dr.channels) == 7 and dr.dir_name == "crumb_dataset"
+    assert dr.drugs[0] == "Amiodarone" and dr.channels[0] == "hERG"
+    for (d, c), g in g4_pairs.items():
+        ne, nums, ex = dr.load_crumb_data(d, c)
+        assert ne == g["num_expts"] and [len(e) for e in ex] == g["expt_sizes"] and nums[0] == 0
+        concs, y = dr.concatenate_experiments(ne, ex)
+        assert np.array_equal(concs, g["concs"]) and np.array_equal(y, g["responses"])
+        w0, w100, wo = dr.response_masks(y)
+        assert (w0.sum(), w100.sum(), wo.sum()) == (g["n0"], g["n100"], g["n_other"])
+        assert dr.compute_pi_bit_of_log_likelihood(wo) == g["pi_bit"]
+    with pytest.raises(ValueError):
+        dr.load_crumb_data("NoSuchDrug", "hERG")
+
+
+def test_csv_round_trip(dr, tmp_path):
+    """the CLI's --data-file is the reference CSV format (data/readme.md): same table through a CSV"""
+    p = tmp_path / "crumb_data.csv"
+    dr.table.to_csv(str(p))
+    with open(p) as f:
+        assert f.readline().strip() == "Compound,Channel,Experiment,Dose,Response"
+    t = dr.Table.from_csv(str(p))
+    assert np.array_equal(t.dose, dr.table.dose) and np.array_equal(t.response, dr.table.response)
+    assert list(t.drug) == list(dr.table.drug) and np.array_equal(t.experiment, dr.table.experiment)
+
+
+def test_packing_groups_points_like_the_masks(dr, g4_pairs):
+    names = list(g4_pairs)
+    pk = dr.pack_single_level(names)
+    assert pk.num_pairs == 210 and pk.stride == 20
+    for p, key in enumerate(names):
+        g = g4_pairs[key]
+        n_other, n0, n100, ntot = pk.counts[p]
+        assert (n_other, n0, n100, ntot) == (g["n_other"], g["n0"], g["n100"], g["n_total"])
+        y = np.array(g["responses"]); c = np.array(g["concs"])
+        assert np.array_equal(pk.response[p, :n_other], y[(y > 0) & (y < 100)])
+        assert np.array_equal(pk.ln_conc[p, :n_other], np.log(c[(y > 0) & (y < 100)]))
+        assert np.all(pk.response[p, n_other:n_other + n0] == 0) and np.all(pk.response[p, n_other + n0:n_other + n0 + n100] == 100)
+        assert pk.pi_bit[p] == g["pi_bit"]
+    # the -2.6 response (crumb_data.csv:155) is in no mask: dropped from the points, still counted in pi_bit
+    p = names.index(("Amitriptyline", "Kv4.3"))
+    assert pk.counts[p].tolist() == [17, 1, 0, 19]
+
+
+def test_zero_dose_and_empty_groups():
+    from pyhillfit_amd.doseresponse import PackedPoints
+    pk = PackedPoints([(np.array([0.0, 1.0, 10.0]), np.array([0.0, 50.0, 100.0])), (np.array([1.0]), np.array([0.0]))])
+    assert pk.ln_conc[0, 1] == -np.inf and pk.counts.tolist() == [[1, 1, 1, 3], [0, 1, 0, 1]]
+
+
+def test_output_paths_follow_the_reference_contract(dr, tmp_path, monkeypatch):
+    monkeypatch.setattr(dr, "output_root", str(tmp_path / "output"))
+    drug, channel, chain_file, images_dir = dr.nonhierarchical_chain_file_and_figs_dir(2, "Moxifloxacin", "KvLQT1/mink", 1)
+    assert channel == "KvLQT1_mink"
+    assert chain_file.endswith("output/crumb_dataset/single-level/Moxifloxacin/KvLQT1_mink/model_2/temperature_1/chain/"
+                               "Moxifloxacin_KvLQT1_mink_model_2_temp_1_chain_single-level.txt")
+    assert os.path.isdir(images_dir)
+    _, _, f2, _ = dr.nonhierarchical_chain_file_and_figs_dir(1, "Amiodarone", "hERG", dr.temperature_ladder()[1])
+    t1 = repr(float(dr.temperature_ladder()[1]))     # PyHillTemp formats the float itself into the path
+    assert "temperature_%s/" % t1 in f2 and f2.endswith("_temp_%s_chain_single-level.txt" % t1) and t1.startswith("1.5625")
+    d, c, out, chain_dir, figs, cf = dr.hierarchical_output_dirs_and_chain_file("Amiodarone", "hERG", 3)
+    assert cf.endswith("output/crumb_dataset/hierarchical/Amiodarone/hERG/3_expts/chain/crumb_dataset_Amiodarone_hERG_hierarchical_chain.txt")
+    assert dr.alpha_mu_downsampling("Amiodarone", "hERG").endswith("hierarchical/alpha_mu_samples/Amiodarone_hERG_hill_pic50_samples.txt")
+
+
+def test_gamma_table_is_the_reference_expression():
+    from pyhillfit_amd.sampler import gamma_table
+    g = gamma_table(5000)
+    for s in (1, 2, 17, 4999):
+        assert g[s] == 1 / (s + 1) ** 0.6            # PyHillFit.py:842
+    assert len(gamma_table(10)) == 11
+
+
+def test_ladder_and_models(dr):
+    lad = dr.temperature_ladder()
+    assert len(lad) == 41 and lad[1] == (1 / 40.) ** 3 and len(dr.temperature_ladder(31)) == 32
+    dr.define_model(1); assert dr.num_params == 2 and dr.file_labels == ['pIC50', 'sigma']
+    dr.define_model(2); assert dr.num_params == 3
+    with pytest.raises(ValueError):
+        dr.define_model(3)
