@@ -115,6 +115,7 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
 /* Evaluate one of the device elementary functions on an array (parity tests: the device must reproduce the
  * host build of pyhillfit_amd/csrc/phf_math.h bit for bit).
  * fn: 0 exp, 1 log, 2 erfcx(y>=0), 3 log_ndtr, 4 ndtr, 5 sqrt, 6 reciprocal, 7 sin(2 pi w/2^32), 8 cos(...)
+ * 9 exp_fast, 10 log_fast, 11 log_ndtr_nonpos — the branch-free forms the kernels use
  * (for 7/8 the input doubles hold integer values w in [0, 2^32)).                                           */
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream);
 

@@ -74,7 +74,7 @@ class PackedPair:
 
     def log_prior(self, theta):
         th = np.ascontiguousarray(theta, dtype=np.float64)
-        return lib().phfo_log_prior(self.pb.model, _p(th))
+        return lib().phfo_log_prior(C.byref(self.pb), _p(th))
 
     def init_state(self, theta0, cov_identity, cov_scale):
         st = np.zeros(lib().phfo_state_size(self.d))
@@ -118,6 +118,7 @@ def philox(ctr_key):
 
 
 def draws(d, chain_id, problem_id, t, seed=25):
-    z = np.zeros(4); u = C.c_double()
-    lib().phfo_draws(d, chain_id, problem_id, t, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, _p(z), C.byref(u))
-    return z, u.value
+    """(z[4], log u) of MH iteration t"""
+    z = np.zeros(4); lu = C.c_double()
+    lib().phfo_draws(d, chain_id, problem_id, t, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, _p(z), C.byref(lu))
+    return z, lu.value

@@ -8,10 +8,12 @@
  *   priors and log-target                     python/doseresponse.py:151-189,304-317
  *   adaptive Metropolis loop                  python/PyHillFit.py:796-856, python/PyHillTemp.py:76-123
  *   hierarchical target and loop              python/PyHillFit.py:113-193,429-511
- * It is written independently of the device code (own loops, own likelihood) and shares with it
- * only the leaf numerics — phf_math.h (fixed-order fp64 exp/log/erfcx/sincos) and phf_philox.h —
- * so that "same seed => same accept sequence and bit-identical chain" is a meaningful test of the
- * GPU kernels.  PINNED two ways (tests/test_oracle_c.py): log-targets against the reference golden
+ * The chain state machine (start, proposal assembly, Cholesky factor, accept rule, adaptation, thinning,
+ * segment hand-over) is written independently of the device code.  The log-target and the per-iteration
+ * draws come from the SAME source the kernels compile (phf_model.h on top of phf_math.h / phf_philox.h):
+ * their evaluation order is tuned for the fp64 VALU and only a shared source can keep two builds bit-identical,
+ * which is what makes "same seed => same accept sequence and bit-identical chain" testable on the GPU.
+ * What pins that shared arithmetic to the reference is below, not the sharing.  PINNED two ways (tests/test_oracle_c.py): log-targets against the reference golden
  * vectors (<= 1e-12 relative), and the loop against reference traces by replaying the recorded
  * proposals/uniforms draw by draw.  Compile: see oracle/Makefile (-ffp-contract=off -mfma).
  */
@@ -19,16 +21,7 @@
 #include <stddef.h>
 #include <string.h>
 
-#include "../pyhillfit_amd/csrc/phf_math.h"
-#include "../pyhillfit_amd/csrc/phf_philox.h"
-
-#define SIGMA_FLOOR 1e-3                /* doseresponse.py:12  */
-#define PIC50_RATE 0.2                  /* doseresponse.py:14  */
-#define PIC50_LOWER (-3.0)              /* doseresponse.py:16  */
-#define HILL_UPPER 10.0                 /* doseresponse.py:18  */
-#define SIGMA_LOC 1e-3                  /* doseresponse.py:24  */
-#define SIGMA_SHAPE_M1 4.0              /* doseresponse.py:22 (shape-1) */
-#define SIGMA_INV_SCALE (4.0 / (6.0 - 1e-3)) /* 1/scale, doseresponse.py:25 */
+#include "../pyhillfit_amd/csrc/phf_model.h"
 
 typedef struct {
   int32_t model;                        /* 1: (pIC50, sigma), Hill = 1;  2: (pIC50, Hill, sigma) */
@@ -49,58 +42,18 @@ typedef struct {
   const double* gamma;                  /* gamma[s] = 1/(s+1)^0.6, s >= 1 */
 } phfo_run;
 
-/* ---------------------------------------------------------------- model library */
-static double hill_percent(double ln_conc, double hill, double ln_ic50, int model) {
-  /* doseresponse.py:84-85 with (dose/IC50)^hill = exp(hill (ln dose - ln IC50)) */
-  const double a = (model == 1) ? (ln_conc - ln_ic50) : hill * (ln_conc - ln_ic50);
-  const double x = phf_exp(a);
-  const double w = 1.0 / (1.0 + x);
-  return phf_fma(-100.0, w, 100.0);
+/* ---------------------------------------------------------------- model library (shared source: phf_model.h) */
+static void target_parts(const phfo_problem* pb, const double* th, double* lik, double* prior) {
+  phf_sl_log_target(pb->model, pb->ln_conc, pb->response, pb->n_other, pb->n_zero + pb->n_hundred, pb->pi_bit,
+                    pb->temperature, th, lik, prior);
 }
 
-double phfo_log_prior(int model, const double* th) {
-  const double pic50 = th[0];
-  const double sigma = (model == 1) ? th[1] : th[2];
-  double lp = -PIC50_RATE * pic50;                          /* doseresponse.py:151-156 */
-  if (pic50 < PIC50_LOWER) lp = -PHF_INF;
-  const double sl = sigma - SIGMA_LOC;                       /* doseresponse.py:304-317 */
-  double g = phf_fma(SIGMA_SHAPE_M1, phf_log(sl), -sl * SIGMA_INV_SCALE);
-  if (sigma < SIGMA_LOC) g = -PHF_INF;
-  lp = lp + g;
-  if (model == 2 && (th[1] < 0.0 || th[1] > HILL_UPPER)) lp = -PHF_INF;  /* doseresponse.py:181-182 */
-  return lp;
-}
+double phfo_log_prior(const phfo_problem* pb, const double* th) { double l, p; target_parts(pb, th, &l, &p); return p; }
 
-double phfo_log_likelihood(const phfo_problem* pb, const double* th) {
-  const int model = pb->model;
-  const double pic50 = th[0];
-  const double hill = (model == 1) ? 1.0 : th[1];
-  const double sigma = (model == 1) ? th[1] : th[2];
-  if (pb->temperature == 0.0) return 0.0;                   /* doseresponse.py:204,230 */
-  const double ln_ic50 = PHF_LN10 * (6.0 - pic50);          /* doseresponse.py:87-88 */
-  const double inv_s = 1.0 / sigma;
-  const double* lc = pb->ln_conc;
-  const double* y = pb->response;
-  double sse = 0.0, lo = 0.0, hi = 0.0;
-  int j = 0;
-  for (int k = 0; k < pb->n_other; ++k, ++j) {               /* :247 */
-    const double r = y[j] - hill_percent(lc[j], hill, ln_ic50, model);
-    sse = phf_fma(r, r, sse);
-  }
-  for (int k = 0; k < pb->n_zero; ++k, ++j)                  /* :244  logcdf(0, pred, sigma) */
-    lo += phf_log_ndtr(-hill_percent(lc[j], hill, ln_ic50, model) * inv_s);
-  for (int k = 0; k < pb->n_hundred; ++k, ++j)               /* :245  logsf(100, pred, sigma) */
-    hi += phf_log_ndtr((hill_percent(lc[j], hill, ln_ic50, model) - 100.0) * inv_s);
-  double a = (lo + hi) - pb->pi_bit;
-  a = phf_fma(-(double)pb->n_other, phf_log(sigma), a);      /* :246 */
-  a = phf_fma(-sse, 0.5 * inv_s * inv_s, a);
-  double lik = pb->temperature * a;                          /* :248 */
-  if (sigma <= SIGMA_FLOOR) lik = -PHF_INF;                  /* :238-240 */
-  return lik;
-}
+double phfo_log_likelihood(const phfo_problem* pb, const double* th) { double l, p; target_parts(pb, th, &l, &p); return l; }
 
 double phfo_log_target(const phfo_problem* pb, const double* th) {  /* doseresponse.py:187-189 */
-  return phfo_log_likelihood(pb, th) + phfo_log_prior(pb->model, th);
+  double l, p; target_parts(pb, th, &l, &p); return l + p;
 }
 
 /* ---------------------------------------------------------------- proposal factor */
@@ -150,7 +103,7 @@ void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, doubl
   double* loga = cov + ntri; double* nacc = loga + 1;
   double L[6], z[4], star[3];
   chol_packed(d, cov, L);
-  double sc = phf_exp(0.5 * *loga);
+  double sc = phf_exp_fast(0.5 * *loga);
   int64_t row = 0;
   for (int64_t t = run->t_begin + 1; t <= run->t_end; ++t) {
     if (scaled_cov_trace) {
@@ -159,21 +112,13 @@ void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, doubl
       for (int i = 0; i < d; ++i)
         for (int j = 0; j < d; ++j) o[i * d + j] = e * cov[(i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i];
     }
-    double u;
+    double log_u;
     if (star_replay) {
       for (int i = 0; i < d; ++i) star[i] = star_replay[(t - run->t_begin - 1) * d + i];
-      u = u_replay[t - run->t_begin - 1];
+      log_u = phf_log(u_replay[t - run->t_begin - 1]);
     } else {
       /* PyHillFit.py:831 — theta* ~ N(theta, e^loga cov) drawn as theta + e^(loga/2) L z */
-      const phf_u32x4 b0 = phf_philox4x32_10(run->chain_id, run->problem_id, (uint32_t)t, 0u, run->seed_lo, run->seed_hi);
-      phf_box_muller(b0.w[0], b0.w[1], &z[0], &z[1]);
-      if (d == 2) {
-        u = phf_uniform53(b0.w[2], b0.w[3]);
-      } else {
-        phf_box_muller(b0.w[2], b0.w[3], &z[2], &z[3]);
-        const phf_u32x4 b1 = phf_philox4x32_10(run->chain_id, run->problem_id, (uint32_t)t, 1u, run->seed_lo, run->seed_hi);
-        u = phf_uniform53(b1.w[0], b1.w[1]);
-      }
+      log_u = phf_mh_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, z);
       for (int i = 0; i < d; ++i) {
         double yv = L[i * (i + 1) / 2 + i] * z[i];
         for (int k = i - 1; k >= 0; --k) yv = phf_fma(L[i * (i + 1) / 2 + k], z[k], yv);
@@ -181,7 +126,7 @@ void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, doubl
       }
     }
     const double lt_star = phfo_log_target(pb, star);                      /* :833 */
-    const int acc = phf_log(u) < lt_star - *lt;                            /* :834-838 */
+    const int acc = log_u < lt_star - *lt;                            /* :834-838 */
     if (acc) { for (int i = 0; i < d; ++i) th[i] = star[i]; *lt = lt_star; }
     *nacc += (double)acc;
     if (run->reset_mean && t == run->adapt_start)                          /* PyHillTemp.py:114-115 */
@@ -196,7 +141,7 @@ void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, doubl
       for (int i = 0; i < d; ++i) mean[i] = phf_fma(g, th[i], omg * mean[i]);
       *loga = phf_fma(g, (double)acc - 0.25, *loga);
       chol_packed(d, cov, L);
-      sc = phf_exp(0.5 * *loga);
+      sc = phf_exp_fast(0.5 * *loga);
     }
     if (t % run->thinning == 0) {                                          /* :847-848 */
       for (int i = 0; i < d; ++i) out_rows[row * (d + 1) + i] = th[i];
@@ -214,6 +159,13 @@ VEC1(phfo_vec_erfcx, phf_erfcx_nonneg)
 VEC1(phfo_vec_log_ndtr, phf_log_ndtr)
 VEC1(phfo_vec_ndtr, phf_ndtr)
 VEC1(phfo_vec_sqrt, phf_sqrt)
+VEC1(phfo_vec_exp_fast, phf_exp_fast)
+VEC1(phfo_vec_log_fast, phf_log_fast)
+VEC1(phfo_vec_log_ndtr_nonpos, phf_log_ndtr_nonpos)
+
+void phfo_vec_log_ndtr_nonpos_x2(int64_t n, const double* x, double* out) {
+  for (int64_t i = 0; i + 1 < n; i += 2) phf_log_ndtr_nonpos_x2(x[i], x[i + 1], &out[i], &out[i + 1]);
+}
 
 void phfo_vec_sincos(int64_t n, const uint32_t* w, double* sn, double* cs) {
   for (int64_t i = 0; i < n; ++i) phf_sincos_2pi_u32(w[i], &sn[i], &cs[i]);
@@ -227,13 +179,8 @@ void phfo_philox(int64_t n, const uint32_t* ctr_key /* [n][6] */, uint32_t* out 
   }
 }
 
-/* the normals and the uniform of iteration t of a chain, exactly as phfo_advance draws them */
+/* the normals and log(u) of iteration t of a chain, exactly as the samplers draw them */
 void phfo_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
-                double* z /* [4] */, double* u) {
-  const phf_u32x4 b0 = phf_philox4x32_10(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
-  phf_box_muller(b0.w[0], b0.w[1], &z[0], &z[1]);
-  if (d == 2) { *u = phf_uniform53(b0.w[2], b0.w[3]); z[2] = z[3] = 0.0; return; }
-  phf_box_muller(b0.w[2], b0.w[3], &z[2], &z[3]);
-  const phf_u32x4 b1 = phf_philox4x32_10(chain_id, problem_id, t, 1u, seed_lo, seed_hi);
-  *u = phf_uniform53(b1.w[0], b1.w[1]);
+                double* z /* [4] */, double* log_u) {
+  *log_u = phf_mh_draws(d, chain_id, problem_id, t, seed_lo, seed_hi, z);
 }

@@ -1,0 +1,153 @@
+/* phf_model.h — the single-level Hill-curve log-target and the per-iteration random draws, written once
+ * and compiled both into the gfx950 kernels and into the host twin (oracle/), so the two evaluate the very
+ * same fp64 operation sequence.
+ *
+ * What it computes is the reference's (python/doseresponse.py):
+ *   dose_response_model :84-85, pic50_to_ic50 :87-88, log_data_likelihood_model_{1,2}_capped :203-248,
+ *   log_priors_model_{1,2} :166-184, log_pic50_exponential :151-156, log_gamma_prior :304-317.
+ * How it computes it is shaped for the fp64 VALU (see phf_math.h): per-point work is done 4 (uncensored) or
+ * 2 (censored) points at a time so independent polynomial chains interleave, and the IEEE divisions of a
+ * group — 1/(1+x) of the Hill curve, the erfcx and log reciprocals — are shared through a product tree
+ * (one division + a few multiplies instead of one division each; ~26 ns vs ~2 ns per wave-instruction).
+ *
+ * Point layout (include/pyhillfit_amd.h, phf_points): n_other uncensored points first (0 < y < 100), then the
+ * n_cens censored ones (y == 0, then y == 100).  Arrays must be readable up to index n_other + n_cens - 1.
+ */
+#ifndef PHF_MODEL_H
+#define PHF_MODEL_H
+
+#include "phf_math.h"
+#include "phf_philox.h"
+
+#define PHF_SIGMA_FLOOR 1e-3                    /* sigma_uniform_lower, doseresponse.py:12  */
+#define PHF_PIC50_RATE 0.2                      /* doseresponse.py:14  */
+#define PHF_PIC50_LOWER (-3.0)                  /* doseresponse.py:16  */
+#define PHF_HILL_UPPER 10.0                     /* doseresponse.py:18  */
+#define PHF_SIGMA_LOC 1e-3                      /* doseresponse.py:24  */
+#define PHF_SIGMA_SHAPE_M1 4.0                  /* sigma_shape - 1, doseresponse.py:22 */
+#define PHF_SIGMA_INV_SCALE (4.0 / (6.0 - 1e-3)) /* 1/sigma_scale, doseresponse.py:25 */
+#define PHF_HILL_ARG_CAP 40.0                   /* exp(40): 100/(1+x) already rounds pred to exactly 100 */
+
+/* Hill-curve denominator 1 + (dose/IC50)^hill = 1 + exp(hill (ln dose - ln IC50))   (doseresponse.py:84-88) */
+PHF_HD double phf_hill_den(int model, double ln_conc, double hill, double ln_ic50) {
+  const double a = (model == 1) ? (ln_conc - ln_ic50) : hill * (ln_conc - ln_ic50);
+  return 1.0 + phf_exp_fast(__builtin_fmin(a, PHF_HILL_ARG_CAP));
+}
+
+/* percent block from w = 1/(1 + x):  100 (1 - w) */
+PHF_HD double phf_hill_percent(double w) { return phf_fma(-100.0, w, 100.0); }
+
+/* z-score of a censored point: y == 0 -> (0 - pred)/sigma (logcdf, :244); y == 100 -> (pred - 100)/sigma (logsf, :245) */
+PHF_HD double phf_censored_z(double pred, double y, double inv_s) {
+  const double sgn = (y > 50.0) ? 1.0 : -1.0;
+  return (sgn * (pred - y)) * inv_s;
+}
+
+/* log-likelihood (tempered) and log-prior of one parameter vector.
+ * model 1: th = (pIC50, sigma), Hill = 1;  model 2: th = (pIC50, Hill, sigma).                               */
+PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int n_other, int n_cens,
+                              double pi_bit, double temperature, const double* th, double* out_lik,
+                              double* out_prior) {
+  const double pic50 = th[0];
+  const double hill = (model == 1) ? 1.0 : th[1];
+  const double sigma = (model == 1) ? th[1] : th[2];
+  const double ln_ic50 = PHF_LN10 * (6.0 - pic50);
+  /* one division for 1/sigma, log sigma and log(sigma - loc) */
+  const double sl = sigma - PHF_SIGMA_LOC;
+  const phf_logred lr_s = phf_log_reduce(sigma), lr_l = phf_log_reduce(sl);
+  const double ds = 2.0 + lr_s.f, dl = 2.0 + lr_l.f;
+  const double p1 = sigma * ds;
+  const double inv3 = 1.0 / (p1 * dl);
+  const double i1 = inv3 * dl;                    /* 1/(sigma ds) */
+  const double inv_s = i1 * ds;
+  const double log_sigma = phf_log_finish(lr_s, lr_s.f * (i1 * sigma));
+  const double log_sl = phf_log_finish(lr_l, lr_l.f * (inv3 * p1));
+
+  double sse = 0.0, cens = 0.0;
+  int j = 0;
+  for (; j + 4 <= n_other; j += 4) {              /* uncensored points, four at a time (:247) */
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50);
+    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50);
+    const double p01 = d0 * d1, p23 = d2 * d3;
+    const double inv = 1.0 / (p01 * p23);
+    const double i01 = inv * p23, i23 = inv * p01;
+    const double r0 = y[j] - phf_hill_percent(i01 * d1), r1 = y[j + 1] - phf_hill_percent(i01 * d0);
+    const double r2 = y[j + 2] - phf_hill_percent(i23 * d3), r3 = y[j + 3] - phf_hill_percent(i23 * d2);
+    sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse); sse = phf_fma(r2, r2, sse); sse = phf_fma(r3, r3, sse);
+  }
+  for (; j < n_other; ++j) {
+    const double r = y[j] - phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50));
+    sse = phf_fma(r, r, sse);
+  }
+  const int n = n_other + n_cens;
+  for (; j + 2 <= n; j += 2) {                    /* censored points, two at a time (:244-245) */
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50);
+    const double inv = 1.0 / (d0 * d1);
+    const double z0 = phf_censored_z(phf_hill_percent(inv * d1), y[j], inv_s);
+    const double z1 = phf_censored_z(phf_hill_percent(inv * d0), y[j + 1], inv_s);
+    double l0, l1;
+    phf_log_ndtr_nonpos_x2(z0, z1, &l0, &l1);
+    cens += l0; cens += l1;
+  }
+  for (; j < n; ++j) {
+    const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50));
+    cens += phf_log_ndtr_nonpos(phf_censored_z(pred, y[j], inv_s));
+  }
+  double a = cens - pi_bit;
+  a = phf_fma(-(double)n_other, log_sigma, a);                           /* :246 */
+  a = phf_fma(-sse, 0.5 * inv_s * inv_s, a);                             /* :247 */
+  double lik = temperature * a;                                          /* :248 */
+  if (sigma <= PHF_SIGMA_FLOOR) lik = -PHF_INF;                          /* :238-240 */
+  if (temperature == 0.0) lik = 0.0;                                     /* :230-231 */
+  *out_lik = lik;
+
+  double lp = -PHF_PIC50_RATE * pic50;                                   /* :151-156 */
+  if (pic50 < PHF_PIC50_LOWER) lp = -PHF_INF;
+  double g = phf_fma(PHF_SIGMA_SHAPE_M1, log_sl, -sl * PHF_SIGMA_INV_SCALE);   /* :304-317 */
+  if (sigma <= PHF_SIGMA_LOC) g = -PHF_INF;                              /* x < loc -> -inf; x == loc -> log 0 = -inf */
+  lp = lp + g;
+  if (model == 2 && (hill < 0.0 || hill > PHF_HILL_UPPER)) lp = -PHF_INF; /* :181-182 */
+  *out_prior = lp;
+}
+
+/* The random numbers of MH iteration t of one chain: d standard normals (Box-Muller on Philox words) and
+ * log(u) of the accept uniform (PyHillFit.py:831,834-835).  One shared division for the three logarithms.
+ * d == 2 uses one Philox block, d == 3 two.  z has room for 4 values (z[3] is the unused Box-Muller mate).  */
+PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
+                           uint32_t seed_hi, double* z) {
+  const phf_u32x4 b0 = phf_philox4x32_10(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
+  double u, ub;
+  uint32_t ang_b = 0u;
+  if (d == 2) {
+    u = phf_uniform53(b0.w[2], b0.w[3]);
+    ub = 0.5;
+  } else {
+    const phf_u32x4 b1 = phf_philox4x32_10(chain_id, problem_id, t, 1u, seed_lo, seed_hi);
+    u = phf_uniform53(b1.w[0], b1.w[1]);
+    ub = phf_unit_open32(b0.w[2]);
+    ang_b = b0.w[3];
+  }
+  const double ua = phf_unit_open32(b0.w[0]);
+  const phf_logred la = phf_log_reduce(ua), lb = phf_log_reduce(ub), lu = phf_log_reduce(u);
+  const double da = 2.0 + la.f, db = 2.0 + lb.f, du = 2.0 + lu.f;
+  const double pab = da * db;
+  const double inv = 1.0 / (pab * du);
+  const double iab = inv * du;
+  const double log_ua = phf_log_finish(la, la.f * (iab * db));
+  double sn, cs;
+  phf_sincos_2pi_u32(b0.w[1], &sn, &cs);
+  const double ra = phf_sqrt(-2.0 * log_ua);
+  z[0] = ra * cs; z[1] = ra * sn;
+  if (d == 2) {
+    z[2] = 0.0; z[3] = 0.0;
+  } else {
+    const double log_ub = phf_log_finish(lb, lb.f * (iab * da));
+    phf_sincos_2pi_u32(ang_b, &sn, &cs);
+    const double rb = phf_sqrt(-2.0 * log_ub);
+    z[2] = rb * cs; z[3] = rb * sn;
+  }
+  const double log_u = phf_log_finish(lu, lu.f * (inv * pab));
+  return (u < PHF_DBL_MIN) ? -PHF_INF : log_u;       /* u == 0 (probability 2^-53): log 0 = -inf, accept */
+}
+
+#endif /* PHF_MODEL_H */

@@ -14,75 +14,13 @@
 
 #include "../../include/pyhillfit_amd.h"
 #include "phf_common.h"
-#include "phf_math.h"
-#include "phf_philox.h"
+#include "phf_model.h"
 
 namespace {
-
-constexpr double kSigmaFloor = 1e-3;                  // doseresponse.py:12
-constexpr double kPic50Rate = 0.2;                    // doseresponse.py:14
-constexpr double kPic50Lower = -3.0;                  // doseresponse.py:16
-constexpr double kHillUpper = 10.0;                   // doseresponse.py:18
-constexpr double kSigmaLoc = 1e-3;                    // doseresponse.py:24
-constexpr double kSigmaShapeM1 = 4.0;                 // doseresponse.py:22
-constexpr double kSigmaInvScale = 4.0 / (6.0 - 1e-3); // doseresponse.py:25
 
 constexpr int kBlock = 64;
 
 template <int MODEL> struct Dim { static constexpr int d = (MODEL == 1) ? 2 : 3; };
-
-// doseresponse.py:84-85, with (dose/IC50)^hill = exp(hill (ln dose - ln IC50))
-template <int MODEL>
-__device__ __forceinline__ double hill_percent(double ln_conc, double hill, double ln_ic50) {
-  const double a = (MODEL == 1) ? (ln_conc - ln_ic50) : hill * (ln_conc - ln_ic50);
-  const double x = phf_exp(a);
-  const double w = 1.0 / (1.0 + x);
-  return phf_fma(-100.0, w, 100.0);
-}
-
-// doseresponse.py:166-184 (+ :151-156, :304-317)
-template <int MODEL>
-__device__ __forceinline__ double log_prior(const double* th) {
-  const double pic50 = th[0];
-  const double sigma = th[Dim<MODEL>::d - 1];
-  double lp = -kPic50Rate * pic50;
-  if (pic50 < kPic50Lower) lp = -PHF_INF;
-  const double sl = sigma - kSigmaLoc;
-  double g = phf_fma(kSigmaShapeM1, phf_log(sl), -sl * kSigmaInvScale);
-  if (sigma < kSigmaLoc) g = -PHF_INF;
-  lp = lp + g;
-  if (MODEL == 2 && (th[1] < 0.0 || th[1] > kHillUpper)) lp = -PHF_INF;
-  return lp;
-}
-
-// doseresponse.py:203-226 (model 1) / :229-248 (model 2); points grouped other | zero | hundred
-template <int MODEL>
-__device__ __forceinline__ double log_likelihood(const double* lc, const double* y, int n_other, int n_zero,
-                                                 int n_hundred, double pi_bit, double temperature,
-                                                 const double* th) {
-  const double pic50 = th[0];
-  const double hill = (MODEL == 1) ? 1.0 : th[1];
-  const double sigma = th[Dim<MODEL>::d - 1];
-  const double ln_ic50 = PHF_LN10 * (6.0 - pic50);
-  const double inv_s = 1.0 / sigma;
-  double sse = 0.0, lo = 0.0, hi = 0.0;
-  int j = 0;
-  for (int k = 0; k < n_other; ++k, ++j) {
-    const double r = y[j] - hill_percent<MODEL>(lc[j], hill, ln_ic50);
-    sse = phf_fma(r, r, sse);
-  }
-  for (int k = 0; k < n_zero; ++k, ++j)
-    lo += phf_log_ndtr(-hill_percent<MODEL>(lc[j], hill, ln_ic50) * inv_s);
-  for (int k = 0; k < n_hundred; ++k, ++j)
-    hi += phf_log_ndtr((hill_percent<MODEL>(lc[j], hill, ln_ic50) - 100.0) * inv_s);
-  double a = (lo + hi) - pi_bit;
-  a = phf_fma(-(double)n_other, phf_log(sigma), a);
-  a = phf_fma(-sse, 0.5 * inv_s * inv_s, a);
-  double lik = temperature * a;
-  if (sigma <= kSigmaFloor) lik = -PHF_INF;
-  if (temperature == 0.0) lik = 0.0;
-  return lik;
-}
 
 // packed lower-triangular Cholesky, D <= 3, fully unrolled; non-positive pivot -> zero column
 template <int D>
@@ -144,6 +82,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
   const int pair = a.prob.pair_index[q];
   stage_points(a.pts, pair, s_pts, n_other, n_zero, n_hundred);
   if (c >= C) return;
+  const int n_cens = n_zero + n_hundred;
   const double* lc = s_pts;
   const double* yv = s_pts + a.pts.stride;
   const double pi_bit = a.pts.pi_bit[pair];
@@ -167,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
   double loga = sp[(size_t)(2 * D + 1 + NTRI) * nchains];
   double nacc = sp[(size_t)(2 * D + 2 + NTRI) * nchains];
   chol_packed<D>(cov, L);
-  double sc = phf_exp(0.5 * loga);
+  double sc = phf_exp_fast(0.5 * loga);
 
   double m1[D + 1], m2[D + 1];
   const bool want_moments = a.moments != nullptr;
@@ -187,16 +126,8 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
 
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
     // ---- proposal: theta* = theta + e^(loga/2) L z  (PyHillFit.py:831) ----
-    double z[4], u;
-    const phf_u32x4 b0 = phf_philox4x32_10(cid, pid, (uint32_t)t, 0u, seed_lo, seed_hi);
-    phf_box_muller(b0.w[0], b0.w[1], &z[0], &z[1]);
-    if (D == 2) {
-      u = phf_uniform53(b0.w[2], b0.w[3]);
-    } else {
-      phf_box_muller(b0.w[2], b0.w[3], &z[2], &z[3]);
-      const phf_u32x4 b1 = phf_philox4x32_10(cid, pid, (uint32_t)t, 1u, seed_lo, seed_hi);
-      u = phf_uniform53(b1.w[0], b1.w[1]);
-    }
+    double z[4];
+    const double log_u = phf_mh_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, z);
     double star[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -206,9 +137,10 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
       star[i] = phf_fma(sc, v, th[i]);
     }
     // ---- target and accept test (PyHillFit.py:833-838) ----
-    const double lt_star = log_likelihood<MODEL>(lc, yv, n_other, n_zero, n_hundred, pi_bit, temperature, star) +
-                           log_prior<MODEL>(star);
-    const bool acc = phf_log(u) < lt_star - lt;
+    double lik_star, prior_star;
+    phf_sl_log_target(MODEL, lc, yv, n_other, n_cens, pi_bit, temperature, star, &lik_star, &prior_star);
+    const double lt_star = lik_star + prior_star;
+    const bool acc = log_u < lt_star - lt;
     if (acc) {
 #pragma unroll
       for (int i = 0; i < D; ++i) th[i] = star[i];
@@ -235,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
       for (int i = 0; i < D; ++i) mean[i] = phf_fma(gs, th[i], omg * mean[i]);
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
       chol_packed<D>(cov, L);
-      sc = phf_exp(0.5 * loga);
+      sc = phf_exp_fast(0.5 * loga);
     }
     // ---- thinning + sample store (PyHillFit.py:847-848) ----
     if (--until_save == 0) {
@@ -302,8 +234,10 @@ __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
   double th[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
-  const double lt = log_likelihood<MODEL>(s_pts, s_pts + a.pts.stride, n_other, n_zero, n_hundred, a.pts.pi_bit[pair],
-                                          a.prob.temperature[q], th) + log_prior<MODEL>(th);
+  double lik0, prior0;
+  phf_sl_log_target(MODEL, s_pts, s_pts + a.pts.stride, n_other, n_zero + n_hundred, a.pts.pi_bit[pair], a.prob.temperature[q],
+                    th, &lik0, &prior0);
+  const double lt = lik0 + prior0;
   double* sp = a.state + g;
 #pragma unroll
   for (int i = 0; i < D; ++i) { sp[(size_t)i * nchains] = th[i]; sp[(size_t)(D + 1 + i) * nchains] = th[i]; }
@@ -336,10 +270,11 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
   double th[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
-  if (out_lik)
-    out_lik[i] = log_likelihood<MODEL>(pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride,
-                                       cnt[0], cnt[1], cnt[2], pts.pi_bit[pair], temperature[i], th);
-  if (out_prior) out_prior[i] = log_prior<MODEL>(th);
+  double lik, prior;
+  phf_sl_log_target(MODEL, pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride, cnt[0],
+                    cnt[1] + cnt[2], pts.pi_bit[pair], temperature[i], th, &lik, &prior);
+  if (out_lik) out_lik[i] = lik;
+  if (out_prior) out_prior[i] = prior;
 }
 
 __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* out) {
@@ -356,6 +291,9 @@ __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* o
     case 5: r = phf_sqrt(x); break;
     case 6: r = 1.0 / x; break;
     case 7: phf_sincos_2pi_u32((uint32_t)x, &s, &c); r = s; break;
+    case 9: r = phf_exp_fast(x); break;
+    case 10: r = phf_log_fast(x); break;
+    case 11: r = phf_log_ndtr_nonpos(x); break;
     default: phf_sincos_2pi_u32((uint32_t)x, &s, &c); r = c; break;
   }
   out[i] = r;
@@ -439,7 +377,7 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
 }
 
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream) {
-  if (fn < 0 || fn > 8 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
+  if (fn < 0 || fn > 11 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
   if (n == 0) return PHF_OK;
   hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, n, in, out);
   return phf_check_launch("phf_debug_math");

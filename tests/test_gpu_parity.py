@@ -49,6 +49,9 @@ def test_device_math_bit_identical_to_host_build(gpu):
         3: ("log_ndtr", np.concatenate([-np.exp(rng.uniform(-30, 12, n)), rng.uniform(-40, 40, n), [0.0, -1e5, 38.5]])),
         4: ("ndtr", rng.uniform(-40, 40, n)),
         5: ("sqrt", np.concatenate([np.exp(rng.uniform(-700, 700, n)), rng.uniform(0, 4, n), [0.0, 5e-324, 1e-310]])),
+        9: ("exp_fast", np.concatenate([rng.uniform(-760, 720, n), rng.uniform(-3, 3, n), [np.nan, np.inf, -np.inf]])),
+        10: ("log_fast", np.concatenate([np.exp(rng.uniform(-708, 709, n)), rng.uniform(-1, 2, n), [0.0, 1e-310]])),
+        11: ("log_ndtr_nonpos", np.concatenate([-np.exp(rng.uniform(-30, 11.6, n)), rng.uniform(-40, 0, n), [0.0, -1e5]])),
     }
     for fn, (name, x) in cases.items():
         got, want = debug_math(fn, x, gpu), co.vec(name, x)
