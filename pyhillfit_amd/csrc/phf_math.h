@@ -8,8 +8,8 @@
  *
  * Shaped for CDNA4's fp64 VALU (measured with tools/microbench.hip on MI355X: v_fma_f64 2.25 ns per
  * wave-instruction per SIMD, v_mov_b64 2.1 ns, IEEE division ~26 ns, v_rcp/v_sqrt_f64 7 ns):
- *   - polynomial steps use PHF_FMA_C, a literal 3-operand v_fma_f64: hipcc otherwise emits
- *     "v_mov_b64 acc, coef ; v_fmac_f64 acc, p, t" for a constant addend, i.e. two fp64-rate instructions per term;
+ *   - polynomial steps are literal 3-operand v_fma_f64 with the coefficient in an SGPR pair fetched through the
+ *     scalar cache (PHF_KLOAD / PHF_FMA_K below);
  *   - polynomials are split into even/odd halves (two independent dependency chains) so a lone wave on a
  *     SIMD is not latency-bound;
  *   - the *_fast / *_core entry points used inside the kernels are branch-free: range problems are handled by
@@ -38,11 +38,23 @@
 #define PHF_HD static inline __attribute__((always_inline))
 #endif
 
-/* p*t + c with a constant addend c */
+/* Polynomial coefficients live in constant memory and reach the VALU through the scalar cache:
+ *   PHF_KLOAD(table)   one s_load_dwordx{4,8,16} burst into SGPRs, issued where the polynomial starts (the empty
+ *                      asm makes the table address opaque, so the loads are neither hoisted out of the MH loop
+ *                      nor kept alive across it: ~100 coefficients would otherwise pin 200+ registers);
+ *   PHF_FMA_K(p,t,c)   p*t + c as a literal 3-operand v_fma_f64 whose addend is that SGPR pair.
+ * hipcc on its own emits "v_mov_b64 acc, coef ; v_fmac_f64 acc, p, t" for a constant addend — two fp64-rate
+ * instructions per term.  On the host both macros are plain C.                                             */
 #if defined(__HIP_DEVICE_COMPILE__)
-#define PHF_FMA_C(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "v"((double)(c))); phf_r_; })
+typedef const double __attribute__((address_space(4))) * phf_ktab;
+#define PHF_KTABLE static __device__ __constant__ const double
+#define PHF_KLOAD(name) __extension__({ phf_ktab phf_p_ = (phf_ktab)(name); asm volatile("" : "+s"(phf_p_)); phf_p_; })
+#define PHF_FMA_K(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "s"(c)); phf_r_; })
 #else
-#define PHF_FMA_C(p, t, c) __builtin_fma((p), (t), (c))
+typedef const double* phf_ktab;
+#define PHF_KTABLE static const double
+#define PHF_KLOAD(name) (name)
+#define PHF_FMA_K(p, t, c) __builtin_fma((p), (t), (c))
 #endif
 
 #define PHF_INF (__builtin_inf())
@@ -67,28 +79,34 @@ PHF_HD double phf_pow2i(int k) { return phf_from_bits((uint64_t)(k + 1023) << 52
  * (approximation error 1.6e-17 relative on |r| <= ln2/2), scaled by 2^k in two multiplications so that
  * subnormal results round once.  The argument is clamped to [-746, 710]: the scaling then overflows to +inf /
  * underflows to 0 by itself, no branches.  phf_exp_fast(NaN) = 0 (min/max drop the NaN); phf_exp keeps NaN. */
-PHF_HD double phf_exp_fast(double x) {
+PHF_KTABLE phf_k_exp[10] = {   /* (exp(r)-1-r)/r^2, coefficient of r^i */
+    0x1.0000000000001p-1, 0x1.5555555555556p-3, 0x1.5555555553d63p-5, 0x1.11111111109b3p-7, 0x1.6c16c1788bd90p-10,
+    0x1.a01a01a7c41d5p-13, 0x1.a019b90d2ae7ap-16, 0x1.71de0dae63bb3p-19, 0x1.289185613a3d6p-22, 0x1.af38a9b0ec855p-26};
+
+PHF_HD double phf_exp_fast_k(double x, phf_ktab k) {
   const double xc = __builtin_fmin(__builtin_fmax(x, -746.0), 710.0);
   const double kd = __builtin_rint(xc * PHF_LOG2E);
   double r = phf_fma(kd, -PHF_LN2_HI, xc);
   r = phf_fma(kd, -PHF_LN2_LO, r);
   const double r2 = r * r;
-  double qe = 0x1.289185613a3d6p-22;              /* even coefficients c8 c6 c4 c2 c0 in r^2 */
-  qe = PHF_FMA_C(qe, r2, 0x1.a019b90d2ae7ap-16);
-  qe = PHF_FMA_C(qe, r2, 0x1.6c16c1788bd90p-10);
-  qe = PHF_FMA_C(qe, r2, 0x1.5555555553d63p-5);
-  qe = PHF_FMA_C(qe, r2, 0x1.0000000000001p-1);
-  double qo = 0x1.af38a9b0ec855p-26;              /* odd coefficients c9 c7 c5 c3 c1 */
-  qo = PHF_FMA_C(qo, r2, 0x1.71de0dae63bb3p-19);
-  qo = PHF_FMA_C(qo, r2, 0x1.a01a01a7c41d5p-13);
-  qo = PHF_FMA_C(qo, r2, 0x1.11111111109b3p-7);
-  qo = PHF_FMA_C(qo, r2, 0x1.5555555555556p-3);
+  double qe = k[8];                               /* even coefficients in r^2 */
+  qe = PHF_FMA_K(qe, r2, k[6]);
+  qe = PHF_FMA_K(qe, r2, k[4]);
+  qe = PHF_FMA_K(qe, r2, k[2]);
+  qe = PHF_FMA_K(qe, r2, k[0]);
+  double qo = k[9];                               /* odd coefficients */
+  qo = PHF_FMA_K(qo, r2, k[7]);
+  qo = PHF_FMA_K(qo, r2, k[5]);
+  qo = PHF_FMA_K(qo, r2, k[3]);
+  qo = PHF_FMA_K(qo, r2, k[1]);
   const double q = phf_fma(qo, r, qe);
   const double p = phf_fma(r2, q, r) + 1.0;
-  const int k = (int)kd;
-  const int k1 = k >> 1;
-  return (p * phf_pow2i(k1)) * phf_pow2i(k - k1);
+  const int ki = (int)kd;
+  const int k1 = ki >> 1;
+  return (p * phf_pow2i(k1)) * phf_pow2i(ki - k1);
 }
+
+PHF_HD double phf_exp_fast(double x) { return phf_exp_fast_k(x, PHF_KLOAD(phf_k_exp)); }
 
 PHF_HD double phf_exp(double x) {
   const double r = phf_exp_fast(x);
@@ -112,22 +130,28 @@ PHF_HD phf_logred phf_log_reduce(double x) { /* exact for positive normal finite
   return lr;
 }
 
-PHF_HD double phf_log_finish(phf_logred lr, double s) {
+PHF_KTABLE phf_k_log[7] = {    /* G(z), coefficient of z^i */
+    0x1.5555555555558p-1, 0x1.99999999952ccp-2, 0x1.2492492df3ba9p-2, 0x1.c71c62e26208bp-3, 0x1.7462b58e46ebep-3,
+    0x1.39fe42e9740a7p-3, 0x1.2b59b713616c9p-3};
+
+PHF_HD double phf_log_finish_k(phf_logred lr, double s, phf_ktab k) {
   const double f = lr.f, dk = lr.dk;
   const double z = s * s;
   const double z2 = z * z;
-  double ge = 0x1.2b59b713616c9p-3;               /* g6 g4 g2 g0 in z^2 */
-  ge = PHF_FMA_C(ge, z2, 0x1.7462b58e46ebep-3);
-  ge = PHF_FMA_C(ge, z2, 0x1.2492492df3ba9p-2);
-  ge = PHF_FMA_C(ge, z2, 0x1.5555555555558p-1);
-  double go = 0x1.39fe42e9740a7p-3;               /* g5 g3 g1 */
-  go = PHF_FMA_C(go, z2, 0x1.c71c62e26208bp-3);
-  go = PHF_FMA_C(go, z2, 0x1.99999999952ccp-2);
+  double ge = k[6];
+  ge = PHF_FMA_K(ge, z2, k[4]);
+  ge = PHF_FMA_K(ge, z2, k[2]);
+  ge = PHF_FMA_K(ge, z2, k[0]);
+  double go = k[5];
+  go = PHF_FMA_K(go, z2, k[3]);
+  go = PHF_FMA_K(go, z2, k[1]);
   const double g = phf_fma(go, z, ge);
   const double hfsq = 0.5 * f * f;
   const double t = phf_fma(dk, PHF_LN2_LO, s * phf_fma(z, g, hfsq));
   return phf_fma(dk, PHF_LN2_HI, f - (hfsq - t));
 }
+
+PHF_HD double phf_log_finish(phf_logred lr, double s) { return phf_log_finish_k(lr, s, PHF_KLOAD(phf_k_log)); }
 
 /* positive normal finite x only (no checks) */
 PHF_HD double phf_log_core(double x) {
@@ -162,36 +186,46 @@ PHF_HD double phf_log(double x) {
  * the final scaling and may come from a batched reciprocal.                                                    */
 PHF_HD double phf_erfcx_den(double y) { return (y + 4.0) * phf_fma(2.0, y, 1.0); }
 
-PHF_HD double phf_erfcx_finish(double y, double r) {
+PHF_KTABLE phf_k_erfcx[24] = { /* (1+2y) erfcx(y) in t = (y-4)/(y+4), coefficient of t^i (24th entry pads the burst) */
+    0x1.3ba5916e9fd7fp+0, -0x1.1df1ad154a1c8p-3, 0x1.f7f5df66fd40dp-7, 0x1.16ecefcf9cb1ep-4, -0x1.9ddb23c3e6861p-4,
+    0x1.7fee004ef1101p-4, -0x1.0fb06dfe8afa8p-4, 0x1.3079ede17a234p-5, -0x1.09623878c700ep-6, 0x1.49c676f414b52p-8,
+    -0x1.8d4aa41628fedp-11, -0x1.a1e16f900a258p-13, 0x1.3be0e09412ec0p-13, -0x1.9928561ea5afcp-16,
+    -0x1.789e79eb906c5p-17, 0x1.7dcf4dcc6199dp-18, 0x1.3ebb0291516c9p-22, -0x1.ae86b29807edbp-21,
+    0x1.355884b1ca9fcp-24, 0x1.8f0920c7d5e28p-24, -0x1.1f8f10ba20f78p-26, -0x1.dff032d300316p-28,
+    0x1.c2e324cb33784p-30, 0.0};
+
+PHF_HD double phf_erfcx_finish_k(double y, double r, phf_ktab k) {
   const double a = y + 4.0, b = phf_fma(2.0, y, 1.0);
   const double t = ((y - 4.0) * b) * r;
   const double t2 = t * t;
-  double pe = 0x1.c2e324cb33784p-30;              /* c22 c20 ... c0 in t^2 */
-  pe = PHF_FMA_C(pe, t2, -0x1.1f8f10ba20f78p-26);
-  pe = PHF_FMA_C(pe, t2, 0x1.355884b1ca9fcp-24);
-  pe = PHF_FMA_C(pe, t2, 0x1.3ebb0291516c9p-22);
-  pe = PHF_FMA_C(pe, t2, -0x1.789e79eb906c5p-17);
-  pe = PHF_FMA_C(pe, t2, 0x1.3be0e09412ec0p-13);
-  pe = PHF_FMA_C(pe, t2, -0x1.8d4aa41628fedp-11);
-  pe = PHF_FMA_C(pe, t2, -0x1.09623878c700ep-6);
-  pe = PHF_FMA_C(pe, t2, -0x1.0fb06dfe8afa8p-4);
-  pe = PHF_FMA_C(pe, t2, -0x1.9ddb23c3e6861p-4);
-  pe = PHF_FMA_C(pe, t2, 0x1.f7f5df66fd40dp-7);
-  pe = PHF_FMA_C(pe, t2, 0x1.3ba5916e9fd7fp+0);
-  double po = -0x1.dff032d300316p-28;             /* c21 c19 ... c1 */
-  po = PHF_FMA_C(po, t2, 0x1.8f0920c7d5e28p-24);
-  po = PHF_FMA_C(po, t2, -0x1.ae86b29807edbp-21);
-  po = PHF_FMA_C(po, t2, 0x1.7dcf4dcc6199dp-18);
-  po = PHF_FMA_C(po, t2, -0x1.9928561ea5afcp-16);
-  po = PHF_FMA_C(po, t2, -0x1.a1e16f900a258p-13);
-  po = PHF_FMA_C(po, t2, 0x1.49c676f414b52p-8);
-  po = PHF_FMA_C(po, t2, 0x1.3079ede17a234p-5);
-  po = PHF_FMA_C(po, t2, 0x1.7fee004ef1101p-4);
-  po = PHF_FMA_C(po, t2, 0x1.16ecefcf9cb1ep-4);
-  po = PHF_FMA_C(po, t2, -0x1.1df1ad154a1c8p-3);
+  double pe = k[22];
+  pe = PHF_FMA_K(pe, t2, k[20]);
+  pe = PHF_FMA_K(pe, t2, k[18]);
+  pe = PHF_FMA_K(pe, t2, k[16]);
+  pe = PHF_FMA_K(pe, t2, k[14]);
+  pe = PHF_FMA_K(pe, t2, k[12]);
+  pe = PHF_FMA_K(pe, t2, k[10]);
+  pe = PHF_FMA_K(pe, t2, k[8]);
+  pe = PHF_FMA_K(pe, t2, k[6]);
+  pe = PHF_FMA_K(pe, t2, k[4]);
+  pe = PHF_FMA_K(pe, t2, k[2]);
+  pe = PHF_FMA_K(pe, t2, k[0]);
+  double po = k[21];
+  po = PHF_FMA_K(po, t2, k[19]);
+  po = PHF_FMA_K(po, t2, k[17]);
+  po = PHF_FMA_K(po, t2, k[15]);
+  po = PHF_FMA_K(po, t2, k[13]);
+  po = PHF_FMA_K(po, t2, k[11]);
+  po = PHF_FMA_K(po, t2, k[9]);
+  po = PHF_FMA_K(po, t2, k[7]);
+  po = PHF_FMA_K(po, t2, k[5]);
+  po = PHF_FMA_K(po, t2, k[3]);
+  po = PHF_FMA_K(po, t2, k[1]);
   const double p = phf_fma(po, t, pe);
   return (p * a) * r;
 }
+
+PHF_HD double phf_erfcx_finish(double y, double r) { return phf_erfcx_finish_k(y, r, PHF_KLOAD(phf_k_erfcx)); }
 
 /* 0 <= y < ~1e150 (no checks) */
 PHF_HD double phf_erfcx_core(double y) { return phf_erfcx_finish(y, 1.0 / phf_erfcx_den(y)); }
@@ -223,12 +257,14 @@ PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1)
   const double y0 = -x0 * PHF_INV_SQRT2, y1 = -x1 * PHF_INV_SQRT2;
   const double q0 = phf_erfcx_den(y0), q1 = phf_erfcx_den(y1);
   const double iq = 1.0 / (q0 * q1);
-  const double e0 = phf_erfcx_finish(y0, iq * q1), e1 = phf_erfcx_finish(y1, iq * q0);
+  const phf_ktab ke = PHF_KLOAD(phf_k_erfcx);
+  const double e0 = phf_erfcx_finish_k(y0, iq * q1, ke), e1 = phf_erfcx_finish_k(y1, iq * q0, ke);
   const phf_logred l0 = phf_log_reduce(0.5 * e0), l1 = phf_log_reduce(0.5 * e1);
   const double d0 = 2.0 + l0.f, d1 = 2.0 + l1.f;
   const double id = 1.0 / (d0 * d1);
-  *r0 = phf_fma(-0.5 * x0, x0, phf_log_finish(l0, l0.f * (id * d1)));
-  *r1 = phf_fma(-0.5 * x1, x1, phf_log_finish(l1, l1.f * (id * d0)));
+  const phf_ktab kl = PHF_KLOAD(phf_k_log);
+  *r0 = phf_fma(-0.5 * x0, x0, phf_log_finish_k(l0, l0.f * (id * d1), kl));
+  *r1 = phf_fma(-0.5 * x1, x1, phf_log_finish_k(l1, l1.f * (id * d0), kl));
 }
 
 /* log Phi(x), any x.  x > 0: log(1 - q), q = erfcx(x/sqrt2) exp(-x^2/2)/2, with the log1p correction term. */
@@ -254,21 +290,25 @@ PHF_HD double phf_ndtr(double x) {
 /* ------------------------------------------------------------------------------------------------ sin/cos
  * sin and cos of 2*pi*w/2^32 for a 32-bit integer w: exact octant reduction in the integer domain,
  * |x| <= pi/8 kernels of degree 11/12 (approximation error 5e-18), exact rotations.                           */
-PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) {
+PHF_KTABLE phf_k_sincos[10] = { /* sin: S(z) coefficients of z^0..z^4, then cos: C(z) of z^0..z^4 */
+    -0x1.5555555555554p-3, 0x1.111111110fd1dp-7, -0x1.a01a018fee5fbp-13, 0x1.71ddf0ef66ef1p-19, -0x1.ad54503fdffb8p-26,
+    0x1.5555555555555p-5, -0x1.6c16c16c160afp-10, 0x1.a01a0196dbfc7p-16, -0x1.27e4d184456c9p-22, 0x1.1e5217c71f176p-29};
+
+PHF_HD void phf_sincos_2pi_u32_k(uint32_t w, double* sn, double* cs, phf_ktab k) {
   const uint32_t q = ((w >> 28) + 1u) >> 1;                 /* nearest multiple of pi/4: 0..8 */
   const int32_t rem = (int32_t)(w - (q << 29));              /* [-2^28, 2^28); q = 8 wraps to the same value */
   const double x = (double)rem * PHF_2PI_2M32;
   const double z = x * x;
-  double ps = -0x1.ad54503fdffb8p-26;
-  ps = PHF_FMA_C(ps, z, 0x1.71ddf0ef66ef1p-19);
-  ps = PHF_FMA_C(ps, z, -0x1.a01a018fee5fbp-13);
-  ps = PHF_FMA_C(ps, z, 0x1.111111110fd1dp-7);
-  ps = PHF_FMA_C(ps, z, -0x1.5555555555554p-3);
-  double pc = 0x1.1e5217c71f176p-29;
-  pc = PHF_FMA_C(pc, z, -0x1.27e4d184456c9p-22);
-  pc = PHF_FMA_C(pc, z, 0x1.a01a0196dbfc7p-16);
-  pc = PHF_FMA_C(pc, z, -0x1.6c16c16c160afp-10);
-  pc = PHF_FMA_C(pc, z, 0x1.5555555555555p-5);
+  double ps = k[4];
+  ps = PHF_FMA_K(ps, z, k[3]);
+  ps = PHF_FMA_K(ps, z, k[2]);
+  ps = PHF_FMA_K(ps, z, k[1]);
+  ps = PHF_FMA_K(ps, z, k[0]);
+  double pc = k[9];
+  pc = PHF_FMA_K(pc, z, k[8]);
+  pc = PHF_FMA_K(pc, z, k[7]);
+  pc = PHF_FMA_K(pc, z, k[6]);
+  pc = PHF_FMA_K(pc, z, k[5]);
   const double s = phf_fma(x * z, ps, x);
   const double c = phf_fma(z * z, pc, phf_fma(-0.5, z, 1.0));
   const double a = (q & 1u) ? PHF_INV_SQRT2 * (s + c) : s;  /* sin(x + (q&1) pi/4) */
@@ -277,6 +317,8 @@ PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) {
   *sn = (h == 0u) ? a : (h == 1u) ? b : (h == 2u) ? -a : -b;
   *cs = (h == 0u) ? b : (h == 1u) ? -a : (h == 2u) ? -b : a;
 }
+
+PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) { phf_sincos_2pi_u32_k(w, sn, cs, PHF_KLOAD(phf_k_sincos)); }
 
 /* 53-bit uniform on [0,1) from two words — numpy's random_sample() construction
  * (the reference's npr.rand(), python/PyHillFit.py:834).                                       */

@@ -29,9 +29,9 @@
 #define PHF_HILL_ARG_CAP 40.0                   /* exp(40): 100/(1+x) already rounds pred to exactly 100 */
 
 /* Hill-curve denominator 1 + (dose/IC50)^hill = 1 + exp(hill (ln dose - ln IC50))   (doseresponse.py:84-88) */
-PHF_HD double phf_hill_den(int model, double ln_conc, double hill, double ln_ic50) {
+PHF_HD double phf_hill_den(int model, double ln_conc, double hill, double ln_ic50, phf_ktab k_exp) {
   const double a = (model == 1) ? (ln_conc - ln_ic50) : hill * (ln_conc - ln_ic50);
-  return 1.0 + phf_exp_fast(__builtin_fmin(a, PHF_HILL_ARG_CAP));
+  return 1.0 + phf_exp_fast_k(__builtin_fmin(a, PHF_HILL_ARG_CAP), k_exp);
 }
 
 /* percent block from w = 1/(1 + x):  100 (1 - w) */
@@ -60,14 +60,16 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
   const double inv3 = 1.0 / (p1 * dl);
   const double i1 = inv3 * dl;                    /* 1/(sigma ds) */
   const double inv_s = i1 * ds;
-  const double log_sigma = phf_log_finish(lr_s, lr_s.f * (i1 * sigma));
-  const double log_sl = phf_log_finish(lr_l, lr_l.f * (inv3 * p1));
+  const phf_ktab k_log = PHF_KLOAD(phf_k_log);
+  const double log_sigma = phf_log_finish_k(lr_s, lr_s.f * (i1 * sigma), k_log);
+  const double log_sl = phf_log_finish_k(lr_l, lr_l.f * (inv3 * p1), k_log);
 
   double sse = 0.0, cens = 0.0;
   int j = 0;
   for (; j + 4 <= n_other; j += 4) {              /* uncensored points, four at a time (:247) */
-    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50);
-    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50);
+    const phf_ktab ke = PHF_KLOAD(phf_k_exp);
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke);
+    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50, ke);
     const double p01 = d0 * d1, p23 = d2 * d3;
     const double inv = 1.0 / (p01 * p23);
     const double i01 = inv * p23, i23 = inv * p01;
@@ -76,12 +78,13 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
     sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse); sse = phf_fma(r2, r2, sse); sse = phf_fma(r3, r3, sse);
   }
   for (; j < n_other; ++j) {
-    const double r = y[j] - phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50));
+    const double r = y[j] - phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, PHF_KLOAD(phf_k_exp)));
     sse = phf_fma(r, r, sse);
   }
   const int n = n_other + n_cens;
   for (; j + 2 <= n; j += 2) {                    /* censored points, two at a time (:244-245) */
-    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50);
+    const phf_ktab ke = PHF_KLOAD(phf_k_exp);
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke);
     const double inv = 1.0 / (d0 * d1);
     const double z0 = phf_censored_z(phf_hill_percent(inv * d1), y[j], inv_s);
     const double z1 = phf_censored_z(phf_hill_percent(inv * d0), y[j + 1], inv_s);
@@ -90,7 +93,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
     cens += l0; cens += l1;
   }
   for (; j < n; ++j) {
-    const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50));
+    const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, PHF_KLOAD(phf_k_exp)));
     cens += phf_log_ndtr_nonpos(phf_censored_z(pred, y[j], inv_s));
   }
   double a = cens - pi_bit;
@@ -133,20 +136,21 @@ PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32
   const double pab = da * db;
   const double inv = 1.0 / (pab * du);
   const double iab = inv * du;
-  const double log_ua = phf_log_finish(la, la.f * (iab * db));
+  const phf_ktab k_log = PHF_KLOAD(phf_k_log), k_sc = PHF_KLOAD(phf_k_sincos);
+  const double log_ua = phf_log_finish_k(la, la.f * (iab * db), k_log);
   double sn, cs;
-  phf_sincos_2pi_u32(b0.w[1], &sn, &cs);
+  phf_sincos_2pi_u32_k(b0.w[1], &sn, &cs, k_sc);
   const double ra = phf_sqrt(-2.0 * log_ua);
   z[0] = ra * cs; z[1] = ra * sn;
   if (d == 2) {
     z[2] = 0.0; z[3] = 0.0;
   } else {
-    const double log_ub = phf_log_finish(lb, lb.f * (iab * da));
-    phf_sincos_2pi_u32(ang_b, &sn, &cs);
+    const double log_ub = phf_log_finish_k(lb, lb.f * (iab * da), k_log);
+    phf_sincos_2pi_u32_k(ang_b, &sn, &cs, k_sc);
     const double rb = phf_sqrt(-2.0 * log_ub);
     z[2] = rb * cs; z[3] = rb * sn;
   }
-  const double log_u = phf_log_finish(lu, lu.f * (inv * pab));
+  const double log_u = phf_log_finish_k(lu, lu.f * (inv * pab), k_log);
   return (u < PHF_DBL_MIN) ? -PHF_INF : log_u;       /* u == 0 (probability 2^-53): log 0 = -inf, accept */
 }
 
