@@ -1,0 +1,135 @@
+"""Drop-in for the sampling step of the reference's python/PyHillTemp.py (thermodynamic integration), on MI355X.
+
+    python -m pyhillfit_amd.PyHillTemp --data-file ../data/crumb_data.csv -m 2 -d 0 -c 0
+           [-i 500000] [-t 5] [-b 4] [-nc 1] [--num-chains 64] [--seed 1] [--rungs 40] [--all-pairs]
+
+The reference runs do_mcmc(temperature) (python/PyHillTemp.py:57-125) once per rung of the ladder
+t_i = (i/n)^c, n = 40, c = 3 (:151, doseresponse.py:27-28) through a process pool (:155-161).  Here all rungs
+(times --num-chains chains, times all selected pairs) advance in one batch of HIP kernel launches; each rung's
+chain 0 is written, burn-in removed, headerless, to the reference's temperature_<t> chain file (:165-169), where
+python/compute_bayes_factors.py expects it.  Start point ones(d), identity covariance, mean reset at 1000*d
+(:63,80,114-115).  `--rungs N` changes n (BASELINE config 5 uses 32 rungs = --rungs 31)."""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+
+from . import chainio
+from . import distributed as phfdist
+from . import doseresponse as dr
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(prog="PyHillTemp.py")
+    # python/PyHillTemp.py:21-37
+    parser.add_argument("-i", "--iterations", type=int, help="number of MCMC iterations", default=500000)
+    parser.add_argument("-t", "--thinning", type=int, help="save every t-th iteration", default=5)
+    parser.add_argument("-b", "--burn-in-fraction", type=int, help="discard the first N/b saved rows as burn-in", default=4)
+    parser.add_argument("-a", "--all", action='store_true', default=False, help="accepted, unused (as in the reference)")
+    parser.add_argument("-nc", "--num-cores", type=int, default=1, help="accepted for compatibility")
+    parser.add_argument("-Ne", "--num_expts", type=int, default=0, help="accepted, unused (as in the reference)")
+    parser.add_argument("--num-APs", type=int, default=500, help="accepted, unused")
+    parser.add_argument("--single", action='store_true', default=True)
+    parser.add_argument("--hierarchical", action='store_true', default=False, help="accepted, unused (as in the reference)")
+    parser.add_argument("--fix-hill", action='store_true', default=False, help="accepted, unused (-m selects the model)")
+    parser.add_argument("-bfo", "--best-fit-only", action='store_true', default=False, help="accepted, unused")
+    req = parser.add_argument_group('required arguments')
+    req.add_argument("--data-file", type=str, required=True)
+    req.add_argument("-m", "--model", type=int, required=True, help="1. fix Hill=1; 2. vary Hill")
+    req.add_argument("-d", "--drug", type=int, help="drug index", required=True)
+    req.add_argument("-c", "--channel", type=int, help="channel index", required=True)
+    new = parser.add_argument_group('MI355X options')
+    new.add_argument("--num-chains", type=int, default=64)
+    new.add_argument("--seed", type=int, default=1, help="Philox seed (the reference seeds numpy with 1, PyHillTemp.py:16-17)")
+    new.add_argument("--rungs", type=int, default=None, help="n of the ladder (i/n)^c, default doseresponse.n = 40 (41 rungs)")
+    new.add_argument("--all-pairs", action='store_true', default=False, help="run every drug x channel pair instead of -d/-c")
+    new.add_argument("--device", type=str, default=None)
+    new.add_argument("--segment", type=int, default=20000)
+    new.add_argument("--output-root", type=str, default="output")
+    return parser
+
+
+def run_tempered(pairs, temperatures, args, device):
+    """pairs: [(drug, channel)]; one problem per (pair, rung).  Returns summaries."""
+    import torch
+    from .sampler import SingleLevelSampler
+    model = args.model
+    d = dr.num_params
+    loaded = []
+    for drug, channel in pairs:
+        num_expts, _, experiments = dr.load_crumb_data(drug, channel)
+        loaded.append((drug, channel) + tuple(dr.concatenate_experiments(num_expts, experiments)))   # PyHillTemp.py:130-136
+    packed = dr.PackedPoints([(c, y) for _, _, c, y in loaded])
+    R = len(temperatures)
+    pair_index = [p for p in range(len(loaded)) for _ in range(R)]
+    temps = [float(t) for _ in loaded for t in temperatures]
+    all_pairs = [(a, b) for a in dr.drugs for b in dr.channels]
+    pids = [all_pairs.index((dg, ch)) * 1024 + r for dg, ch, _, _ in loaded for r in range(R)]
+    Q, C = len(pair_index), args.num_chains
+    total_iterations, thinning = args.iterations, args.thinning
+    if total_iterations % thinning:
+        raise SystemExit("iterations must be a multiple of thinning")
+    s = SingleLevelSampler(packed, model, pair_index, temps, C, thinning=thinning, seed=args.seed, adapt_start=1000 * d,
+                           reset_mean_at_adapt_start=True, problem_ids=pids, device=device)        # :83,114-115
+    s.init(np.ones(d), cov_identity=True, cov_scale=1.0)                                            # :63,80
+    num_saved = total_iterations // thinning + 1                                                    # :70
+    burn = num_saved // args.burn_in_fraction                                                       # :71
+    s.enable_moments(after_iteration=max(burn * thinning - 1, 0))
+    s.reserve(total_iterations)
+    kept = torch.empty((num_saved, Q, d + 1), dtype=torch.float64)
+    kept[0] = s.row0[:, :, 0].cpu()
+    seg = max(thinning, args.segment - args.segment % thinning)
+    buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
+    done, r = 0, 1
+    start = time.time()
+    while done < total_iterations:
+        k = min(seg, total_iterations - done)
+        nr = k // thinning
+        rows = s.advance(k, out=buf[:nr])
+        kept[r:r + nr] = rows[:, :, :, 0].cpu()
+        done += k; r += nr
+    torch.cuda.synchronize(device)
+    mcmc_time = time.time() - start
+    print("\nMCMC time: {} s\n".format(int(mcmc_time)))                                             # :162-163
+    mean, var, _ = s.posterior_moments()
+    mean = mean.cpu().numpy()
+    out = []
+    for ip, (drug, channel, _, _) in enumerate(loaded):
+        for ir, temperature in enumerate(temperatures):
+            q = ip * R + ir
+            d_clean, c_clean, chain_file, _ = dr.nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature)
+            print("chain_file:", chain_file)
+            chainio.save_tempered_chain(chain_file, kept[burn:, q].numpy())                         # :125,169
+            out.append({"drug": d_clean, "channel": c_clean, "temperature": float(temperature),
+                        "pooled_mean": mean[:, q].mean(axis=1).tolist(), "chain_file": chain_file})
+    with open(dr.output_root + "/" + dr.dir_name + "/tempered_summary_model_%d.json" % model, "w") as f:
+        json.dump({"mcmc_seconds": mcmc_time, "chains": C, "rungs": out}, f, indent=1)
+    return out
+
+
+def main(argv=None):
+    parser = build_parser()
+    if argv is None and len(sys.argv) == 1:
+        parser.print_help()
+        sys.exit(1)
+    args = parser.parse_args(argv)
+    rank, local_rank, world = phfdist.init()
+    device = args.device or "cuda:%d" % local_rank
+    dr.define_model(args.model)                                          # PyHillTemp.py:45
+    dr.setup(args.data_file)                                             # :48
+    dr.output_root = args.output_root
+    if args.all_pairs:
+        pairs = [(a, b) for a in dr.drugs for b in dr.channels]
+    else:
+        pairs = [(dr.drugs[args.drug], dr.channels[args.channel])]       # :52-53
+    if world > 1:
+        pairs = [pairs[i] for i in phfdist.shard_problems([1.0] * len(pairs), world)[rank]]
+    temperatures = dr.temperature_ladder(args.rungs)                     # :151
+    print("\nDoing temperatures: {}\n".format(temperatures))
+    return run_tempered(pairs, temperatures, args, device) if pairs else []
+
+
+if __name__ == "__main__":
+    main()

@@ -257,6 +257,17 @@ def log_target(y, where_y_0, where_y_100, where_y_other, concs, params, t, pi_bi
 output_root = "output"
 
 
+def py2_str(x):
+    """How the reference's Python 2 renders a number inside '{}'.format(...) (12 significant digits for floats):
+    the temperature in the chain paths is formatted this way (doseresponse.py:120,127), e.g. 1, 0.0, 1.5625e-05."""
+    if isinstance(x, (int, np.integer)):
+        return str(int(x))
+    s = '%.12g' % float(x)
+    if not any(ch in s for ch in '.en'):
+        s += '.0'
+    return s
+
+
 def _clean(name):
     return name.replace('/', '_') if '/' in name else name
 
@@ -280,6 +291,7 @@ def hierarchical_output_dirs_and_chain_file(drug, channel, Ne=0):
 def nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature):
     """doseresponse.py:115-128."""
     drug, channel = _clean(drug), _clean(channel)
+    temperature = py2_str(temperature)
     output_dir = '{}/{}/single-level/{}/{}/model_{}/temperature_{}/'.format(output_root, dir_name, drug, channel, model, temperature)
     chain_dir, images_dir = output_dir + 'chain/', output_dir + 'figures/'
     _mk(output_dir, chain_dir, images_dir)

@@ -1,0 +1,83 @@
+"""The drop-in command lines on a GPU: same flags, same files in the same places as the reference
+(python/PyHillFit.py, python/PyHillTemp.py), chain 0 bit-identical to the CPU twin through the text file."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def csv_file(tmp_path_factory):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pyhillfit_amd import doseresponse as dr
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    p = tmp_path_factory.mktemp("data") / "crumb_data.csv"
+    dr.table.to_csv(str(p))
+    return str(p)
+
+
+def test_pyhillfit_single_level_cli(csv_file, tmp_path):
+    from oracle import c_oracle as co
+    from pyhillfit_amd import PyHillFit, bestfit
+    from pyhillfit_amd import doseresponse as dr
+    from pyhillfit_amd.sampler import gamma_table
+    out = str(tmp_path / "output")
+    T, thin = 4000, 5
+    summ = PyHillFit.main(["--data-file", csv_file, "-m", "2", "-i", str(T), "-t", str(thin), "-b", "4", "--drugs", "Amiodarone,Bepridil",
+                           "--channels", "hERG,KvLQT1/mink", "--num-chains", "64", "--output-root", out, "--segment", "1500",
+                           "--save-all-chains"])
+    assert len(summ) == 4
+    all_pairs = [(a, b) for a in dr.drugs for b in dr.channels]
+    for drug, channel in [("Amiodarone", "hERG"), ("Bepridil", "KvLQT1/mink")]:
+        cc = channel.replace("/", "_")
+        base = os.path.join(out, "crumb_data", "single-level", drug, cc, "model_2", "temperature_1")
+        chain_file = os.path.join(base, "chain", "%s_%s_model_2_temp_1_chain_single-level.txt" % (drug, cc))
+        with open(chain_file) as f:
+            assert f.readline().startswith("# Nonhierarchical MCMC output for %s + %s" % (drug, cc))
+        chain = np.loadtxt(chain_file)
+        saved = T // thin + 1
+        assert chain.shape == (saved - saved // 4, 4)                       # PyHillFit.py:810,861-864
+        best = np.loadtxt(os.path.join(base, "figures", "%s_%s_best_fit_params.txt" % (drug, cc)))
+        ne, _, ex = dr.load_crumb_data(drug, channel)
+        concs, y = dr.concatenate_experiments(ne, ex)
+        th0, _ = bestfit.best_fit(concs, y, 2)
+        assert np.array_equal(best, th0)
+        # chain 0 == CPU twin started at the same point, same Philox stream (problem id = index in drugs x channels)
+        pk = co.PackedPair(concs, y, 2, 1.0)
+        st = pk.init_state(th0, False, 0.05)
+        rows = pk.advance(st, 0, T, thin, 3000, False, gamma_table(T), seed=25, chain_id=0, problem_id=all_pairs.index((drug, channel)))
+        full = np.vstack([np.concatenate([th0, [pk.log_target(th0)]]), rows])
+        assert np.array_equal(chain, full[saved // 4:])
+        allc = np.load(chain_file[:-4] + "_all_chains.npy")
+        assert allc.shape == (saved - saved // 4, 4, 64) and np.array_equal(allc[:, :, 0], chain)
+        with open(chain_file[:-4] + "_summary.json") as f:
+            s = json.load(f)
+        assert s["chains"] == 64 and 0.05 < s["acceptance"] < 0.8
+        post = allc[:, :, :].transpose(0, 2, 1).reshape(-1, 4)
+        np.testing.assert_allclose(s["pooled_mean"], post.mean(axis=0), rtol=1e-9)   # device moments == file contents
+
+
+def test_pyhilltemp_cli(csv_file, tmp_path):
+    from pyhillfit_amd import PyHillTemp
+    from pyhillfit_amd import doseresponse as dr
+    out = str(tmp_path / "output")
+    res = PyHillTemp.main(["--data-file", csv_file, "-m", "1", "-d", "0", "-c", "0", "-i", "3000", "-t", "5", "--rungs", "4",
+                           "--num-chains", "64", "--output-root", out])
+    assert len(res) == 5
+    lad = dr.temperature_ladder(4)
+    assert [dr.py2_str(t) for t in lad] == ["0.0", "0.015625", "0.125", "0.421875", "1.0"]
+    for t in lad:
+        f = os.path.join(out, "crumb_data", "single-level", "Amiodarone", "hERG", "model_1", "temperature_%s" % dr.py2_str(t), "chain",
+                         "Amiodarone_hERG_model_1_temp_%s_chain_single-level.txt" % dr.py2_str(t))
+        chain = np.loadtxt(f)                                                 # headerless, PyHillTemp.py:169
+        assert chain.shape == (601 - 601 // 4, 3) and np.isfinite(chain).all()
+    # the likelihood weight grows with temperature: hotter rungs sit closer to the data
+    hot = np.loadtxt(f)[:, 0].mean()
+    assert 5.0 < hot < 7.0

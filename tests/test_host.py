@@ -73,8 +73,9 @@ def test_output_paths_follow_the_reference_contract(dr, tmp_path, monkeypatch):
                                "Moxifloxacin_KvLQT1_mink_model_2_temp_1_chain_single-level.txt")
     assert os.path.isdir(images_dir)
     _, _, f2, _ = dr.nonhierarchical_chain_file_and_figs_dir(1, "Amiodarone", "hERG", dr.temperature_ladder()[1])
-    t1 = repr(float(dr.temperature_ladder()[1]))     # PyHillTemp formats the float itself into the path
-    assert "temperature_%s/" % t1 in f2 and f2.endswith("_temp_%s_chain_single-level.txt" % t1) and t1.startswith("1.5625")
+    # PyHillTemp formats the float into the path with Python-2 str(): 12 significant digits
+    assert "temperature_1.5625e-05/" in f2 and f2.endswith("_temp_1.5625e-05_chain_single-level.txt")
+    assert [dr.py2_str(v) for v in (1, 1.0, 0.0, 0.125, (3 / 40.) ** 3, (39 / 40.) ** 3)] == ["1", "1.0", "0.0", "0.125", "0.000421875", "0.926859375"]
     d, c, out, chain_dir, figs, cf = dr.hierarchical_output_dirs_and_chain_file("Amiodarone", "hERG", 3)
     assert cf.endswith("output/crumb_dataset/hierarchical/Amiodarone/hERG/3_expts/chain/crumb_dataset_Amiodarone_hERG_hierarchical_chain.txt")
     assert dr.alpha_mu_downsampling("Amiodarone", "hERG").endswith("hierarchical/alpha_mu_samples/Amiodarone_hERG_hill_pic50_samples.txt")
