@@ -112,6 +112,57 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
                                 const double* temperature, const double* theta, double* out_lik,
                                 double* out_prior, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Hierarchical model (python/PyHillFit.py --hierarchical: log_target_distribution :113-193, loop :429-511).
+ * theta = [alpha, beta, mu, s, pIC50_1, Hill_1, ..., pIC50_Ne, Hill_Ne, sigma], dim = 5 + 2 Ne (:178-181).
+ * One call handles problems whose pairs all have the same number of experiments Ne (1 <= Ne <= PHF_HIER_MAX_EXPTS);
+ * the host groups the pairs by Ne (Crumb: Ne = 3..6).                                                         */
+#define PHF_HIER_MAX_EXPTS 8
+
+/* Points of P pairs, stored experiment by experiment (python/doseresponse.py:60-67 keeps one array per experiment). */
+typedef struct phf_hier_points {
+  int32_t num_pairs;          /* P */
+  int32_t stride;             /* doubles per pair row in ln_conc/response */
+  int32_t n_expts;            /* Ne, the same for every pair of this set */
+  int32_t reserved;
+  const double* ln_conc;      /* device [P][stride] */
+  const double* response;     /* device [P][stride] */
+  const int32_t* expt_start;  /* device [P][Ne+1]  first point of each experiment; [Ne] = number of points */
+} phf_hier_points;
+
+#ifndef PHF_HIER_PRIOR_DEFINED
+#define PHF_HIER_PRIOR_DEFINED
+/* Shifted-Gamma hyper-priors of (alpha, beta, mu, s, sigma): python/PyHillFit.py:301,340-364 */
+typedef struct phf_hier_prior {
+  double shape_m1[5];         /* shapes - 1 */
+  double inv_scale[5];        /* 1/scales */
+  double loc[5];              /* lower bounds (locs) */
+} phf_hier_prior;
+#endif
+
+/* doubles of per-chain state: theta[dim], log-target, mean[dim], L[dim(dim+1)/2] (lower Cholesky factor of the
+ * adapted covariance, packed row-major), loga, accepted-count.  The factor is carried instead of the covariance:
+ * the reference's update cov <- (1-g) cov + g v v' (PyHillFit.py:498-499) is applied to it as a rank-one
+ * update, which is the same matrix in exact arithmetic and needs one pass over dim(dim+1)/2 numbers per iteration
+ * instead of an O(dim^3) refactorisation.                                                                     */
+int phf_hierarchical_state_size(int n_expts);
+
+/* Start chains: theta = mean = theta0, cov = diag(cov_scale*|theta0|) (PyHillFit.py:431, cov_scale 0.01), loga = 0.
+ *   theta0 device [dim][Q*C];  state device [S][Q*C];  row0 device [Q][dim+1][C] or NULL.
+ *   prob->temperature is ignored (the hierarchical sampler is not tempered).                                  */
+int phf_hierarchical_init(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
+                          double cov_scale, const double* theta0, double* state, double* row0, void* stream);
+
+/* MH iterations t_begin+1 .. t_end (python/PyHillFit.py:484-511); arguments as phf_single_level_advance with
+ * d = dim; cfg->model is ignored, cfg->adapt_start is 100*dim in the reference (:440).                        */
+int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
+                             const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
+                             double* moments, int64_t moments_after, void* stream);
+
+/* log_target_distribution (python/PyHillFit.py:173-193) at M parameter vectors: theta device [dim][M]. */
+int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior* prior, int64_t m,
+                                const int32_t* pair_index, const double* theta, double* out, void* stream);
+
 /* Evaluate one of the device elementary functions on an array (parity tests: the device must reproduce the
  * host build of pyhillfit_amd/csrc/phf_math.h bit for bit).
  * fn: 0 exp, 1 log, 2 erfcx(y>=0), 3 log_ndtr, 4 ndtr, 5 sqrt, 6 reciprocal, 7 sin(2 pi w/2^32), 8 cos(...)

@@ -24,6 +24,15 @@ class Run(C.Structure):
                 ("chain_id", C.c_uint32), ("problem_id", C.c_uint32), ("gamma", C.c_void_p)]
 
 
+class HierPrior(C.Structure):
+    _fields_ = [("shape_m1", C.c_double * 5), ("inv_scale", C.c_double * 5), ("loc", C.c_double * 5)]
+
+
+class HierProblem(C.Structure):
+    _fields_ = [("n_expts", C.c_int32), ("expt_start", C.c_void_p), ("ln_conc", C.c_void_p), ("response", C.c_void_p),
+                ("prior", HierPrior)]
+
+
 _lib = None
 
 
@@ -37,6 +46,7 @@ def lib():
         L.phfo_log_likelihood.restype = C.c_double
         L.phfo_log_prior.restype = C.c_double
         L.phfo_state_size.restype = C.c_int
+        L.phfo_hier_log_target.restype = C.c_double
         _lib = L
     return _lib
 
@@ -122,3 +132,48 @@ def draws(d, chain_id, problem_id, t, seed=25):
     z = np.zeros(4); lu = C.c_double()
     lib().phfo_draws(d, chain_id, problem_id, t, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, _p(z), C.byref(lu))
     return z, lu.value
+
+
+def hier_prior(shapes, scales, locs):
+    pr = HierPrior()
+    for k in range(5):
+        pr.shape_m1[k] = shapes[k] - 1.0; pr.inv_scale[k] = 1.0 / scales[k]; pr.loc[k] = locs[k]
+    return pr
+
+
+class PackedHierPair:
+    """One pair, points stored experiment by experiment (kernel order of the hierarchical sampler)."""
+
+    def __init__(self, experiments, shapes, scales, locs):
+        self.n_expts = len(experiments)
+        self.dim = 5 + 2 * self.n_expts
+        sizes = [len(e) for e in experiments]
+        self.expt_start = np.ascontiguousarray(np.concatenate([[0], np.cumsum(sizes)]), dtype=np.int32)
+        conc = np.concatenate([np.asarray(e)[:, 0] for e in experiments]).astype(float)
+        with np.errstate(divide="ignore"):
+            self.ln_conc = np.ascontiguousarray(np.log(conc))
+        self.response = np.ascontiguousarray(np.concatenate([np.asarray(e)[:, 1] for e in experiments]).astype(float))
+        self.pb = HierProblem(self.n_expts, _p(self.expt_start), _p(self.ln_conc), _p(self.response), hier_prior(shapes, scales, locs))
+
+    def log_target(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        assert th.size == self.dim
+        return lib().phfo_hier_log_target(C.byref(self.pb), _p(th))
+
+    def init_state(self, theta0, cov_scale=0.01):
+        st = np.zeros(2 * self.dim + self.dim * (self.dim + 1) // 2 + 3)
+        th = np.ascontiguousarray(theta0, dtype=np.float64)
+        lib().phfo_hier_init_state(C.byref(self.pb), C.c_double(cov_scale), _p(th), _p(st))
+        return st
+
+    def advance(self, st, t_begin, t_end, thinning, adapt_start, gamma, seed=25, chain_id=0, problem_id=0,
+                star_replay=None, u_replay=None):
+        rows = t_end // thinning - t_begin // thinning
+        out = np.zeros((rows, self.dim + 1))
+        run = Run(t_begin, t_end, thinning, 0, adapt_start, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, chain_id,
+                  problem_id, _p(gamma))
+        sr = np.ascontiguousarray(star_replay, dtype=np.float64) if star_replay is not None else None
+        ur = np.ascontiguousarray(u_replay, dtype=np.float64) if u_replay is not None else None
+        lib().phfo_hier_advance(C.byref(self.pb), C.byref(run), _p(st), _p(out), _p(sr) if sr is not None else None,
+                                _p(ur) if ur is not None else None)
+        return out

@@ -13,15 +13,16 @@
  * draws come from the SAME source the kernels compile (phf_model.h on top of phf_math.h / phf_philox.h):
  * their evaluation order is tuned for the fp64 VALU and only a shared source can keep two builds bit-identical,
  * which is what makes "same seed => same accept sequence and bit-identical chain" testable on the GPU.
- * What pins that shared arithmetic to the reference is below, not the sharing.  PINNED two ways (tests/test_oracle_c.py): log-targets against the reference golden
- * vectors (<= 1e-12 relative), and the loop against reference traces by replaying the recorded
- * proposals/uniforms draw by draw.  Compile: see oracle/Makefile (-ffp-contract=off -mfma).
+ * What pins that shared arithmetic to the reference is below, not the sharing.
+ * PINNED (tests/test_oracle_c.py): log-targets, single-level and hierarchical, against the reference golden vectors
+ * (<= 1e-12 relative), and the loop against reference traces by replaying the recorded proposals/uniforms draw by draw.  Compile: see oracle/Makefile (-ffp-contract=off -mfma).
  */
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
 
 #include "../pyhillfit_amd/csrc/phf_model.h"
+#include "../pyhillfit_amd/csrc/phf_hier_model.h"
 
 typedef struct {
   int32_t model;                        /* 1: (pIC50, sigma), Hill = 1;  2: (pIC50, Hill, sigma) */
@@ -60,7 +61,7 @@ double phfo_log_target(const phfo_problem* pb, const double* th) {  /* doserespo
 /* lower Cholesky factor of a packed lower-triangular covariance (row-major), semi-definite safe:
  * a non-positive pivot zeroes its column (numpy's SVD-based sampler accepts such matrices too). */
 static void chol_packed(int d, const double* c, double* l) {
-  double inv[32];
+  double inv[128];
   for (int i = 0; i < d; ++i) {
     for (int j = 0; j <= i; ++j) {
       double s = c[i * (i + 1) / 2 + j];
@@ -91,17 +92,20 @@ void phfo_init_state(const phfo_problem* pb, int cov_identity, double cov_scale,
   cov[d * (d + 1) / 2 + 1] = 0.0;  /* accepted count */
 }
 
-/* Advance one chain.  out_rows receives (theta, log-target) for every t with t % thinning == 0,
- * densely.  If star_replay/u_replay are given the proposals and uniforms come from them (reference
- * trace replay) instead of Philox.  scaled_cov_trace, if given, receives exp(loga)*cov (d*d, full)
+/* Advance one chain of any dimension.  out_rows receives (theta, log-target) for every t with
+ * t % thinning == 0, densely.  If star_replay/u_replay are given the proposals and uniforms come from them
+ * (reference trace replay) instead of Philox.  scaled_cov_trace, if given, receives exp(loga)*cov (d*d, full)
  * as handed to the proposal at each iteration (what the reference passes to multivariate_normal). */
-void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, double* out_rows,
-                  const double* star_replay, const double* u_replay, double* scaled_cov_trace) {
-  const int d = (pb->model == 1) ? 2 : 3;
+#define PHFO_MAX_DIM 128
+typedef double (*target_fn)(const void* ctx, const double* th);
+
+static void advance_generic(int d, target_fn target, const void* ctx, const phfo_run* run, double* st,
+                            double* out_rows, const double* star_replay, const double* u_replay, double* scaled_cov_trace) {
   const int ntri = d * (d + 1) / 2;
   double* th = st; double* lt = st + d; double* mean = st + d + 1; double* cov = mean + d;
   double* loga = cov + ntri; double* nacc = loga + 1;
-  double L[6], z[4], star[3];
+  static __thread double L[PHFO_MAX_DIM * (PHFO_MAX_DIM + 1) / 2];
+  double z[PHFO_MAX_DIM + 4], star[PHFO_MAX_DIM], v[PHFO_MAX_DIM];
   chol_packed(d, cov, L);
   double sc = phf_exp_fast(0.5 * *loga);
   int64_t row = 0;
@@ -117,7 +121,7 @@ void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, doubl
       for (int i = 0; i < d; ++i) star[i] = star_replay[(t - run->t_begin - 1) * d + i];
       log_u = phf_log(u_replay[t - run->t_begin - 1]);
     } else {
-      /* PyHillFit.py:831 — theta* ~ N(theta, e^loga cov) drawn as theta + e^(loga/2) L z */
+      /* PyHillFit.py:831/485 — theta* ~ N(theta, e^loga cov) drawn as theta + e^(loga/2) L z */
       log_u = phf_mh_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, z);
       for (int i = 0; i < d; ++i) {
         double yv = L[i * (i + 1) / 2 + i] * z[i];
@@ -125,16 +129,15 @@ void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, doubl
         star[i] = phf_fma(sc, yv, th[i]);
       }
     }
-    const double lt_star = phfo_log_target(pb, star);                      /* :833 */
-    const int acc = log_u < lt_star - *lt;                            /* :834-838 */
+    const double lt_star = target(ctx, star);                                /* :833 / :486 */
+    const int acc = log_u < lt_star - *lt;                                   /* :834-838 / :487-492 */
     if (acc) { for (int i = 0; i < d; ++i) th[i] = star[i]; *lt = lt_star; }
     *nacc += (double)acc;
-    if (run->reset_mean && t == run->adapt_start)                          /* PyHillTemp.py:114-115 */
+    if (run->reset_mean && t == run->adapt_start)                            /* PyHillTemp.py:114-115 */
       for (int i = 0; i < d; ++i) mean[i] = th[i];
-    if (t > run->adapt_start) {                                            /* :840-846 */
+    if (t > run->adapt_start) {                                              /* :840-846 / :495-501 */
       const double g = run->gamma[t - run->adapt_start];
       const double omg = 1.0 - g;
-      double v[3];
       for (int i = 0; i < d; ++i) v[i] = th[i] - mean[i];
       for (int i = 0; i < d; ++i)
         for (int j = 0; j <= i; ++j) cov[i * (i + 1) / 2 + j] = phf_fma(g, v[i] * v[j], omg * cov[i * (i + 1) / 2 + j]);
@@ -143,7 +146,97 @@ void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, doubl
       chol_packed(d, cov, L);
       sc = phf_exp_fast(0.5 * *loga);
     }
-    if (t % run->thinning == 0) {                                          /* :847-848 */
+    if (t % run->thinning == 0) {                                            /* :847-848 / :502-503 */
+      for (int i = 0; i < d; ++i) out_rows[row * (d + 1) + i] = th[i];
+      out_rows[row * (d + 1) + d] = *lt;
+      ++row;
+    }
+  }
+}
+
+static double sl_target(const void* ctx, const double* th) { return phfo_log_target((const phfo_problem*)ctx, th); }
+
+void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, double* out_rows,
+                  const double* star_replay, const double* u_replay, double* scaled_cov_trace) {
+  advance_generic((pb->model == 1) ? 2 : 3, sl_target, pb, run, st, out_rows, star_replay, u_replay, scaled_cov_trace);
+}
+
+/* ---------------------------------------------------------------- hierarchical model (PyHillFit.py:113-193,429-511) */
+typedef struct {
+  int32_t n_expts;
+  const int32_t* expt_start;            /* [n_expts+1] */
+  const double* ln_conc;
+  const double* response;
+  phf_hier_prior prior;
+} phfo_hier_problem;
+
+double phfo_hier_log_target(const phfo_hier_problem* pb, const double* th) {
+  return phf_hier_log_target(pb->n_expts, pb->expt_start, pb->ln_conc, pb->response, th, 1, &pb->prior);
+}
+
+/* state: th[d], lt, mean[d], L[d(d+1)/2] (factor of the adapted covariance), loga, n_accepted */
+void phfo_hier_init_state(const phfo_hier_problem* pb, double cov_scale, const double* theta0, double* st) {
+  const int d = 5 + 2 * pb->n_expts;
+  double* th = st; double* lt = st + d; double* mean = st + d + 1; double* L = mean + d;
+  for (int i = 0; i < d; ++i) { th[i] = theta0[i]; mean[i] = theta0[i]; }   /* PyHillFit.py:433,442 */
+  for (int i = 0; i < d; ++i)                                               /* factor of diag(0.01 |theta0|), :431 */
+    for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = (i != j) ? 0.0 : phf_sqrt(cov_scale * __builtin_fabs(theta0[i]));
+  *lt = phfo_hier_log_target(pb, th);                                       /* :447 */
+  L[d * (d + 1) / 2] = 0.0;
+  L[d * (d + 1) / 2 + 1] = 0.0;
+}
+
+/* The hierarchical loop (PyHillFit.py:484-511).  The covariance recursion cov <- (1-g) cov + g v v' (:498-499) is
+ * carried on the Cholesky factor: scale by sqrt(1-g), then a rank-one update with sqrt(g) v by Givens rotations. */
+void phfo_hier_advance(const phfo_hier_problem* pb, const phfo_run* run, double* st, double* out_rows,
+                       const double* star_replay, const double* u_replay) {
+  const int d = 5 + 2 * pb->n_expts;
+  const int ntri = d * (d + 1) / 2;
+  double* th = st; double* lt = st + d; double* mean = st + d + 1; double* L = mean + d;
+  double* loga = L + ntri; double* nacc = loga + 1;
+  double z[PHFO_MAX_DIM + 4], star[PHFO_MAX_DIM], w[PHFO_MAX_DIM];
+  double sc = phf_exp_fast(0.5 * *loga);
+  int64_t row = 0;
+  for (int64_t t = run->t_begin + 1; t <= run->t_end; ++t) {
+    double log_u;
+    if (star_replay) {
+      for (int i = 0; i < d; ++i) star[i] = star_replay[(t - run->t_begin - 1) * d + i];
+      log_u = phf_log(u_replay[t - run->t_begin - 1]);
+    } else {
+      log_u = phf_hier_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, z, 1);
+      for (int i = 0; i < d; ++i) {                                        /* :485 */
+        double yv = L[i * (i + 1) / 2 + i] * z[i];
+        for (int k = i - 1; k >= 0; --k) yv = phf_fma(L[i * (i + 1) / 2 + k], z[k], yv);
+        star[i] = phf_fma(sc, yv, th[i]);
+      }
+    }
+    const double lt_star = phfo_hier_log_target(pb, star);                 /* :486 */
+    const int acc = log_u < lt_star - *lt;                                 /* :487-492 */
+    if (acc) { for (int i = 0; i < d; ++i) th[i] = star[i]; *lt = lt_star; }
+    *nacc += (double)acc;
+    if (t > run->adapt_start) {                                            /* :495-501 */
+      const double g = run->gamma[t - run->adapt_start];
+      const double omg = 1.0 - g;
+      const double sqa = phf_sqrt(omg), sqg = phf_sqrt(g);
+      for (int i = 0; i < d; ++i) w[i] = sqg * (th[i] - mean[i]);
+      for (int i = 0; i < d; ++i) mean[i] = phf_fma(g, th[i], omg * mean[i]);
+      *loga = phf_fma(g, (double)acc - 0.25, *loga);
+      for (int k = 0; k < d; ++k) {
+        const double tkk = sqa * L[k * (k + 1) / 2 + k];
+        const double r = phf_sqrt(phf_fma(tkk, tkk, w[k] * w[k]));
+        const double inv = (r > 0.0) ? 1.0 / r : 0.0;
+        const double cs = (r > 0.0) ? tkk * inv : 1.0;
+        const double sn = w[k] * inv;
+        L[k * (k + 1) / 2 + k] = r;
+        for (int i = k + 1; i < d; ++i) {
+          const double tik = sqa * L[i * (i + 1) / 2 + k];
+          L[i * (i + 1) / 2 + k] = phf_fma(cs, tik, sn * w[i]);
+          w[i] = phf_fma(cs, w[i], -(sn * tik));
+        }
+      }
+      sc = phf_exp_fast(0.5 * *loga);
+    }
+    if (t % run->thinning == 0) {                                          /* :502-503 */
       for (int i = 0; i < d; ++i) out_rows[row * (d + 1) + i] = th[i];
       out_rows[row * (d + 1) + d] = *lt;
       ++row;

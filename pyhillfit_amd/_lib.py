@@ -10,7 +10,9 @@ ABI_VERSION = 1
 
 # every symbol include/pyhillfit_amd.h declares
 EXPORTS = ["phf_version", "phf_last_error", "phf_single_level_state_size", "phf_single_level_init",
-           "phf_single_level_advance", "phf_single_level_log_target", "phf_debug_math", "phf_debug_philox"]
+           "phf_single_level_advance", "phf_single_level_log_target", "phf_debug_math", "phf_debug_philox",
+           "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance",
+           "phf_hierarchical_log_target"]
 
 
 class PhfError(RuntimeError):

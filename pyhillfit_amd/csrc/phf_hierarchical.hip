@@ -1,0 +1,337 @@
+// phf_hierarchical.hip — gfx950 kernels for PyHillFit's hierarchical sampler (python/PyHillFit.py:113-193,429-511).
+//
+// One lane = one Markov chain of dimension dim = 5 + 2 Ne (11..17 for the Crumb set); a wavefront advances 64
+// chains of the same (drug, channel) pair in lock-step.  The kernel is compiled per Ne so that theta, mean and the
+// proposal live in registers with static indices.  What does not fit in registers is the proposal factor: the
+// lower Cholesky factor L of the adapted covariance (dim(dim+1)/2 = 66..153 doubles per chain) lives in LDS as
+// L[element][lane] (stride 64 doubles: every ds_read/ds_write is conflict-free, 34..78 KB per wavefront) for the
+// whole launch, so that its two passes per iteration (y = L z, and the rank-one adaptation update) cost no HBM
+// traffic at all.  HBM sees the state once per launch and the thinned samples.
+#include <hip/hip_runtime.h>
+
+#include "../../include/pyhillfit_amd.h"
+#include "phf_common.h"
+#include "phf_hier_model.h"
+
+namespace {
+
+constexpr int kBlock = 64;
+
+struct HierArgs {
+  phf_hier_points pts;
+  phf_problems prob;
+  phf_hier_prior prior;
+  phf_mh_config cfg;
+  int64_t t_begin, t_end;
+  double* state;
+  double* rows;
+  double* moments;
+  int64_t moments_after;
+  int32_t blocks_per_problem;
+  // init only
+  double cov_scale;
+  const double* theta0;
+  double* row0;
+};
+
+// LDS layout: [tri][64] factor, then ln_conc[stride], response[stride], expt_start[NE+1]
+template <int NE>
+struct Lds {
+  static constexpr int dim = 5 + 2 * NE;
+  static constexpr int tri = dim * (dim + 1) / 2;
+  static size_t bytes(int stride) { return (size_t)tri * kBlock * 8 + (size_t)stride * 16 + (NE + 1) * 4 + 8; }
+};
+
+template <int NE>
+__device__ __forceinline__ void stage(const phf_hier_points& pts, int pair, double* s_lc, double* s_y, int* s_es) {
+  const int n = pts.expt_start[(size_t)pair * (NE + 1) + NE];
+  for (int j = threadIdx.x; j < n; j += kBlock) {
+    s_lc[j] = pts.ln_conc[(size_t)pair * pts.stride + j];
+    s_y[j] = pts.response[(size_t)pair * pts.stride + j];
+  }
+  if (threadIdx.x <= NE) s_es[threadIdx.x] = pts.expt_start[(size_t)pair * (NE + 1) + threadIdx.x];
+  __syncthreads();
+}
+
+template <int NE>
+__global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) {
+  constexpr int D = 5 + 2 * NE;
+  constexpr int TRI = D * (D + 1) / 2;
+  extern __shared__ double s_mem[];
+  double* sL = s_mem + threadIdx.x;                       // element e of this lane's factor: sL[e * 64]
+  double* s_lc = s_mem + (size_t)TRI * kBlock;
+  double* s_y = s_lc + a.pts.stride;
+  int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
+  const int q = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - q * a.blocks_per_problem;
+  const int C = a.prob.chains_per_problem;
+  const int c = chunk * kBlock + threadIdx.x;
+  const int pair = a.prob.pair_index[q];
+  stage<NE>(a.pts, pair, s_lc, s_y, s_es);
+  if (c >= C) return;
+  const uint32_t pid = a.prob.problem_id[q];
+  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
+  const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
+  const size_t nchains = (size_t)a.prob.num_problems * C;
+  const size_t g = (size_t)q * C + c;
+
+  double th[D], mean[D];
+  double* sp = a.state + g;
+#pragma unroll
+  for (int i = 0; i < D; ++i) th[i] = sp[(size_t)i * nchains];
+  double lt = sp[(size_t)D * nchains];
+#pragma unroll
+  for (int i = 0; i < D; ++i) mean[i] = sp[(size_t)(D + 1 + i) * nchains];
+  for (int e = 0; e < TRI; ++e) sL[e * kBlock] = sp[(size_t)(2 * D + 1 + e) * nchains];
+  double loga = sp[(size_t)(2 * D + 1 + TRI) * nchains];
+  double nacc = sp[(size_t)(2 * D + 2 + TRI) * nchains];
+  double sc = phf_exp_fast(0.5 * loga);
+
+  const bool want_moments = a.moments != nullptr;
+  const int thin = a.cfg.thinning;
+  int until_save = thin - (int)(a.t_begin % thin);
+  double* out = a.rows ? a.rows + ((size_t)q * (D + 1)) * C + c : nullptr;
+  const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
+
+  for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
+    // ---- proposal theta* = theta + e^(loga/2) L z   (PyHillFit.py:485) ----
+    double z[D], star[D];
+    const double log_u = phf_hier_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, z, 1);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double v = sL[(i * (i + 1) / 2 + i) * kBlock] * z[i];
+#pragma unroll
+      for (int k = i - 1; k >= 0; --k) v = phf_fma(sL[(i * (i + 1) / 2 + k) * kBlock], z[k], v);
+      star[i] = phf_fma(sc, v, th[i]);
+    }
+    // ---- target, accept (:486-492) ----
+    const double lt_star = phf_hier_log_target(NE, s_es, s_lc, s_y, star, 1, &a.prior);
+    const bool acc = log_u < lt_star - lt;
+    if (acc) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) th[i] = star[i];
+      lt = lt_star;
+    }
+    nacc += acc ? 1.0 : 0.0;
+    // ---- adaptation (:495-501): cov <- (1-g) cov + g v v' applied to the factor as a rank-one update ----
+    if (t > a.cfg.adapt_start) {
+      const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
+      const double omg = 1.0 - gs;
+      const double sqa = phf_sqrt(omg), sqg = phf_sqrt(gs);
+      double w[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) w[i] = sqg * (th[i] - mean[i]);
+#pragma unroll
+      for (int i = 0; i < D; ++i) mean[i] = phf_fma(gs, th[i], omg * mean[i]);
+      loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {                        // Givens sweep down column k
+        const double tkk = sqa * sL[(k * (k + 1) / 2 + k) * kBlock];
+        const double r = phf_sqrt(phf_fma(tkk, tkk, w[k] * w[k]));
+        const double inv = (r > 0.0) ? 1.0 / r : 0.0;
+        const double cs = (r > 0.0) ? tkk * inv : 1.0;
+        const double sn = w[k] * inv;
+        sL[(k * (k + 1) / 2 + k) * kBlock] = r;
+#pragma unroll
+        for (int i = k + 1; i < D; ++i) {
+          const double tik = sqa * sL[(i * (i + 1) / 2 + k) * kBlock];
+          sL[(i * (i + 1) / 2 + k) * kBlock] = phf_fma(cs, tik, sn * w[i]);
+          w[i] = phf_fma(cs, w[i], -(sn * tik));
+        }
+      }
+      sc = phf_exp_fast(0.5 * loga);
+    }
+    // ---- thinning + sample store (:502-503) ----
+    if (--until_save == 0) {
+      until_save = thin;
+      if (out) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) out[(size_t)i * C] = th[i];
+        out[(size_t)D * C] = lt;
+        out += row_stride;
+      }
+      if (want_moments && t > a.moments_after) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          a.moments[(size_t)i * nchains + g] += th[i];
+          a.moments[(size_t)(D + 1 + i) * nchains + g] = phf_fma(th[i], th[i], a.moments[(size_t)(D + 1 + i) * nchains + g]);
+        }
+        a.moments[(size_t)D * nchains + g] += lt;
+        a.moments[(size_t)(2 * D + 1) * nchains + g] = phf_fma(lt, lt, a.moments[(size_t)(2 * D + 1) * nchains + g]);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < D; ++i) sp[(size_t)i * nchains] = th[i];
+  sp[(size_t)D * nchains] = lt;
+#pragma unroll
+  for (int i = 0; i < D; ++i) sp[(size_t)(D + 1 + i) * nchains] = mean[i];
+  for (int e = 0; e < TRI; ++e) sp[(size_t)(2 * D + 1 + e) * nchains] = sL[e * kBlock];
+  sp[(size_t)(2 * D + 1 + TRI) * nchains] = loga;
+  sp[(size_t)(2 * D + 2 + TRI) * nchains] = nacc;
+}
+
+template <int NE>
+__global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
+  constexpr int D = 5 + 2 * NE;
+  constexpr int TRI = D * (D + 1) / 2;
+  extern __shared__ double s_mem[];
+  double* s_lc = s_mem;
+  double* s_y = s_lc + a.pts.stride;
+  int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
+  const int q = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - q * a.blocks_per_problem;
+  const int C = a.prob.chains_per_problem;
+  const int c = chunk * kBlock + threadIdx.x;
+  const int pair = a.prob.pair_index[q];
+  stage<NE>(a.pts, pair, s_lc, s_y, s_es);
+  if (c >= C) return;
+  const size_t nchains = (size_t)a.prob.num_problems * C;
+  const size_t g = (size_t)q * C + c;
+  double th[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
+  const double lt = phf_hier_log_target(NE, s_es, s_lc, s_y, th, 1, &a.prior);
+  double* sp = a.state + g;
+#pragma unroll
+  for (int i = 0; i < D; ++i) { sp[(size_t)i * nchains] = th[i]; sp[(size_t)(D + 1 + i) * nchains] = th[i]; }
+  sp[(size_t)D * nchains] = lt;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j)   // factor of diag(cov_scale |theta0|)  (PyHillFit.py:431)
+      sp[(size_t)(2 * D + 1 + i * (i + 1) / 2 + j) * nchains] = (i != j) ? 0.0 : phf_sqrt(a.cov_scale * __builtin_fabs(th[i]));
+  sp[(size_t)(2 * D + 1 + TRI) * nchains] = 0.0;
+  sp[(size_t)(2 * D + 2 + TRI) * nchains] = 0.0;
+  if (a.row0) {
+    double* o = a.row0 + ((size_t)q * (D + 1)) * C + c;
+#pragma unroll
+    for (int i = 0; i < D; ++i) o[(size_t)i * C] = th[i];
+    o[(size_t)D * C] = lt;
+  }
+}
+
+template <int NE>
+__global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_points pts, const phf_hier_prior prior, int64_t m,
+                                                                 const int32_t* pair_index, const double* theta, double* out) {
+  constexpr int D = 5 + 2 * NE;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const int pair = pair_index[i];
+  double th[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
+  out[i] = phf_hier_log_target(NE, pts.expt_start + (size_t)pair * (NE + 1), pts.ln_conc + (size_t)pair * pts.stride,
+                               pts.response + (size_t)pair * pts.stride, th, 1, &prior);
+}
+
+int check(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior) {
+  if (!pts || !prior) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null hierarchical points/prior");
+  if (pts->n_expts < 1 || pts->n_expts > PHF_HIER_MAX_EXPTS)
+    return phf_fail(PHF_ERR_UNSUPPORTED, "hierarchical sampler supports 1..8 experiments per pair");
+  if (pts->num_pairs <= 0 || pts->stride <= 0 || !pts->ln_conc || !pts->response || !pts->expt_start)
+    return phf_fail(PHF_ERR_INVALID_ARGUMENT, "incomplete phf_hier_points");
+  if (prob) {
+    if (prob->num_problems <= 0 || prob->chains_per_problem <= 0 || !prob->pair_index || !prob->problem_id)
+      return phf_fail(PHF_ERR_INVALID_ARGUMENT, "incomplete phf_problems");
+    const int64_t bpp = (prob->chains_per_problem + kBlock - 1) / kBlock;
+    if (bpp * prob->num_problems > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
+  }
+  return PHF_OK;
+}
+
+template <int NE>
+int launch_advance(const HierArgs& a, hipStream_t stream) {
+  const size_t lds = Lds<NE>::bytes(a.pts.stride);
+  if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_advance_kernel<NE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    configured = true;
+  }
+  const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
+  hipLaunchKernelGGL(hier_advance_kernel<NE>, grid, block, lds, stream, a);
+  return phf_check_launch("phf_hierarchical_advance");
+}
+
+template <int NE>
+int launch_init(const HierArgs& a, hipStream_t stream) {
+  const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
+  hipLaunchKernelGGL(hier_init_kernel<NE>, grid, block, (size_t)a.pts.stride * 16 + (NE + 1) * 4 + 8, stream, a);
+  return phf_check_launch("phf_hierarchical_init");
+}
+
+#define PHF_DISPATCH_NE(ne, FN, ...)                                \
+  switch (ne) {                                                     \
+    case 1: return FN<1>(__VA_ARGS__);                              \
+    case 2: return FN<2>(__VA_ARGS__);                              \
+    case 3: return FN<3>(__VA_ARGS__);                              \
+    case 4: return FN<4>(__VA_ARGS__);                              \
+    case 5: return FN<5>(__VA_ARGS__);                              \
+    case 6: return FN<6>(__VA_ARGS__);                              \
+    case 7: return FN<7>(__VA_ARGS__);                              \
+    default: return FN<8>(__VA_ARGS__);                             \
+  }
+
+int dispatch_advance(const HierArgs& a, hipStream_t s) { PHF_DISPATCH_NE(a.pts.n_expts, launch_advance, a, s) }
+int dispatch_init(const HierArgs& a, hipStream_t s) { PHF_DISPATCH_NE(a.pts.n_expts, launch_init, a, s) }
+
+template <int NE>
+int launch_log_target(const phf_hier_points& pts, const phf_hier_prior& prior, int64_t m, const int32_t* pair_index,
+                      const double* theta, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(hier_log_target_kernel<NE>, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, pts, prior, m,
+                     pair_index, theta, out);
+  return phf_check_launch("phf_hierarchical_log_target");
+}
+
+}  // namespace
+
+extern "C" {
+
+int phf_hierarchical_state_size(int n_expts) {
+  if (n_expts < 1 || n_expts > PHF_HIER_MAX_EXPTS) return phf_fail(PHF_ERR_UNSUPPORTED, "hierarchical sampler supports 1..8 experiments per pair");
+  const int d = 5 + 2 * n_expts;
+  return 2 * d + d * (d + 1) / 2 + 3;
+}
+
+int phf_hierarchical_init(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
+                          double cov_scale, const double* theta0, double* state, double* row0, void* stream) {
+  if (!prob) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null problems");
+  if (int rc = check(pts, prob, prior)) return rc;
+  if (!theta0 || !state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null theta0/state");
+  HierArgs a{};
+  a.pts = *pts; a.prob = *prob; a.prior = *prior; a.state = state; a.cov_scale = cov_scale; a.theta0 = theta0; a.row0 = row0;
+  a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
+  return dispatch_init(a, (hipStream_t)stream);
+}
+
+int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
+                             const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
+                             double* moments, int64_t moments_after, void* stream) {
+  if (!prob || !cfg) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null problems/config");
+  if (int rc = check(pts, prob, prior)) return rc;
+  if (!state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null state");
+  if (cfg->thinning <= 0) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "thinning must be positive");
+  if (t_begin < 0 || t_end < t_begin || t_end > 0xffffffffLL) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad iteration range");
+  if (t_end > cfg->adapt_start && !cfg->gamma) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "gamma table required once adapting");
+  if (t_end == t_begin) return PHF_OK;
+  HierArgs a{};
+  a.pts = *pts; a.prob = *prob; a.prior = *prior; a.cfg = *cfg; a.t_begin = t_begin; a.t_end = t_end; a.state = state; a.rows = rows;
+  a.moments = moments; a.moments_after = moments_after;
+  a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
+  return dispatch_advance(a, (hipStream_t)stream);
+}
+
+int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior* prior, int64_t m,
+                                const int32_t* pair_index, const double* theta, double* out, void* stream) {
+  if (int rc = check(pts, nullptr, prior)) return rc;
+  if (m < 0 || !pair_index || !theta || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_hierarchical_log_target");
+  if (m == 0) return PHF_OK;
+  PHF_DISPATCH_NE(pts->n_expts, launch_log_target, *pts, *prior, m, pair_index, theta, out, (hipStream_t)stream)
+}
+
+}  // extern "C"

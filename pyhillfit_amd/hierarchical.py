@@ -1,0 +1,317 @@
+"""Host side of the hierarchical sampler (python/PyHillFit.py --hierarchical: run_hierarchical :213-642).
+
+Mirrors the reference's set-up — per-experiment least-squares fits (:243-257), initial (alpha, beta) and (mu, s)
+from those fits (:310-336), Gamma hyper-priors from the Elkins constants (:340-364), first covariance
+diag(0.01*|theta0|) (:431), adaptation after 100*dim iterations (:440) — and hands the loop (:484-511) to the HIP
+kernels.  Pairs are grouped by their number of experiments Ne (one kernel instantiation per Ne)."""
+import ctypes as C
+import json
+import time
+
+import numpy as np
+import torch
+from scipy.optimize import minimize
+import scipy.stats as st
+
+from . import _lib, bestfit, chainio
+from . import doseresponse as dr
+from .sampler import _ptr, _stream_ptr, gamma_table
+
+# ---- Gamma hyper-priors: python/PyHillFit.py:301,340-364 (numbers from Elkins et al., as in the reference) ----------
+ELKINS_HILL_ALPHAS = np.array([1.188, 1.744, 1.530, 0.930, 0.605, 1.325, 1.179, 0.979, 1.790, 1.708, 1.586, 1.469,
+                               1.429, 1.127, 1.011, 1.318, 1.063])
+ELKINS_HILL_BETAS = 1. / np.array([0.0835, 0.1983, 0.2089, 0.1529, 0.1206, 0.2386, 0.2213, 0.2263, 0.1784, 0.1544,
+                                   0.2486, 0.2031, 0.2025, 0.1510, 0.1837, 0.1677, 0.0862])
+ELKINS_PIC50_MUS = np.array([5.235, 5.765, 6.060, 5.315, 5.571, 7.378, 7.248, 5.249, 6.408, 5.625, 7.321, 6.852, 6.169,
+                             6.217, 5.927, 7.414, 4.860])
+ELKINS_PIC50_SIGMAS = np.array([0.0760, 0.1388, 0.1459, 0.2044, 0.1597, 0.2216, 0.1856, 0.1560, 0.1034, 0.1033, 0.1914,
+                                0.1498, 0.1464, 0.1053, 0.1342, 0.1808, 0.0860])
+MAX_EXPTS = 8     # PHF_HIER_MAX_EXPTS
+
+
+def prior_params():
+    """(shapes, scales, locs) for (alpha, beta, mu, s, sigma): PyHillFit.py:301,349-364."""
+    locs = np.array([0., 2., -4, 0.01, dr.sigma_loc])
+    modes = np.array([np.mean(ELKINS_HILL_ALPHAS), np.mean(ELKINS_HILL_BETAS) - 2., np.mean(ELKINS_PIC50_MUS),
+                      np.mean(ELKINS_PIC50_SIGMAS), dr.sigma_mode])
+    shapes = np.array([5., 2.5, 7.5, 2.5, dr.sigma_shape])
+    scales = (modes - locs) / (shapes - 1.)
+    return shapes, scales, locs
+
+
+class HierPrior(C.Structure):
+    _fields_ = [("shape_m1", C.c_double * 5), ("inv_scale", C.c_double * 5), ("loc", C.c_double * 5)]
+
+
+class HierPoints(C.Structure):
+    _fields_ = [("num_pairs", C.c_int32), ("stride", C.c_int32), ("n_expts", C.c_int32), ("reserved", C.c_int32),
+                ("ln_conc", C.c_void_p), ("response", C.c_void_p), ("expt_start", C.c_void_p)]
+
+
+def make_prior(shapes=None, scales=None, locs=None):
+    if shapes is None:
+        shapes, scales, locs = prior_params()
+    pr = HierPrior()
+    for k in range(5):
+        pr.shape_m1[k] = shapes[k] - 1.0; pr.inv_scale[k] = 1.0 / scales[k]; pr.loc[k] = locs[k]
+    return pr
+
+
+class PackedHierPoints(object):
+    """numpy image of `phf_hier_points`: pairs that all have Ne experiments, points experiment by experiment."""
+
+    def __init__(self, experiments_per_pair):
+        ne = {len(e) for e in experiments_per_pair}
+        if len(ne) != 1:
+            raise ValueError("all pairs of one PackedHierPoints must have the same number of experiments")
+        self.n_expts = ne.pop()
+        self.num_pairs = len(experiments_per_pair)
+        self.stride = max(sum(len(x) for x in e) for e in experiments_per_pair)
+        self.ln_conc = np.zeros((self.num_pairs, self.stride))
+        self.response = np.zeros((self.num_pairs, self.stride))
+        self.expt_start = np.zeros((self.num_pairs, self.n_expts + 1), dtype=np.int32)
+        for p, expts in enumerate(experiments_per_pair):
+            conc = np.concatenate([np.asarray(x)[:, 0] for x in expts]).astype(float)
+            y = np.concatenate([np.asarray(x)[:, 1] for x in expts]).astype(float)
+            with np.errstate(divide="ignore"):
+                self.ln_conc[p, :len(conc)] = np.log(conc)
+            self.response[p, :len(y)] = y
+            self.expt_start[p] = np.concatenate([[0], np.cumsum([len(x) for x in expts])])
+
+
+class DeviceHierPoints(object):
+    def __init__(self, packed, device):
+        self.packed = packed
+        self.device = torch.device(device)
+        self.ln_conc = torch.from_numpy(packed.ln_conc).to(self.device)
+        self.response = torch.from_numpy(packed.response).to(self.device)
+        self.expt_start = torch.from_numpy(packed.expt_start).to(self.device)
+        self.struct = HierPoints(packed.num_pairs, packed.stride, packed.n_expts, 0, self.ln_conc.data_ptr(),
+                                 self.response.data_ptr(), self.expt_start.data_ptr())
+
+
+def _bind(lib):
+    if getattr(lib, "_phf_hier_bound", False):
+        return
+    vp, i64, f64 = C.c_void_p, C.c_int64, C.c_double
+    lib.phf_hierarchical_state_size.argtypes = [C.c_int]
+    lib.phf_hierarchical_init.argtypes = [C.POINTER(HierPoints), C.POINTER(_lib.Problems), C.POINTER(HierPrior), f64, vp, vp, vp, vp]
+    lib.phf_hierarchical_advance.argtypes = [C.POINTER(HierPoints), C.POINTER(_lib.Problems), C.POINTER(HierPrior),
+                                             C.POINTER(_lib.MhConfig), i64, i64, vp, vp, vp, i64, vp]
+    lib.phf_hierarchical_log_target.argtypes = [C.POINTER(HierPoints), C.POINTER(HierPrior), i64, vp, vp, vp, vp]
+    lib._phf_hier_bound = True
+
+
+def log_target_batch(packed, pair_index, theta, prior=None, device="cuda"):
+    """log_target_distribution (PyHillFit.py:173-193) of M parameter vectors theta[M][dim] on the GPU."""
+    lib = _lib.load(); _bind(lib)
+    dev = torch.device(device)
+    pts = packed if isinstance(packed, DeviceHierPoints) else DeviceHierPoints(packed, dev)
+    prior = prior or make_prior()
+    theta = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
+    m, dim = theta.shape
+    if dim != 5 + 2 * pts.packed.n_expts:
+        raise ValueError("theta must have 5 + 2*Ne columns")
+    th = torch.from_numpy(np.ascontiguousarray(theta.T)).to(dev)
+    pi = torch.from_numpy(np.ascontiguousarray(pair_index, dtype=np.int32)).to(dev)
+    out = torch.empty(m, dtype=torch.float64, device=dev)
+    _lib.check(lib.phf_hierarchical_log_target(C.byref(pts.struct), C.byref(prior), m, _ptr(pi), _ptr(th), _ptr(out),
+                                               _stream_ptr(dev)), "phf_hierarchical_log_target")
+    return out.cpu().numpy()
+
+
+class HierarchicalSampler(object):
+    """Q pairs (all with Ne experiments) x C chains of the hierarchical adaptive-Metropolis sampler on one GPU."""
+
+    def __init__(self, points, pair_index, chains_per_problem, thinning=5, seed=25, adapt_start=None, prior=None,
+                 problem_ids=None, chain_id_base=0, device="cuda"):
+        self.lib = _lib.load(); _bind(self.lib)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PhfError("pyhillfit_amd samplers run on a HIP device only (got %s)" % self.device)
+        self.points = points if isinstance(points, DeviceHierPoints) else DeviceHierPoints(points, self.device)
+        self.n_expts = self.points.packed.n_expts
+        self.d = 5 + 2 * self.n_expts
+        self.Q, self.C = len(pair_index), int(chains_per_problem)
+        self.thinning, self.seed = int(thinning), int(seed)
+        self.adapt_start = 100 * self.d if adapt_start is None else int(adapt_start)      # PyHillFit.py:440
+        self.prior = prior or make_prior()
+        dev = self.device
+        self.pair_index = torch.tensor(np.asarray(pair_index, dtype=np.int32), device=dev)
+        self.temperature = torch.ones(self.Q, dtype=torch.float64, device=dev)
+        ids = np.arange(self.Q) if problem_ids is None else np.asarray(problem_ids)
+        self.problem_ids = torch.tensor(ids.astype(np.int64), device=dev).to(torch.int32)
+        self.prob = _lib.Problems(self.Q, self.C, self.pair_index.data_ptr(), self.temperature.data_ptr(),
+                                  self.problem_ids.data_ptr(), int(chain_id_base) & 0xFFFFFFFF, 0)
+        self.S = self.lib.phf_hierarchical_state_size(self.n_expts)
+        if self.S < 0:
+            raise _lib.PhfError(self.lib.phf_last_error().decode())
+        self.state = torch.zeros((self.S, self.Q * self.C), dtype=torch.float64, device=dev)
+        self.moments, self.moments_after, self.t, self.row0, self._gamma = None, 0, 0, None, None
+
+    def init(self, theta0, cov_scale=0.01):
+        """theta0: [dim], [Q][dim] or [Q][C][dim]"""
+        th = torch.as_tensor(np.asarray(theta0, dtype=np.float64), device=self.device)
+        if th.dim() == 1:
+            th = th.view(1, 1, self.d).expand(self.Q, self.C, self.d)
+        elif th.dim() == 2:
+            th = th.view(self.Q, 1, self.d).expand(self.Q, self.C, self.d)
+        th = th.permute(2, 0, 1).reshape(self.d, self.Q * self.C).contiguous()
+        self.row0 = torch.empty((self.Q, self.d + 1, self.C), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.phf_hierarchical_init(C.byref(self.points.struct), C.byref(self.prob), C.byref(self.prior),
+                                                  float(cov_scale), _ptr(th), _ptr(self.state), _ptr(self.row0),
+                                                  _stream_ptr(self.device)), "phf_hierarchical_init")
+        self.t = 0
+        return self.row0
+
+    def enable_moments(self, after_iteration=0):
+        self.moments = torch.zeros((2 * (self.d + 1), self.Q * self.C), dtype=torch.float64, device=self.device)
+        self.moments_after = int(after_iteration)
+
+    def _config(self, t_end):
+        need = max(0, t_end - self.adapt_start)
+        if self._gamma is None or self._gamma.numel() < need + 1:
+            self._gamma = torch.from_numpy(gamma_table(max(need, 1))).to(self.device)
+        return _lib.MhConfig(2, self.thinning, self.adapt_start, 0, 0, self.seed, self._gamma.data_ptr())
+
+    def reserve(self, total_iterations):
+        self._config(int(total_iterations))
+
+    def rows_between(self, t_begin, t_end):
+        return t_end // self.thinning - t_begin // self.thinning
+
+    def advance(self, n_iterations, out=None, save=True):
+        t_end = self.t + int(n_iterations)
+        cfg = self._config(t_end)
+        rows = None
+        if save:
+            shape = (self.rows_between(self.t, t_end), self.Q, self.d + 1, self.C)
+            rows = torch.empty(shape, dtype=torch.float64, device=self.device) if out is None else out
+            if tuple(rows.shape) != shape or not rows.is_contiguous():
+                raise ValueError("out must be contiguous with shape %s" % (shape,))
+        _lib.check(self.lib.phf_hierarchical_advance(C.byref(self.points.struct), C.byref(self.prob), C.byref(self.prior),
+                                                     C.byref(cfg), self.t, t_end, _ptr(self.state), _ptr(rows),
+                                                     _ptr(self.moments), self.moments_after, _stream_ptr(self.device)),
+                   "phf_hierarchical_advance")
+        self.t = t_end
+        return rows
+
+    def acceptance(self):
+        return self.state[-1].view(self.Q, self.C) / max(self.t, 1)
+
+    def posterior_moments(self):
+        n = self.t // self.thinning - self.moments_after // self.thinning
+        k = self.d + 1
+        s1 = self.moments[:k].view(k, self.Q, self.C); s2 = self.moments[k:].view(k, self.Q, self.C)
+        mean = s1 / n
+        return mean, (s2 - s1 * mean) / max(n - 1, 1), n
+
+
+# ---- start point (replaces the CMA-ES / scipy fits of PyHillFit.py:243-257,310-336) ----------------------------------
+def first_iteration(experiments, locs):
+    """theta0 = [alpha, beta, mu, s, pIC50_1, Hill_1, ..., sigma] as the reference builds it (:336), with
+    deterministic least-squares / maximum-likelihood fits instead of CMA-ES."""
+    best_fits = []
+    for ex in experiments:                                           # :243-257  per-experiment (pIC50, Hill) fit
+        th, ss = _fit_pic50_hill(ex[:, 0], ex[:, 1])
+        best_fits.append([th[0], th[1], np.sqrt(ss / len(ex))])      # initial_sigma, :101-102,255
+    best_fits = np.array(best_fits)
+    sigma_cur = np.mean(best_fits[:, -1])                            # :303-305
+    if sigma_cur <= locs[3]:
+        sigma_cur = locs[3] + 0.1
+    hills = np.maximum(best_fits[:, 1], 1e-3)
+    nll = lambda x: -np.sum(st.fisk.logpdf(hills, c=abs(x[1]) + 1e-9, scale=abs(x[0]) + 1e-9))   # :310-324 (product of pdfs)
+    res = minimize(nll, np.array([max(np.median(hills), 0.1), 3.0]), method="Nelder-Mead", options={"xatol": 1e-8, "fatol": 1e-10})
+    alpha_cur, beta_cur = abs(res.x[0]), min(abs(res.x[1]), 20.0)
+    if alpha_cur <= locs[0]:
+        alpha_cur = locs[0] + 0.1
+    if beta_cur <= locs[1]:
+        beta_cur = locs[1] + 0.1
+    mu_cur, s_cur = st.logistic.fit(best_fits[:, 0])                 # :330
+    if mu_cur <= locs[2]:
+        mu_cur = locs[2] + 0.1
+    if s_cur <= locs[3]:
+        s_cur = locs[3] + 0.1
+    return np.concatenate(([alpha_cur, beta_cur, mu_cur, s_cur], best_fits[:, :-1].flatten(), [sigma_cur]))
+
+
+def _fit_pic50_hill(concs, responses):
+    """sum-of-squares fit with pIC50 >= -2, Hill >= 0 (pic50_hill_priors_lowers, PyHillFit.py:218,253)."""
+    lowers = np.array([-2., 0.])
+    p_grid = np.linspace(-2.0, 12.0, 57); h_grid = np.exp(np.linspace(np.log(0.05), np.log(10.0), 30))
+    with np.errstate(all="ignore"):
+        pred = bestfit._curve(concs[None, None, :], p_grid[:, None, None], h_grid[None, :, None])
+        ss = np.sum((pred - responses) ** 2, axis=2)
+    ip, ih = np.unravel_index(np.argmin(ss), ss.shape)
+    x0 = np.sqrt(np.array([p_grid[ip], h_grid[ih]]) - lowers)
+    res = minimize(lambda x: bestfit.sum_of_square_diffs(x ** 2 + lowers, concs, responses), x0, method="Nelder-Mead",
+                   options={"xatol": 1e-9, "fatol": 1e-11, "maxiter": 6000})
+    return res.x ** 2 + lowers, float(res.fun)
+
+
+# ---- driver ------------------------------------------------------------------------------------------------------------
+def run_hierarchical(pairs, args, device, rank=0, world=1):
+    """All pairs of this rank — replaces python/PyHillFit.py:213-642 run per pair."""
+    shapes, scales, locs = prior_params()
+    prior = make_prior(shapes, scales, locs)
+    groups = {}
+    all_pairs = [(a, b) for a in dr.drugs for b in dr.channels]
+    for drug, channel in pairs:
+        try:
+            num_expts, experiment_numbers, experiments = dr.load_crumb_data(drug, channel)
+        except Exception:
+            print("Problem loading data for {} + {} --- skipping".format(drug, channel)); continue
+        if 0 < args.num_expts < num_expts:                            # :228-231
+            num_expts = args.num_expts
+            experiments = experiments[:num_expts]
+        experiments = experiments[:num_expts] if len(experiments) > num_expts else experiments
+        ne = len(experiments)
+        if ne > MAX_EXPTS:
+            print("{} + {}: {} experiments exceed the {} supported by the hierarchical kernels --- skipping".format(drug, channel, ne, MAX_EXPTS))
+            continue
+        groups.setdefault(ne, []).append((drug, channel, experiments, all_pairs.index((drug, channel))))
+    summaries = []
+    total_iterations, thinning = args.iterations, args.thinning
+    saved_iterations = total_iterations // thinning + 1                # :469
+    burn = saved_iterations // 4                                       # :472
+    rng = np.random.RandomState(args.seed)
+    for ne, members in sorted(groups.items()):
+        packed = PackedHierPoints([m[2] for m in members])
+        theta0 = np.array([first_iteration(m[2], locs) for m in members])
+        Q, C, d = len(members), args.num_chains, 5 + 2 * ne
+        s = HierarchicalSampler(packed, list(range(Q)), C, thinning=thinning, seed=args.seed, prior=prior,
+                                problem_ids=[m[3] for m in members], device=device)
+        s.init(theta0, cov_scale=0.01)                                 # :431
+        s.enable_moments(after_iteration=max(burn * thinning - 1, 0))
+        s.reserve(total_iterations)
+        kept = torch.empty((saved_iterations, Q, d + 1), dtype=torch.float64)
+        kept[0] = s.row0[:, :, 0].cpu()
+        seg = max(thinning, args.segment - args.segment % thinning)
+        buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
+        done, r = 0, 1
+        start = time.time()
+        while done < total_iterations:
+            k = min(seg, total_iterations - done)
+            nr = s.rows_between(s.t, s.t + k)
+            rows = s.advance(k, out=buf[:nr])
+            kept[r:r + nr] = rows[:, :, :, 0].cpu()
+            done += k; r += nr
+        torch.cuda.synchronize(device)
+        elapsed = time.time() - start
+        mean, var, _ = s.posterior_moments()
+        mean, var = mean.cpu().numpy(), var.cpu().numpy()
+        acc = s.acceptance().cpu().numpy()
+        for q, (drug, channel, experiments, _) in enumerate(members):
+            d_clean, c_clean, output_dir, chain_dir, figs_dir, chain_file = dr.hierarchical_output_dirs_and_chain_file(drug, channel, ne)
+            chain0 = kept[:, q].numpy()
+            chainio.save_hierarchical_chain(chain_file, chain0)                                     # :423-426,514-515
+            chainio.save_alpha_mu_samples(dr.alpha_mu_downsampling(d_clean, c_clean), chain0, args.num_APs, burn, d_clean, c_clean, rng)  # :519-525
+            summ = {"drug": d_clean, "channel": c_clean, "num_expts": ne, "chains": C, "iterations": total_iterations,
+                    "pooled_mean": mean[:, q].mean(axis=1).tolist(),
+                    "pooled_sd": np.sqrt(var[:, q].mean(axis=1) + mean[:, q].var(axis=1)).tolist(),
+                    "acceptance": float(acc[q].mean()), "first_iteration": theta0[q].tolist(),
+                    "mh_samples_per_second": Q * C * total_iterations / elapsed}
+            with open(chain_file[:-4] + "_summary.json", "w") as f:
+                json.dump(summ, f, indent=1)
+            summaries.append(summ)
+    return summaries

@@ -1,0 +1,113 @@
+"""Hierarchical sampler on the GPU (-m gpu): log_target_distribution against the reference golden vectors, chains
+bit-identical to the CPU twin, the --hierarchical command line and its files."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO, rows_of
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return "cuda:0"
+
+
+def test_prior_parameters_match_reference():
+    from pyhillfit_amd import hierarchical as H
+    g = np.load(os.path.join(GOLDEN, "g2_hier_target.npz"))
+    shapes, scales, locs = H.prior_params()
+    assert np.array_equal(shapes, g["shapes"]) and np.array_equal(scales, g["scales"]) and np.array_equal(locs, g["locs"])
+
+
+def test_hier_log_target_vs_reference_golden_and_twin(gpu, golden_meta, oracle_pair):
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H
+    g = np.load(os.path.join(GOLDEN, "g2_hier_target.npz"))
+    shapes, scales, locs = H.prior_params()
+    done = 0
+    for ip, m in enumerate(golden_meta["g2_pairs"]):
+        if m["Ne"] > H.MAX_EXPTS:
+            continue
+        p = oracle_pair(m["drug"], m["channel"], m["file"])
+        packed = H.PackedHierPoints([p.experiments])
+        th = g["theta_%d" % ip]
+        got = H.log_target_batch(packed, np.zeros(len(th), dtype=np.int32), th, device=gpu)
+        want = g["target_%d" % ip]
+        bad = ~np.isfinite(want)
+        assert np.array_equal(got[bad], want[bad], equal_nan=True)
+        np.testing.assert_allclose(got[~bad], want[~bad], rtol=1e-12, atol=0)
+        pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+        assert np.array_equal(got, np.array([pk.log_target(t) for t in th]), equal_nan=True)
+        done += 1
+    assert done >= 7
+
+
+@pytest.mark.parametrize("names", [[("Amiodarone", "hERG"), ("Lidocaine", "KvLQT1/mink")], [("Amitriptyline", "Kv4.3"), ("Cibenzoline", "Kv4.3")]])
+def test_hier_chains_bit_identical_to_cpu_twin(names, gpu, oracle_pair):
+    """Ne = 3 (dim 11) and Ne = 6 (dim 17): same seed => same chain and final state bit for bit, launches cut unevenly"""
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import gamma_table
+    shapes, scales, locs = H.prior_params()
+    pairs = [oracle_pair(d, c) for d, c in names]
+    packed = H.PackedHierPoints([p.experiments for p in pairs])
+    ne = packed.n_expts
+    d = 5 + 2 * ne
+    theta0 = np.array([np.concatenate([[1., 5., 6., .3], np.tile([6.0, 0.8], ne), [8.0]]),
+                       np.concatenate([[1.2, 4., 5., .4], np.tile([4.5, 1.1], ne), [5.0]])])
+    C, T, thin, adapt = 70, 700, 5, 150
+    s = H.HierarchicalSampler(packed, [0, 1], C, thinning=thin, seed=987654321, adapt_start=adapt, problem_ids=[11, 12],
+                              chain_id_base=5, device=gpu)
+    s.init(theta0, cov_scale=0.01)
+    row0 = s.row0.cpu().numpy()
+    parts = [s.advance(k).cpu().numpy() for k in (adapt - 3, 4, T - adapt - 1)]
+    chain = np.concatenate(parts)
+    assert chain.shape == (T // thin, 2, d + 1, C)
+    state = s.state.cpu().numpy().reshape(s.S, 2, C)
+    gam = gamma_table(T)
+    for q in range(2):
+        pk = co.PackedHierPair(pairs[q].experiments, shapes, scales, locs)
+        for c in (0, 33, C - 1):
+            st = pk.init_state(theta0[q], 0.01)
+            assert np.array_equal(row0[q, :, c], np.concatenate([theta0[q], [st[d]]]))
+            rows = pk.advance(st, 0, T, thin, adapt, gam, seed=987654321, chain_id=5 + c, problem_id=11 + q)
+            assert np.array_equal(chain[:, q, :, c], rows), (q, c)
+            assert np.array_equal(state[:, q, c], st), (q, c)
+    assert 0.01 < float(s.acceptance().mean()) < 0.95
+
+
+def test_hierarchical_cli_and_statistics(gpu, tmp_path):
+    """python PyHillFit.py --hierarchical: files where the reference puts them, (alpha, mu) consistent with the
+    reference's stored samples (chaste/samples, coarse: 500 draws of an unseeded run)"""
+    from pyhillfit_amd import PyHillFit
+    from pyhillfit_amd import doseresponse as dr
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    csv = str(tmp_path / "crumb_data.csv")
+    dr.table.to_csv(csv)
+    out = str(tmp_path / "output")
+    T = 60000
+    summ = PyHillFit.main(["--data-file", csv, "-m", "2", "--hierarchical", "-i", str(T), "-t", "5", "--drugs", "Amiodarone,Dofetilide",
+                           "--channels", "hERG", "--num-chains", "64", "--output-root", out, "--num-APs", "100"])
+    assert len(summ) == 2
+    with open(os.path.join(GOLDEN, "chaste_alpha_mu_stats.json")) as f:
+        ref = json.load(f)
+    for sm in summ:
+        ne = sm["num_expts"]
+        f = os.path.join(out, "crumb_data", "hierarchical", sm["drug"], "hERG", "%d_expts" % ne, "chain",
+                         "crumb_data_%s_hERG_hierarchical_chain.txt" % sm["drug"])
+        with open(f) as fh:
+            assert fh.readline().startswith("# Hill ~ log-logistic(alpha,beta)") and fh.readline().startswith("# alpha, beta, mu, s")
+        chain = np.loadtxt(f)
+        assert chain.shape == (T // 5 + 1, 5 + 2 * ne + 1) and np.isfinite(chain[1:]).all()      # full chain, burn-in included (:514-515)
+        samples = np.loadtxt(os.path.join(out, "crumb_data", "hierarchical", "alpha_mu_samples", "%s_hERG_hill_pic50_samples.txt" % sm["drug"]))
+        assert samples.shape == (100, 2)
+        w = ref["%s_hERG" % sm["drug"]]
+        assert abs(sm["pooled_mean"][0] - w["alpha_mean"]) < 0.12 * w["alpha_mean"] + 0.03
+        assert abs(sm["pooled_mean"][2] - w["mu_mean"]) < 0.015 * w["mu_mean"] + 0.03

@@ -124,3 +124,69 @@ def test_twin_agrees_with_numpy_oracle_on_all_pairs(g4_pairs, oracle_pair):
                 th = np.array([rng.uniform(3, 9), rng.uniform(0.3, 3), rng.uniform(1, 20)])
                 params = th if model == 2 else th[[0, 2]]
                 assert pk.log_target(params) == pytest.approx(orc.log_target(model, p, params, 1.0), rel=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ hierarchical
+def test_hierarchical_target_against_reference_golden(golden_meta, oracle_pair):
+    """G2: PyHillFit.log_target_distribution, Ne = 3..6 and the synthetic Ne = 5 / 50 sets, support edges included."""
+    g = np.load(os.path.join(GOLDEN, "g2_hier_target.npz"))
+    shapes, scales, locs = orc.hierarchical_prior_params()
+    for ip, m in enumerate(golden_meta["g2_pairs"]):
+        p = oracle_pair(m["drug"], m["channel"], m["file"])
+        pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+        got = np.array([pk.log_target(th) for th in g["theta_%d" % ip]])
+        _close(got, g["target_%d" % ip], 1e-12)
+        assert np.isinf(g["target_%d" % ip]).sum() >= 8
+
+
+def test_hierarchical_factor_update_is_the_reference_covariance_recursion(oracle_pair):
+    """the twin carries the Cholesky factor and applies cov <- (1-g) cov + g v v' (PyHillFit.py:498-499) as a rank-one
+    update: L L' must equal the covariance obtained by iterating the reference formula on the same accepted states"""
+    p = oracle_pair("Amiodarone", "hERG")
+    shapes, scales, locs = orc.hierarchical_prior_params()
+    pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+    d = pk.dim
+    theta0 = np.array([1., 5., 6., .3, 6., .8, 6.1, .7, 5.9, .9, 8.])
+    T, adapt = 3000, 400
+    gam = co.gamma_table(T)
+    st = pk.init_state(theta0, 0.01)
+    assert st[d] == pytest.approx(-28.722039448904166, rel=1e-13)              # SURVEY probe value
+    rows = pk.advance(st, 0, T, 1, adapt, gam, seed=7, chain_id=2, problem_id=5)
+    chain = np.vstack([np.concatenate([theta0, [st[d] * 0 + pk.log_target(theta0)]]), rows])
+    cov = np.diag(0.01 * np.abs(theta0)); mean = theta0.copy()
+    for t in range(1, T + 1):
+        th = chain[t, :d]
+        if t > adapt:
+            gs = gam[t - adapt]
+            v = (th - mean)[None, :]
+            cov = (1 - gs) * cov + gs * np.dot(v.T, v)
+            mean = (1 - gs) * mean + gs * th
+    L = np.zeros((d, d)); L[np.tril_indices(d)] = st[2 * d + 1:2 * d + 1 + d * (d + 1) // 2]
+    np.testing.assert_allclose(L @ L.T, cov, rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(st[d + 1:2 * d + 1], mean, rtol=1e-12)
+    assert 0.05 < st[-1] / T < 0.7 and (np.diff(chain[:, 0]) != 0).sum() > 200
+
+
+def test_hierarchical_posterior_is_consistent_with_reference_samples(oracle_pair):
+    """coarse statistical pin (the reference's stored chaste/samples: 500 draws of an unseeded run):
+    top-level (alpha, mu) of Amiodarone-hERG and Dofetilide-hERG"""
+    with open(os.path.join(GOLDEN, "chaste_alpha_mu_stats.json")) as f:
+        ref = json.load(f)
+    shapes, scales, locs = orc.hierarchical_prior_params()
+    for drug, start in (("Amiodarone", [1., 5., 6., .3]), ("Dofetilide", [1., 5., 8.5, .3])):
+        p = oracle_pair(drug, "hERG")
+        pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+        ne = pk.n_expts
+        theta0 = np.concatenate([start, np.tile([start[2], 0.8], ne), [8.0]])
+        T = 150000
+        gam = co.gamma_table(T)
+        samples = []
+        for c in range(4):
+            st = pk.init_state(theta0, 0.01)
+            rows = pk.advance(st, 0, T, 5, 100 * pk.dim, gam, seed=25, chain_id=c)
+            samples.append(rows[len(rows) // 4:])
+        s = np.concatenate(samples)
+        w = ref["%s_hERG" % drug]
+        assert abs(s[:, 0].mean() - w["alpha_mean"]) < 0.12 * w["alpha_mean"] + 3 * w["alpha_sd"] / np.sqrt(w["n"] / 10.)
+        assert abs(s[:, 2].mean() - w["mu_mean"]) < 0.01 * abs(w["mu_mean"]) + 3 * w["mu_sd"] / np.sqrt(w["n"] / 10.)
+        assert s[:, 0].std() == pytest.approx(w["alpha_sd"], rel=0.35) and s[:, 2].std() == pytest.approx(w["mu_sd"], rel=0.35)
