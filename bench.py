@@ -22,6 +22,25 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 64 fp64 FMA lanes x 2 x 2.4 GHz (vector, non-MFMA)
+FP64_VALU_MEASURED_TFLOPS = 58.3  # tools/microbench.hip: v_fma_f64 saturates at 2.25 ns per wave-instruction per SIMD
+
+
+def profile_facts(workload, chains, iters, thinning):
+    """Per-launch PMC facts measured with rocprofv3 on this kernel and committed under profiles/ (PMC counters cannot be
+    read from inside the process): fp64 flop per MH iteration (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64) and HBM traffic
+    (WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md), valid for the exact launch shape they
+    were taken on — otherwise traffic is null."""
+    path = os.path.join(REPO, "profiles", "pmc_facts.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        facts = json.load(f).get(workload)
+    if not facts:
+        return {}
+    out = {"flop_per_iteration": facts.get("flop_per_iteration"), "source": facts.get("source")}
+    if (facts.get("chains"), facts.get("iterations_per_launch"), facts.get("thinning")) == (chains, iters, thinning):
+        out["traffic_bytes_per_launch"] = facts.get("traffic_bytes_per_launch")
+    return out
 
 
 def cpu_baseline(iterations=15000):
@@ -56,9 +75,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--iters-per-step", type=int, default=2000)
-    ap.add_argument("--chains", type=int, default=None, help="chains per problem (default: 65536 for c2, 4096 for c3)")
+    ap.add_argument("--chains", type=int, default=None, help="chains per problem (default: 65536 c2, 4096 c3, 1024 c4/c5)")
     ap.add_argument("--thinning", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -79,23 +98,76 @@ def main():
     from pyhillfit_amd.sampler import SingleLevelSampler
     dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
     dr.define_model(2)
+    all_names = [(d, c) for d in dr.drugs for c in dr.channels]
+    kernel_name = "mh_advance_kernel<2>"
     if a.workload == "c2":
         names = [("Amiodarone", "hERG")]
         C = a.chains or 65536
         label = "Amiodarone-hERG, non-hierarchical model 2 (pIC50, Hill, sigma), %d chains per GPU (BASELINE configs[1])" % C
-    else:
-        names = [(d, c) for d in dr.drugs for c in dr.channels]
-        C = a.chains or 4096
+    elif a.workload == "c3":
+        names, C = all_names, a.chains or 4096
         label = "all %d Crumb drug x channel pairs, non-hierarchical model 2, %d chains each per GPU (BASELINE configs[2])" % (len(names), C)
-    packed = dr.pack_single_level(names)
-    Q = len(names)
-    # weak scaling: rank r owns chains [r*C, (r+1)*C) of every problem
-    s = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, C, thinning=a.thinning, seed=25,
-                           chain_id_base=rank * C, device=dev)
-    s.init([6.0, 0.8, 8.0], cov_identity=False, cov_scale=0.05)      # PyHillFit.py:748-751 start
+    elif a.workload == "c5":
+        names, C = all_names, a.chains or 1024
+        label = "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains per GPU, model 2 (BASELINE configs[4])" % (len(names), C)
+    else:
+        names, C = all_names, a.chains or 1024
+        label = "hierarchical model, all Crumb pairs, %d chains each per GPU (BASELINE configs[3])" % C
+    if a.workload == "c4":
+        # hierarchical: one sampler per Ne group, stepped back to back inside a "step"
+        from pyhillfit_amd import hierarchical as H
+        groups = {}
+        for d_, c_ in names:
+            ne, _, ex = dr.load_crumb_data(d_, c_)
+            groups.setdefault(len(ex), []).append(ex)
+        shapes, scales, locs = H.prior_params()
+        samplers = []
+        for ne, exs in sorted(groups.items()):
+            hs = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(len(exs))), C, thinning=a.thinning, seed=25,
+                                       chain_id_base=rank * C, device=dev)
+            hs.init(np.array([H.first_iteration(e, locs) for e in exs]), cov_scale=0.01)
+            samplers.append(hs)
+        kernel_name = "hier_advance_kernel<Ne=3..6>"
+
+        class Multi(object):
+            d = None
+            adapt_start = max(h.adapt_start for h in samplers)
+            bytes_per_iter = sum(h.Q * C * 8.0 * (h.d + 1) for h in samplers) / a.thinning
+            chains = sum(h.Q * C for h in samplers)
+
+            def reserve(self, n):
+                [h.reserve(n) for h in samplers]
+
+            def make_rows(self, I):
+                return [torch.empty((h.rows_between(0, I), h.Q, h.d + 1, C), dtype=torch.float64, device=dev) for h in samplers]
+
+            def advance(self, I, out):
+                for h, o in zip(samplers, out):
+                    h.advance(I, out=o)
+        s = Multi()
+        Q = len(names)
+    else:
+        packed = dr.pack_single_level(names)
+        if a.workload == "c5":
+            ladder = dr.temperature_ladder(31)                           # 32 rungs (BASELINE configs[4]); reference ladder has 41
+            pair_index = [p for p in range(len(names)) for _ in ladder]
+            temps = [float(t) for _ in names for t in ladder]
+        else:
+            pair_index, temps = list(range(len(names))), [1.0] * len(names)
+        Q = len(pair_index)
+        # weak scaling: rank r owns chains [r*C, (r+1)*C) of every problem
+        s = SingleLevelSampler(packed, 2, pair_index, temps, C, thinning=a.thinning, seed=25, chain_id_base=rank * C,
+                               reset_mean_at_adapt_start=(a.workload == "c5"), device=dev)
+        if a.workload == "c5":
+            s.init(np.ones(3), cov_identity=True, cov_scale=1.0)          # PyHillTemp.py:63,80 start
+        else:
+            s.init([6.0, 0.8, 8.0], cov_identity=False, cov_scale=0.05)   # PyHillFit.py:748-751 start
+        s.bytes_per_iter = float(Q) * C * 8 * (s.d + 1) / a.thinning      # 8(d+1)/thin B per iteration
+        s.chains = Q * C
+        s.make_rows = lambda I: torch.empty((s.rows_between(0, I), Q, s.d + 1, C), dtype=torch.float64, device=dev)
     I = a.iters_per_step
     s.reserve((a.warmup + a.steps) * I)
-    rows = torch.empty((s.rows_between(0, I), Q, s.d + 1, C), dtype=torch.float64, device=dev)
+    rows = s.make_rows(I)
 
     for _ in range(a.warmup):
         s.advance(I, out=rows)
@@ -119,27 +191,32 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kernel_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))   # HIP events on the launch stream
-    assert torch.isfinite(rows).all()
+    for r_ in (rows if isinstance(rows, list) else [rows]):
+        assert torch.isfinite(r_).all()
 
     if rank == 0:
-        samples_per_step = float(Q) * C * I * world
+        samples_per_step = float(s.chains) * I * world
         value = samples_per_step * a.steps / dt
-        alg_bytes = float(Q) * C * I * 8 * (s.d + 1) / a.thinning      # 8(d+1)/thin B per iteration
+        alg_bytes = s.bytes_per_iter * I
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        flop_per_iter = 2.0 * float(os.environ.get("PHF_FP64_OPS_PER_ITER", "1250"))  # see DESIGN.md (static count)
-        tflops = float(Q) * C * I * flop_per_iter / (kernel_ms * 1e-3) / 1e12
+        prof = profile_facts(a.workload, s.chains, I, a.thinning)
+        flop_per_iter = prof.get("flop_per_iteration")
+        tflops = None if flop_per_iter is None else float(s.chains) * I * flop_per_iter / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "MCMC samples/sec (whole node)", "value": value, "unit": "MH samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "real Crumb dose-response rows (data/crumb_dataset.json), synthetic chain batch",
-            "config": {"workload": label, "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": Q * C,
+            "config": {"workload": label, "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": s.chains,
                        "adaptation": "on (steps start after iteration %d > adapt_start %d)" % (a.warmup * I, s.adapt_start)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "mh_advance_kernel<2>", "kernel_ms": kernel_ms,
+                         "traffic": prof.get("traffic_bytes_per_launch"), "kernel": kernel_name, "kernel_ms": kernel_ms,
+                         "traffic_source": prof.get("source"),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "fp64-VALU-bound scalar-per-chain arithmetic; the HBM fraction is reported as BASELINE asks, the binding roof is fp64_valu"},
-            "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
-                          "flop_per_iteration": flop_per_iter},
+            "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": None if tflops is None else tflops / FP64_VALU_PEAK_TFLOPS,
+                          "measured_achievable_peak": FP64_VALU_MEASURED_TFLOPS, "flop_per_iteration": flop_per_iter,
+                          "flop_source": prof.get("source")},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
