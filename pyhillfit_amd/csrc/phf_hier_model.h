@@ -61,7 +61,7 @@ PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const doub
     for (int j = expt_start[i]; j < expt_start[i + 1]; ++j) {               /* :117-125 */
       const phf_ktab ke = PHF_KLOAD(phf_k_exp);
       const double a = hill * (lc[j] - ln_ic50);
-      const double w = 1.0 / (1.0 + phf_exp_fast_k(__builtin_fmin(a, 40.0), ke));
+      const double w = 1.0 / (1.0 + phf_exp_capped_k(__builtin_fmin(a, 40.0), ke, 1));
       const double pred = phf_fma(-100.0, w, 100.0);
       const double r = y[j] - pred;
       sse = phf_fma(r, r, sse);

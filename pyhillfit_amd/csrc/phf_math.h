@@ -75,35 +75,60 @@ PHF_HD double phf_sqrt(double x) { return __builtin_sqrt(x); } /* correctly roun
 PHF_HD double phf_pow2i(int k) { return phf_from_bits((uint64_t)(k + 1023) << 52); } /* -1022 <= k <= 1023 */
 
 /* ------------------------------------------------------------------------------------------------ exp
- * k = rint(x/ln2), r = x - k ln2 (two fma), exp(r) = 1 + r + r^2 q(r), q degree 9 evaluated as even + r*odd
- * (approximation error 1.6e-17 relative on |r| <= ln2/2), scaled by 2^k in two multiplications so that
- * subnormal results round once.  The argument is clamped to [-746, 710]: the scaling then overflows to +inf /
+ * k = nearest integer to x/ln2 (magic-number add), r = x - k ln2 (two fma), exp(r) = 1 + r + r^2 q(r), q degree 9
+ * (approximation error 1.6e-17 relative on |r| <= ln2/2), scaled by 2^k with ldexp (subnormal results round once).  The argument is clamped to [-746, 710]: the scaling then overflows to +inf /
  * underflows to 0 by itself, no branches.  phf_exp_fast(NaN) = 0 (min/max drop the NaN); phf_exp keeps NaN. */
 PHF_KTABLE phf_k_exp[10] = {   /* (exp(r)-1-r)/r^2, coefficient of r^i */
     0x1.0000000000001p-1, 0x1.5555555555556p-3, 0x1.5555555553d63p-5, 0x1.11111111109b3p-7, 0x1.6c16c1788bd90p-10,
     0x1.a01a01a7c41d5p-13, 0x1.a019b90d2ae7ap-16, 0x1.71de0dae63bb3p-19, 0x1.289185613a3d6p-22, 0x1.af38a9b0ec855p-26};
 
-PHF_HD double phf_exp_fast_k(double x, phf_ktab k) {
-  const double xc = __builtin_fmin(__builtin_fmax(x, -746.0), 710.0);
-  const double kd = __builtin_rint(xc * PHF_LOG2E);
+#define PHF_EXP_MAGIC 0x1.8p52   /* adding it rounds to an integer and leaves that integer in the low mantissa bits */
+
+/* core: x already within [-746, 710].  SPLIT = 1: even/odd halves (two dependency chains, for lone evaluations);
+ * SPLIT = 0: plain Horner (one instruction fewer; used where several evaluations already interleave).           */
+PHF_HD double phf_exp_core_k(double xc, phf_ktab k, int split) {
+  const double t = phf_fma(xc, PHF_LOG2E, PHF_EXP_MAGIC);
+  const double kd = t - PHF_EXP_MAGIC;
+  const int ki = (int)(int32_t)(uint32_t)phf_bits(t);
   double r = phf_fma(kd, -PHF_LN2_HI, xc);
   r = phf_fma(kd, -PHF_LN2_LO, r);
   const double r2 = r * r;
-  double qe = k[8];                               /* even coefficients in r^2 */
-  qe = PHF_FMA_K(qe, r2, k[6]);
-  qe = PHF_FMA_K(qe, r2, k[4]);
-  qe = PHF_FMA_K(qe, r2, k[2]);
-  qe = PHF_FMA_K(qe, r2, k[0]);
-  double qo = k[9];                               /* odd coefficients */
-  qo = PHF_FMA_K(qo, r2, k[7]);
-  qo = PHF_FMA_K(qo, r2, k[5]);
-  qo = PHF_FMA_K(qo, r2, k[3]);
-  qo = PHF_FMA_K(qo, r2, k[1]);
-  const double q = phf_fma(qo, r, qe);
+  double q;
+  if (split) {
+    double qe = k[8];                             /* even coefficients in r^2 */
+    qe = PHF_FMA_K(qe, r2, k[6]);
+    qe = PHF_FMA_K(qe, r2, k[4]);
+    qe = PHF_FMA_K(qe, r2, k[2]);
+    qe = PHF_FMA_K(qe, r2, k[0]);
+    double qo = k[9];                             /* odd coefficients */
+    qo = PHF_FMA_K(qo, r2, k[7]);
+    qo = PHF_FMA_K(qo, r2, k[5]);
+    qo = PHF_FMA_K(qo, r2, k[3]);
+    qo = PHF_FMA_K(qo, r2, k[1]);
+    q = phf_fma(qo, r, qe);
+  } else {
+    q = k[9];
+    q = PHF_FMA_K(q, r, k[8]);
+    q = PHF_FMA_K(q, r, k[7]);
+    q = PHF_FMA_K(q, r, k[6]);
+    q = PHF_FMA_K(q, r, k[5]);
+    q = PHF_FMA_K(q, r, k[4]);
+    q = PHF_FMA_K(q, r, k[3]);
+    q = PHF_FMA_K(q, r, k[2]);
+    q = PHF_FMA_K(q, r, k[1]);
+    q = PHF_FMA_K(q, r, k[0]);
+  }
   const double p = phf_fma(r2, q, r) + 1.0;
-  const int ki = (int)kd;
-  const int k1 = ki >> 1;
-  return (p * phf_pow2i(k1)) * phf_pow2i(ki - k1);
+  return __builtin_ldexp(p, ki);                  /* v_ldexp_f64: exact scaling, one rounding if the result is subnormal */
+}
+
+PHF_HD double phf_exp_fast_k(double x, phf_ktab k) {
+  return phf_exp_core_k(__builtin_fmin(__builtin_fmax(x, -746.0), 710.0), k, 1);
+}
+
+/* x known to be <= 709 (callers that have already capped their argument): lower clamp only */
+PHF_HD double phf_exp_capped_k(double x, phf_ktab k, int split) {
+  return phf_exp_core_k(__builtin_fmax(x, -746.0), k, split);
 }
 
 PHF_HD double phf_exp_fast(double x) { return phf_exp_fast_k(x, PHF_KLOAD(phf_k_exp)); }
@@ -329,6 +354,9 @@ PHF_HD double phf_uniform53(uint32_t w1, uint32_t w2) {
 /* Box-Muller radius argument: u1 = (w+0.5)/2^32 in (0,1), so -2 log u1 is finite; |z| <= 6.66.
  * The proposal stays symmetric, which is all Metropolis needs.                                  */
 PHF_HD double phf_unit_open32(uint32_t w) { return ((double)w + 0.5) * 0x1p-32; }
+
+/* the same from the top 24 bits of a field: u1 = (v+0.5)/2^24, |z| <= 5.89 */
+PHF_HD double phf_unit_open24(uint32_t v24) { return ((double)v24 + 0.5) * 0x1p-24; }
 
 /* Box-Muller pair from two 32-bit words (own division; the samplers use phf_mh_draws in phf_model.h) */
 PHF_HD void phf_box_muller(uint32_t w1, uint32_t w2, double* z0, double* z1) {

@@ -29,9 +29,9 @@
 #define PHF_HILL_ARG_CAP 40.0                   /* exp(40): 100/(1+x) already rounds pred to exactly 100 */
 
 /* Hill-curve denominator 1 + (dose/IC50)^hill = 1 + exp(hill (ln dose - ln IC50))   (doseresponse.py:84-88) */
-PHF_HD double phf_hill_den(int model, double ln_conc, double hill, double ln_ic50, phf_ktab k_exp) {
+PHF_HD double phf_hill_den(int model, double ln_conc, double hill, double ln_ic50, phf_ktab k_exp, int split) {
   const double a = (model == 1) ? (ln_conc - ln_ic50) : hill * (ln_conc - ln_ic50);
-  return 1.0 + phf_exp_fast_k(__builtin_fmin(a, PHF_HILL_ARG_CAP), k_exp);
+  return 1.0 + phf_exp_capped_k(__builtin_fmin(a, PHF_HILL_ARG_CAP), k_exp, split);
 }
 
 /* percent block from w = 1/(1 + x):  100 (1 - w) */
@@ -68,8 +68,8 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
   int j = 0;
   for (; j + 4 <= n_other; j += 4) {              /* uncensored points, four at a time (:247) */
     const phf_ktab ke = PHF_KLOAD(phf_k_exp);
-    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke);
-    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50, ke);
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
+    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke, 0), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50, ke, 0);
     const double p01 = d0 * d1, p23 = d2 * d3;
     const double inv = 1.0 / (p01 * p23);
     const double i01 = inv * p23, i23 = inv * p01;
@@ -78,13 +78,13 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
     sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse); sse = phf_fma(r2, r2, sse); sse = phf_fma(r3, r3, sse);
   }
   for (; j < n_other; ++j) {
-    const double r = y[j] - phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, PHF_KLOAD(phf_k_exp)));
+    const double r = y[j] - phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, PHF_KLOAD(phf_k_exp), 1));
     sse = phf_fma(r, r, sse);
   }
   const int n = n_other + n_cens;
   for (; j + 2 <= n; j += 2) {                    /* censored points, two at a time (:244-245) */
     const phf_ktab ke = PHF_KLOAD(phf_k_exp);
-    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke);
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double inv = 1.0 / (d0 * d1);
     const double z0 = phf_censored_z(phf_hill_percent(inv * d1), y[j], inv_s);
     const double z1 = phf_censored_z(phf_hill_percent(inv * d0), y[j + 1], inv_s);
@@ -93,7 +93,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
     cens += l0; cens += l1;
   }
   for (; j < n; ++j) {
-    const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, PHF_KLOAD(phf_k_exp)));
+    const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, PHF_KLOAD(phf_k_exp), 1));
     cens += phf_log_ndtr_nonpos(phf_censored_z(pred, y[j], inv_s));
   }
   double a = cens - pi_bit;
@@ -113,24 +113,26 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
   *out_prior = lp;
 }
 
-/* The random numbers of MH iteration t of one chain: d standard normals (Box-Muller on Philox words) and
- * log(u) of the accept uniform (PyHillFit.py:831,834-835).  One shared division for the three logarithms.
- * d == 2 uses one Philox block, d == 3 two.  z has room for 4 values (z[3] is the unused Box-Muller mate).  */
+/* The random numbers of MH iteration t of one chain — ONE Philox4x32-10 block (128 bits) per iteration:
+ *   d == 2: radius 32 bits | angle 32 bits | accept uniform 53 bits (numpy's random_sample construction);
+ *   d == 3: two Box-Muller pairs from 24-bit radius / 24-bit angle fields, accept uniform (w+0.5)/2^32.
+ * Returns log(u) (PyHillFit.py:834-835) and the d standard normals in z (PyHillFit.py:831; z[3] is the unused
+ * Box-Muller mate).  The three logarithms share one division.  Truncating the normals at 6.7 / 5.9 sigma keeps
+ * the proposal symmetric, which is all Metropolis needs.                                                        */
 PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
                            uint32_t seed_hi, double* z) {
-  const phf_u32x4 b0 = phf_philox4x32_10(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
-  double u, ub;
-  uint32_t ang_b = 0u;
+  const phf_u32x4 b = phf_philox4x32_10(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
+  double u, ua, ub;
+  uint32_t ang_a, ang_b = 0u;
   if (d == 2) {
-    u = phf_uniform53(b0.w[2], b0.w[3]);
+    ua = phf_unit_open32(b.w[0]); ang_a = b.w[1];
+    u = phf_uniform53(b.w[2], b.w[3]);
     ub = 0.5;
   } else {
-    const phf_u32x4 b1 = phf_philox4x32_10(chain_id, problem_id, t, 1u, seed_lo, seed_hi);
-    u = phf_uniform53(b1.w[0], b1.w[1]);
-    ub = phf_unit_open32(b0.w[2]);
-    ang_b = b0.w[3];
+    ua = phf_unit_open24(b.w[0] >> 8); ang_a = (b.w[0] << 24) | ((b.w[1] >> 8) & 0x00ffff00u);   /* 8 + 16 angle bits */
+    ub = phf_unit_open24(((b.w[1] & 0xffffu) << 8) | (b.w[2] >> 24)); ang_b = b.w[2] << 8;       /* 16 + 8 radius bits; 24 angle bits */
+    u = phf_unit_open32(b.w[3]);
   }
-  const double ua = phf_unit_open32(b0.w[0]);
   const phf_logred la = phf_log_reduce(ua), lb = phf_log_reduce(ub), lu = phf_log_reduce(u);
   const double da = 2.0 + la.f, db = 2.0 + lb.f, du = 2.0 + lu.f;
   const double pab = da * db;
@@ -139,7 +141,7 @@ PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32
   const phf_ktab k_log = PHF_KLOAD(phf_k_log), k_sc = PHF_KLOAD(phf_k_sincos);
   const double log_ua = phf_log_finish_k(la, la.f * (iab * db), k_log);
   double sn, cs;
-  phf_sincos_2pi_u32_k(b0.w[1], &sn, &cs, k_sc);
+  phf_sincos_2pi_u32_k(ang_a, &sn, &cs, k_sc);
   const double ra = phf_sqrt(-2.0 * log_ua);
   z[0] = ra * cs; z[1] = ra * sn;
   if (d == 2) {
@@ -151,7 +153,7 @@ PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32
     z[2] = rb * cs; z[3] = rb * sn;
   }
   const double log_u = phf_log_finish_k(lu, lu.f * (inv * pab), k_log);
-  return (u < PHF_DBL_MIN) ? -PHF_INF : log_u;       /* u == 0 (probability 2^-53): log 0 = -inf, accept */
+  return (u < PHF_DBL_MIN) ? -PHF_INF : log_u;       /* d == 2: u == 0 (probability 2^-53): log 0 = -inf, accept */
 }
 
 #endif /* PHF_MODEL_H */
