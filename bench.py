@@ -141,9 +141,18 @@ def main():
             def make_rows(self, I):
                 return [torch.empty((h.rows_between(0, I), h.Q, h.d + 1, C), dtype=torch.float64, device=dev) for h in samplers]
 
+            streams = [torch.cuda.Stream(device=dev) for _ in samplers]
+
             def advance(self, I, out):
-                for h, o in zip(samplers, out):
-                    h.advance(I, out=o)
+                # one HIP stream per Ne group: the small groups (Ne = 5, 6: tens of wavefronts) are latency-bound
+                # and hide under the big Ne = 3 launch instead of queueing behind it
+                cur = torch.cuda.current_stream(dev)
+                for h, o, st in zip(samplers, out, self.streams):
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        h.advance(I, out=o)
+                for st in self.streams:
+                    cur.wait_stream(st)
         s = Multi()
         Q = len(names)
     else:

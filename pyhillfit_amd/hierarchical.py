@@ -275,6 +275,8 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     saved_iterations = total_iterations // thinning + 1                # :469
     burn = saved_iterations // 4                                       # :472
     rng = np.random.RandomState(args.seed)
+    # one sampler and one HIP stream per Ne group: the groups are independent, their launches overlap on the GPU
+    runs = []
     for ne, members in sorted(groups.items()):
         packed = PackedHierPoints([m[2] for m in members])
         theta0 = np.array([first_iteration(m[2], locs) for m in members])
@@ -288,16 +290,30 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         kept[0] = s.row0[:, :, 0].cpu()
         seg = max(thinning, args.segment - args.segment % thinning)
         buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
-        done, r = 0, 1
-        start = time.time()
-        while done < total_iterations:
-            k = min(seg, total_iterations - done)
+        runs.append(dict(ne=ne, members=members, theta0=theta0, s=s, kept=kept, buf=buf, seg=seg, r=1,
+                         stream=torch.cuda.Stream(device=device)))
+    torch.cuda.synchronize(device)
+    start = time.time()
+    done = 0
+    while done < total_iterations:
+        k = min(runs[0]["seg"], total_iterations - done) if runs else total_iterations
+        pending = []
+        for run in runs:                       # launch every group first (asynchronous, one stream each) ...
+            s = run["s"]
             nr = s.rows_between(s.t, s.t + k)
-            rows = s.advance(k, out=buf[:nr])
-            kept[r:r + nr] = rows[:, :, :, 0].cpu()
-            done += k; r += nr
-        torch.cuda.synchronize(device)
-        elapsed = time.time() - start
+            with torch.cuda.stream(run["stream"]):
+                pending.append((run, nr, s.advance(k, out=run["buf"][:nr])))
+        for run, nr, rows in pending:          # ... then collect chain 0 of each pair
+            with torch.cuda.stream(run["stream"]):
+                run["kept"][run["r"]:run["r"] + nr] = rows[:, :, :, 0].cpu()
+            run["r"] += nr
+        done += k
+    torch.cuda.synchronize(device)
+    elapsed = time.time() - start
+    total_chains = sum(len(r_["members"]) for r_ in runs) * args.num_chains
+    for run in runs:
+        ne, members, theta0, s, kept = run["ne"], run["members"], run["theta0"], run["s"], run["kept"]
+        Q, C = len(members), args.num_chains
         mean, var, _ = s.posterior_moments()
         mean, var = mean.cpu().numpy(), var.cpu().numpy()
         acc = s.acceptance().cpu().numpy()
@@ -310,7 +326,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
                     "pooled_mean": mean[:, q].mean(axis=1).tolist(),
                     "pooled_sd": np.sqrt(var[:, q].mean(axis=1) + mean[:, q].var(axis=1)).tolist(),
                     "acceptance": float(acc[q].mean()), "first_iteration": theta0[q].tolist(),
-                    "mh_samples_per_second": Q * C * total_iterations / elapsed}
+                    "mh_samples_per_second": total_chains * total_iterations / elapsed}
             with open(chain_file[:-4] + "_summary.json", "w") as f:
                 json.dump(summ, f, indent=1)
             summaries.append(summ)
