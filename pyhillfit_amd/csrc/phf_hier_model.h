@@ -33,56 +33,155 @@ typedef struct phf_hier_prior {   /* Gamma hyper-priors of (alpha, beta, mu, s, 
 #define PHF_UNROLL
 #endif
 
-/* Phi(b) - Phi(a) for a <= 0 <= b:  1 - [Q(b) + Phi(a)], both tails through erfcx (no cancellation in the tails) */
-PHF_HD double phf_norm_mass_between(double a, double b, phf_ktab k_erfcx, phf_ktab k_exp) {
-  const double ya = -a * PHF_INV_SQRT2, yb = b * PHF_INV_SQRT2;
-  const double qa = phf_erfcx_den(ya), qb = phf_erfcx_den(yb);
-  const double iq = 1.0 / (qa * qb);
-  const double ea = phf_erfcx_finish_k(ya, iq * qb, k_erfcx), eb = phf_erfcx_finish_k(yb, iq * qa, k_erfcx);
-  const double ga = phf_exp_fast_k(-0.5 * a * a, k_exp), gb = phf_exp_fast_k(-0.5 * b * b, k_exp);
-  return 1.0 - 0.5 * phf_fma(ea, ga, eb * gb);
+/* capacity of the fixed-size work arrays: the device kernels are compiled for Ne <= 8; the host twin also serves the
+ * reference's synthetic Ne = 50 data set */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PHF_HIER_CAP 8
+#else
+#define PHF_HIER_CAP 64
+#endif
+#define PHF_MAX_BATCH (2 + 9 + 2 * PHF_HIER_CAP)
+
+/* v[i] <- 1/v[i] for i < n with ONE division (prefix products, then back-substitution): 3(n-1) multiplications.
+ * n must be a compile-time constant at the call site (fully unrolled, static register indices).                 */
+PHF_HD void phf_batch_recip(double* v, int n) {
+  double pre[PHF_MAX_BATCH];
+  pre[0] = v[0];
+  PHF_UNROLL
+  for (int i = 1; i < n; ++i) pre[i] = pre[i - 1] * v[i];
+  double inv = 1.0 / pre[n - 1];
+  PHF_UNROLL
+  for (int i = n - 1; i > 0; --i) {
+    const double vi = v[i];
+    v[i] = inv * pre[i - 1];
+    inv = inv * vi;
+  }
+  v[0] = inv;
 }
 
+/* log of a positive normal number from its reduction and the reciprocal of (2 + f); -inf below DBL_MIN */
+PHF_HD double phf_log_from_recip(double x, phf_logred lr, double inv_den, phf_ktab k_log) {
+  const double r = phf_log_finish_k(lr, lr.f * inv_den, k_log);
+  return (x < PHF_DBL_MIN) ? -PHF_INF : r;
+}
+
+/* Truncated-Gaussian terms of two points at once (PyHillFit.py:121-125): returns ln(Phi(b0)-Phi(a0)) + ln(Phi(b1)-Phi(a1))
+ * where a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma.  Phi(b)-Phi(a) = 1 - [Q(b) + Phi(a)], both tails through
+ * erfcx (no cancellation in the tails); four erfcx share one division, the two logs another.                    */
+PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s) {
+  const double a0 = -pred0 * inv_s, b0 = (100.0 - pred0) * inv_s, a1 = -pred1 * inv_s, b1 = (100.0 - pred1) * inv_s;
+  const double ya0 = -a0 * PHF_INV_SQRT2, yb0 = b0 * PHF_INV_SQRT2, ya1 = -a1 * PHF_INV_SQRT2, yb1 = b1 * PHF_INV_SQRT2;
+  double q[4] = {phf_erfcx_den(ya0), phf_erfcx_den(yb0), phf_erfcx_den(ya1), phf_erfcx_den(yb1)};
+  phf_batch_recip(q, 4);
+  const phf_ktab ke = PHF_KLOAD(phf_k_erfcx);
+  const double ea0 = phf_erfcx_finish_k(ya0, q[0], ke), eb0 = phf_erfcx_finish_k(yb0, q[1], ke);
+  const double ea1 = phf_erfcx_finish_k(ya1, q[2], ke), eb1 = phf_erfcx_finish_k(yb1, q[3], ke);
+  const phf_ktab kx = PHF_KLOAD(phf_k_exp);
+  const double ga0 = phf_exp_capped_k(-0.5 * a0 * a0, kx, 0), gb0 = phf_exp_capped_k(-0.5 * b0 * b0, kx, 0);
+  const double ga1 = phf_exp_capped_k(-0.5 * a1 * a1, kx, 0), gb1 = phf_exp_capped_k(-0.5 * b1 * b1, kx, 0);
+  const double m0 = 1.0 - 0.5 * phf_fma(ea0, ga0, eb0 * gb0), m1 = 1.0 - 0.5 * phf_fma(ea1, ga1, eb1 * gb1);
+  const phf_logred l0 = phf_log_reduce(m0), l1 = phf_log_reduce(m1);
+  double d[2] = {2.0 + l0.f, 2.0 + l1.f};
+  phf_batch_recip(d, 2);
+  const phf_ktab kl = PHF_KLOAD(phf_k_log);
+  return phf_log_from_recip(m0, l0, d[0], kl) + phf_log_from_recip(m1, l1, d[1], kl);
+}
+
+PHF_HD double phf_trunc_term(double pred, double inv_s) {
+  const double a = -pred * inv_s, b = (100.0 - pred) * inv_s;
+  const double ya = -a * PHF_INV_SQRT2, yb = b * PHF_INV_SQRT2;
+  double q[2] = {phf_erfcx_den(ya), phf_erfcx_den(yb)};
+  phf_batch_recip(q, 2);
+  const phf_ktab ke = PHF_KLOAD(phf_k_erfcx);
+  const double ea = phf_erfcx_finish_k(ya, q[0], ke), eb = phf_erfcx_finish_k(yb, q[1], ke);
+  const phf_ktab kx = PHF_KLOAD(phf_k_exp);
+  const double ga = phf_exp_capped_k(-0.5 * a * a, kx, 1), gb = phf_exp_capped_k(-0.5 * b * b, kx, 1);
+  return phf_log_fast(1.0 - 0.5 * phf_fma(ea, ga, eb * gb));
+}
+
+/* n_expts must be a compile-time constant at the call site (PHF_HIER_MAX_EXPTS at most) when theta lives in registers. */
 PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const double* lc, const double* y,
                                   const double* th, int ts, const phf_hier_prior* pr) {
   const int dim = 5 + 2 * n_expts;
   const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
   int bad = (alpha <= pr->loc[0]) | (beta <= pr->loc[1]) | (mu <= pr->loc[2]) | (s <= pr->loc[3]) | (sigma <= pr->loc[4]);
-  const double inv_s = 1.0 / sigma;
-  const double log_sigma = phf_log_fast(sigma);
-  const double ln_alpha = phf_log_fast(alpha), ln_beta = phf_log_fast(beta), ln_s = phf_log_fast(s);
-  const double inv_sc = 1.0 / s;
+  /* ---- one division for 1/sigma, 1/s and the 9 + Ne logarithms that depend on theta alone ---- */
+  const double hv[5] = {alpha, beta, mu, s, sigma};
+  double lx[9 + PHF_HIER_CAP];                                   /* arguments: sigma, alpha, beta, s, 5 x (hyper - loc), Hill_i */
+  lx[0] = sigma; lx[1] = alpha; lx[2] = beta; lx[3] = s;
+  PHF_UNROLL
+  for (int k = 0; k < 5; ++k) lx[4 + k] = hv[k] - pr->loc[k];
+  PHF_UNROLL
+  for (int i = 0; i < n_expts; ++i) lx[9 + i] = th[(5 + 2 * i) * ts];
+  const int nl = 9 + n_expts;
+  phf_logred lr[9 + PHF_HIER_CAP];
+  double rc[2 + 9 + PHF_HIER_CAP];
+  rc[0] = sigma; rc[1] = s;
+  PHF_UNROLL
+  for (int k = 0; k < nl; ++k) { lr[k] = phf_log_reduce(lx[k]); rc[2 + k] = 2.0 + lr[k].f; }
+  phf_batch_recip(rc, 2 + nl);
+  const double inv_s = rc[0], inv_sc = rc[1];
+  const phf_ktab k_log = PHF_KLOAD(phf_k_log);
+  double lg[9 + PHF_HIER_CAP];
+  PHF_UNROLL
+  for (int k = 0; k < nl; ++k) lg[k] = phf_log_from_recip(lx[k], lr[k], rc[2 + k], k_log);
+  const double log_sigma = lg[0], ln_alpha = lg[1], ln_beta = lg[2], ln_s = lg[3];
+
   double sse = 0.0, trunc = 0.0, hyper = 0.0;
+  double la[2 * PHF_HIER_CAP];                                   /* 1 + (Hill_i/alpha)^beta and 1 + exp(-z_i), logged together below */
   PHF_UNROLL
   for (int i = 0; i < n_expts; ++i) {
     const double pic50 = th[(4 + 2 * i) * ts], hill = th[(5 + 2 * i) * ts];
     bad |= (hill < 0.0) | (pic50 < PHF_HIER_PIC50_LOWER);
     const double ln_ic50 = PHF_LN10 * (6.0 - pic50);
-    for (int j = expt_start[i]; j < expt_start[i + 1]; ++j) {               /* :117-125 */
+    int j = expt_start[i];
+    const int jend = expt_start[i + 1];
+    for (; j + 2 <= jend; j += 2) {                                          /* :117-125, two points at a time */
       const phf_ktab ke = PHF_KLOAD(phf_k_exp);
-      const double a = hill * (lc[j] - ln_ic50);
-      const double w = 1.0 / (1.0 + phf_exp_capped_k(__builtin_fmin(a, 40.0), ke, 1));
+      const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
+      const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke, 0);
+      const double inv = 1.0 / (d0 * d1);
+      const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
+      const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
+      sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
+      trunc += phf_trunc_terms_x2(pred0, pred1, inv_s);
+    }
+    for (; j < jend; ++j) {
+      const double w = 1.0 / (1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), PHF_KLOAD(phf_k_exp), 1));
       const double pred = phf_fma(-100.0, w, 100.0);
       const double r = y[j] - pred;
       sse = phf_fma(r, r, sse);
-      const double mass = phf_norm_mass_between(-pred * inv_s, (100.0 - pred) * inv_s, PHF_KLOAD(phf_k_erfcx), ke);
-      trunc += phf_log_fast(mass);
+      trunc += phf_trunc_term(pred, inv_s);
     }
-    /* log-logistic density of Hill_i (:134-142) and logistic density of pIC50_i (:144-154) */
-    const double ln_h = phf_log_fast(hill);
-    const double pw = phf_exp_fast(beta * (ln_h - ln_alpha));               /* (Hill_i/alpha)^beta */
-    const double ll = (ln_beta - beta * ln_alpha) + (beta - 1.0) * ln_h - 2.0 * phf_log_fast(1.0 + pw);
+    /* log-logistic density of Hill_i (:134-142) and logistic density of pIC50_i (:144-154), logs deferred */
+    const double ln_h = lg[9 + i];
+    const phf_ktab kx = PHF_KLOAD(phf_k_exp);
+    la[2 * i] = 1.0 + phf_exp_fast_k(beta * (ln_h - ln_alpha), kx);          /* 1 + (Hill_i/alpha)^beta */
     const double z = (pic50 - mu) * inv_sc;
-    const double lg = (-z - ln_s) - 2.0 * phf_log_fast(1.0 + phf_exp_fast(-z));
-    hyper += ll; hyper += lg;
+    la[2 * i + 1] = 1.0 + phf_exp_fast_k(-z, kx);
+    hyper += (ln_beta - beta * ln_alpha) + (beta - 1.0) * ln_h;
+    hyper += (-z - ln_s);
+  }
+  {                                                                          /* the 2 Ne deferred logs: one division */
+    phf_logred l2[2 * PHF_HIER_CAP];
+    double d2[2 * PHF_HIER_CAP];
+    PHF_UNROLL
+    for (int k = 0; k < 2 * n_expts; ++k) { l2[k] = phf_log_reduce(la[k]); d2[k] = 2.0 + l2[k].f; }
+    phf_batch_recip(d2, 2 * n_expts);
+    const phf_ktab kl = PHF_KLOAD(phf_k_log);
+    PHF_UNROLL
+    for (int k = 0; k < 2 * n_expts; ++k) {
+      const double v = phf_log_finish_k(l2[k], l2[k].f * d2[k], kl);
+      hyper -= 2.0 * ((la[k] > 0x1p1000) ? PHF_INF : v);                     /* overflowed power: log(inf) = inf */
+    }
   }
   const int n_pts = expt_start[n_expts];
   double total = -(phf_fma((double)n_pts, log_sigma, sse * (0.5 * inv_s * inv_s)) + trunc);   /* :122-125 */
   total += hyper;
-  const double hv[5] = {alpha, beta, mu, s, sigma};
+  PHF_UNROLL
   for (int k = 0; k < 5; ++k) {                                              /* :187 */
     const double xl = hv[k] - pr->loc[k];
-    total += phf_fma(pr->shape_m1[k], phf_log_fast(xl), -xl * pr->inv_scale[k]);
+    total += phf_fma(pr->shape_m1[k], lg[4 + k], -xl * pr->inv_scale[k]);
   }
   return bad ? -PHF_INF : total;
 }
