@@ -78,7 +78,8 @@ int phf_version(void);
 const char* phf_last_error(void);
 
 /* doubles of per-chain state for the single-level sampler: theta[d], log-target, mean[d], cov[d(d+1)/2]
- * (packed lower triangle, row-major), loga, accepted-count  ->  2d + d(d+1)/2 + 3.                          */
+ * (packed lower triangle, row-major), loga, accepted-count, untempered log-likelihood of the current state
+ * ->  2d + d(d+1)/2 + 4.                                                                                     */
 int phf_single_level_state_size(int model);
 
 /* Start Q*C chains.  Replaces python/PyHillFit.py:748-751,789,796-798,814 (PyHillTemp.py:63-80):
@@ -95,9 +96,11 @@ int phf_single_level_init(const phf_points* pts, const phf_problems* prob, int m
  *   state     device [S][Q*C]   read, advanced, written back (so calls can be chained; also the checkpoint)
  *   rows      device [R][Q][d+1][C] or NULL, R = t_end/thinning - t_begin/thinning: the saved samples
  *             (theta, log-target) of iterations t with t % thinning == 0, in order (PyHillFit.py:847-848)
- *   moments   device [2(d+1)][Q*C] or NULL: running sums of x and x*x over the saved samples with
- *             t > moments_after (on-device replacement for reading the chain file back to get posterior
- *             means/variances); accumulated into, never zeroed.                                              */
+ *   moments   device [2(d+1)+1][Q*C] or NULL: running sums of x and x*x (x = theta, log-target) over the saved samples
+ *             with t > moments_after (on-device replacement for reading the chain file back to get posterior
+ *             means/variances); last row: sum of log_data_likelihood(theta, t = 1) over the same samples — the
+ *             expectation python/compute_bayes_factors.py:11-27 needs per temperature rung (thermodynamic
+ *             integration), at no extra cost.  Accumulated into, never zeroed.                               */
 int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg,
                              int64_t t_begin, int64_t t_end, double* state, double* rows,
                              double* moments, int64_t moments_after, void* stream);

@@ -46,6 +46,7 @@ def lib():
         L.phfo_log_likelihood.restype = C.c_double
         L.phfo_log_prior.restype = C.c_double
         L.phfo_state_size.restype = C.c_int
+        L.phfo_log_likelihood_t1.restype = C.c_double
         L.phfo_hier_log_target.restype = C.c_double
         _lib = L
     return _lib
@@ -81,6 +82,11 @@ class PackedPair:
     def log_likelihood(self, theta):
         th = np.ascontiguousarray(theta, dtype=np.float64)
         return lib().phfo_log_likelihood(C.byref(self.pb), _p(th))
+
+    def log_likelihood_t1(self, theta):
+        """log_data_likelihood(..., t=1) regardless of this problem's temperature (compute_bayes_factors.py:19-20)"""
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        return lib().phfo_log_likelihood_t1(C.byref(self.pb), _p(th))
 
     def log_prior(self, theta):
         th = np.ascontiguousarray(theta, dtype=np.float64)

@@ -44,17 +44,20 @@ typedef struct {
 } phfo_run;
 
 /* ---------------------------------------------------------------- model library (shared source: phf_model.h) */
-static void target_parts(const phfo_problem* pb, const double* th, double* lik, double* prior) {
+static void target_parts(const phfo_problem* pb, const double* th, double* lik, double* prior, double* ll1) {
   phf_sl_log_target(pb->model, pb->ln_conc, pb->response, pb->n_other, pb->n_zero + pb->n_hundred, pb->pi_bit,
-                    pb->temperature, th, lik, prior);
+                    pb->temperature, th, lik, prior, ll1);
 }
 
-double phfo_log_prior(const phfo_problem* pb, const double* th) { double l, p; target_parts(pb, th, &l, &p); return p; }
+double phfo_log_prior(const phfo_problem* pb, const double* th) { double l, p, a; target_parts(pb, th, &l, &p, &a); return p; }
 
-double phfo_log_likelihood(const phfo_problem* pb, const double* th) { double l, p; target_parts(pb, th, &l, &p); return l; }
+double phfo_log_likelihood(const phfo_problem* pb, const double* th) { double l, p, a; target_parts(pb, th, &l, &p, &a); return l; }
+
+/* log_data_likelihood at temperature 1 whatever the problem's own temperature (compute_bayes_factors.py:19-20) */
+double phfo_log_likelihood_t1(const phfo_problem* pb, const double* th) { double l, p, a; target_parts(pb, th, &l, &p, &a); return a; }
 
 double phfo_log_target(const phfo_problem* pb, const double* th) {  /* doseresponse.py:187-189 */
-  double l, p; target_parts(pb, th, &l, &p); return l + p;
+  double l, p, a; target_parts(pb, th, &l, &p, &a); return l + p;
 }
 
 /* ---------------------------------------------------------------- proposal factor */
@@ -77,8 +80,8 @@ static void chol_packed(int d, const double* c, double* l) {
   }
 }
 
-/* state layout: th[d], lt, mean[d], cov[d(d+1)/2], loga, n_accepted */
-int phfo_state_size(int d) { return 2 * d + d * (d + 1) / 2 + 3; }
+/* state layout: th[d], lt, mean[d], cov[d(d+1)/2], loga, n_accepted, untempered log-likelihood of the current state */
+int phfo_state_size(int d) { return 2 * d + d * (d + 1) / 2 + 4; }
 
 void phfo_init_state(const phfo_problem* pb, int cov_identity, double cov_scale, const double* theta0, double* st) {
   const int d = (pb->model == 1) ? 2 : 3;
@@ -90,6 +93,7 @@ void phfo_init_state(const phfo_problem* pb, int cov_identity, double cov_scale,
   *lt = phfo_log_target(pb, th);                                          /* PyHillFit.py:789 */
   cov[d * (d + 1) / 2] = 0.0;      /* loga   :796 */
   cov[d * (d + 1) / 2 + 1] = 0.0;  /* accepted count */
+  cov[d * (d + 1) / 2 + 2] = phfo_log_likelihood_t1(pb, th);
 }
 
 /* Advance one chain of any dimension.  out_rows receives (theta, log-target) for every t with
@@ -97,13 +101,13 @@ void phfo_init_state(const phfo_problem* pb, int cov_identity, double cov_scale,
  * (reference trace replay) instead of Philox.  scaled_cov_trace, if given, receives exp(loga)*cov (d*d, full)
  * as handed to the proposal at each iteration (what the reference passes to multivariate_normal). */
 #define PHFO_MAX_DIM 128
-typedef double (*target_fn)(const void* ctx, const double* th);
+typedef double (*target_fn)(const void* ctx, const double* th, double* ll1);
 
 static void advance_generic(int d, target_fn target, const void* ctx, const phfo_run* run, double* st,
                             double* out_rows, const double* star_replay, const double* u_replay, double* scaled_cov_trace) {
   const int ntri = d * (d + 1) / 2;
   double* th = st; double* lt = st + d; double* mean = st + d + 1; double* cov = mean + d;
-  double* loga = cov + ntri; double* nacc = loga + 1;
+  double* loga = cov + ntri; double* nacc = loga + 1; double* ll1 = loga + 2;
   static __thread double L[PHFO_MAX_DIM * (PHFO_MAX_DIM + 1) / 2];
   double z[PHFO_MAX_DIM + 4], star[PHFO_MAX_DIM], v[PHFO_MAX_DIM];
   chol_packed(d, cov, L);
@@ -129,9 +133,10 @@ static void advance_generic(int d, target_fn target, const void* ctx, const phfo
         star[i] = phf_fma(sc, yv, th[i]);
       }
     }
-    const double lt_star = target(ctx, star);                                /* :833 / :486 */
-    const int acc = log_u < lt_star - *lt;                                   /* :834-838 / :487-492 */
-    if (acc) { for (int i = 0; i < d; ++i) th[i] = star[i]; *lt = lt_star; }
+    double ll1_star;
+    const double lt_star = target(ctx, star, &ll1_star);                     /* :833 */
+    const int acc = log_u < lt_star - *lt;                                   /* :834-838 */
+    if (acc) { for (int i = 0; i < d; ++i) th[i] = star[i]; *lt = lt_star; *ll1 = ll1_star; }
     *nacc += (double)acc;
     if (run->reset_mean && t == run->adapt_start)                            /* PyHillTemp.py:114-115 */
       for (int i = 0; i < d; ++i) mean[i] = th[i];
@@ -154,7 +159,9 @@ static void advance_generic(int d, target_fn target, const void* ctx, const phfo
   }
 }
 
-static double sl_target(const void* ctx, const double* th) { return phfo_log_target((const phfo_problem*)ctx, th); }
+static double sl_target(const void* ctx, const double* th, double* ll1) {
+  double l, p; target_parts((const phfo_problem*)ctx, th, &l, &p, ll1); return l + p;
+}
 
 void phfo_advance(const phfo_problem* pb, const phfo_run* run, double* st, double* out_rows,
                   const double* star_replay, const double* u_replay, double* scaled_cov_trace) {

@@ -95,6 +95,7 @@ def run_tempered(pairs, temperatures, args, device):
     print("\nMCMC time: {} s\n".format(int(mcmc_time)))                                             # :162-163
     mean, var, _ = s.posterior_moments()
     mean = mean.cpu().numpy()
+    ll1 = s.mean_log_likelihood_t1().cpu().numpy()            # [Q][C]  E_rung[log L(theta; t=1)], fused into the sampler
     out = []
     for ip, (drug, channel, _, _) in enumerate(loaded):
         for ir, temperature in enumerate(temperatures):
@@ -103,10 +104,29 @@ def run_tempered(pairs, temperatures, args, device):
             print("chain_file:", chain_file)
             chainio.save_tempered_chain(chain_file, kept[burn:, q].numpy())                         # :125,169
             out.append({"drug": d_clean, "channel": c_clean, "temperature": float(temperature),
-                        "pooled_mean": mean[:, q].mean(axis=1).tolist(), "chain_file": chain_file})
+                        "pooled_mean": mean[:, q].mean(axis=1).tolist(), "chain_file": chain_file,
+                        "log_py_pooled": float(ll1[q].mean()), "log_py_chain0": float(ll1[q, 0])})
+        # thermodynamic integration (compute_bayes_factors.py:67-83): what that script recomputes from the chain files
+        rungs = out[ip * R:(ip + 1) * R]
+        ti = {"drug": d_clean, "channel": c_clean, "model": model, "temperatures": [float(t) for t in temperatures],
+              "log_py_pooled": [r_["log_py_pooled"] for r_ in rungs], "log_py_chain0": [r_["log_py_chain0"] for r_ in rungs],
+              "chains": C, "iterations": total_iterations, "thinning": thinning, "burn_in_fraction": args.burn_in_fraction}
+        ti["expectation_pooled"] = float(dr.trapezium_rule(ti["temperatures"], ti["log_py_pooled"]))
+        ti["expectation_chain0"] = float(dr.trapezium_rule(ti["temperatures"], ti["log_py_chain0"]))
+        with open(thermodynamic_integration_file(model, drug, channel), "w") as f:
+            json.dump(ti, f, indent=1)
     with open(dr.output_root + "/" + dr.dir_name + "/tempered_summary_model_%d.json" % model, "w") as f:
         json.dump({"mcmc_seconds": mcmc_time, "chains": C, "rungs": out}, f, indent=1)
     return out
+
+
+def thermodynamic_integration_file(model, drug, channel):
+    """<output>/<csv>/single-level/<drug>/<channel>/model_<m>/thermodynamic_integration.json"""
+    import os
+    d_clean, c_clean = drug.replace('/', '_'), channel.replace('/', '_')
+    base = '{}/{}/single-level/{}/{}/model_{}/'.format(dr.output_root, dr.dir_name, d_clean, c_clean, model)
+    os.makedirs(base, exist_ok=True)
+    return base + "thermodynamic_integration.json"
 
 
 def main(argv=None):

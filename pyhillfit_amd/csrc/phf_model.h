@@ -43,11 +43,13 @@ PHF_HD double phf_censored_z(double pred, double y, double inv_s) {
   return (sgn * (pred - y)) * inv_s;
 }
 
-/* log-likelihood (tempered) and log-prior of one parameter vector.
- * model 1: th = (pIC50, sigma), Hill = 1;  model 2: th = (pIC50, Hill, sigma).                               */
+/* log-likelihood (tempered), log-prior and UNtempered log-likelihood of one parameter vector.
+ * model 1: th = (pIC50, sigma), Hill = 1;  model 2: th = (pIC50, Hill, sigma).
+ * out_ll1 = log_data_likelihood(..., t = 1): what python/compute_bayes_factors.py:18-21 re-evaluates for every saved
+ * sample of every rung; it falls out of the same arithmetic here, so the samplers carry it along for free.      */
 PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int n_other, int n_cens,
                               double pi_bit, double temperature, const double* th, double* out_lik,
-                              double* out_prior) {
+                              double* out_prior, double* out_ll1) {
   const double pic50 = th[0];
   const double hill = (model == 1) ? 1.0 : th[1];
   const double sigma = (model == 1) ? th[1] : th[2];
@@ -100,9 +102,10 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
   a = phf_fma(-(double)n_other, log_sigma, a);                           /* :246 */
   a = phf_fma(-sse, 0.5 * inv_s * inv_s, a);                             /* :247 */
   double lik = temperature * a;                                          /* :248 */
-  if (sigma <= PHF_SIGMA_FLOOR) lik = -PHF_INF;                          /* :238-240 */
+  if (sigma <= PHF_SIGMA_FLOOR) { lik = -PHF_INF; a = -PHF_INF; }        /* :238-240 */
   if (temperature == 0.0) lik = 0.0;                                     /* :230-231 */
   *out_lik = lik;
+  *out_ll1 = a;
 
   double lp = -PHF_PIC50_RATE * pic50;                                   /* :151-156 */
   if (pic50 < PHF_PIC50_LOWER) lp = -PHF_INF;

@@ -105,10 +105,11 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
   for (int i = 0; i < NTRI; ++i) cov[i] = sp[(size_t)(2 * D + 1 + i) * nchains];
   double loga = sp[(size_t)(2 * D + 1 + NTRI) * nchains];
   double nacc = sp[(size_t)(2 * D + 2 + NTRI) * nchains];
+  double ll1 = sp[(size_t)(2 * D + 3 + NTRI) * nchains];   // untempered log-likelihood of the current state
   chol_packed<D>(cov, L);
   double sc = phf_exp_fast(0.5 * loga);
 
-  double m1[D + 1], m2[D + 1];
+  double m1[D + 1], m2[D + 1], mll = 0.0;
   const bool want_moments = a.moments != nullptr;
   if (want_moments) {
 #pragma unroll
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
       m1[i] = a.moments[(size_t)i * nchains + g];
       m2[i] = a.moments[(size_t)(D + 1 + i) * nchains + g];
     }
+    mll = a.moments[(size_t)(2 * D + 2) * nchains + g];
   }
 
   const int thin = a.cfg.thinning;
@@ -137,14 +139,15 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
       star[i] = phf_fma(sc, v, th[i]);
     }
     // ---- target and accept test (PyHillFit.py:833-838) ----
-    double lik_star, prior_star;
-    phf_sl_log_target(MODEL, lc, yv, n_other, n_cens, pi_bit, temperature, star, &lik_star, &prior_star);
+    double lik_star, prior_star, ll1_star;
+    phf_sl_log_target(MODEL, lc, yv, n_other, n_cens, pi_bit, temperature, star, &lik_star, &prior_star, &ll1_star);
     const double lt_star = lik_star + prior_star;
     const bool acc = log_u < lt_star - lt;
     if (acc) {
 #pragma unroll
       for (int i = 0; i < D; ++i) th[i] = star[i];
       lt = lt_star;
+      ll1 = ll1_star;
     }
     nacc += acc ? 1.0 : 0.0;
     // ---- adaptation (PyHillFit.py:840-846; PyHillTemp.py:114-122) ----
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
 #pragma unroll
         for (int i = 0; i < D; ++i) { m1[i] += th[i]; m2[i] = phf_fma(th[i], th[i], m2[i]); }
         m1[D] += lt; m2[D] = phf_fma(lt, lt, m2[D]);
+        mll += ll1;
       }
     }
   }
@@ -196,12 +200,14 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
   for (int i = 0; i < NTRI; ++i) sp[(size_t)(2 * D + 1 + i) * nchains] = cov[i];
   sp[(size_t)(2 * D + 1 + NTRI) * nchains] = loga;
   sp[(size_t)(2 * D + 2 + NTRI) * nchains] = nacc;
+  sp[(size_t)(2 * D + 3 + NTRI) * nchains] = ll1;
   if (want_moments) {
 #pragma unroll
     for (int i = 0; i <= D; ++i) {
       a.moments[(size_t)i * nchains + g] = m1[i];
       a.moments[(size_t)(D + 1 + i) * nchains + g] = m2[i];
     }
+    a.moments[(size_t)(2 * D + 2) * nchains + g] = mll;
   }
 }
 
@@ -234,9 +240,9 @@ __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
   double th[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
-  double lik0, prior0;
+  double lik0, prior0, ll10;
   phf_sl_log_target(MODEL, s_pts, s_pts + a.pts.stride, n_other, n_zero + n_hundred, a.pts.pi_bit[pair], a.prob.temperature[q],
-                    th, &lik0, &prior0);
+                    th, &lik0, &prior0, &ll10);
   const double lt = lik0 + prior0;
   double* sp = a.state + g;
 #pragma unroll
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
           (i != j) ? 0.0 : (a.cov_identity ? a.cov_scale : a.cov_scale * __builtin_fabs(th[i]));
   sp[(size_t)(2 * D + 1 + NTRI) * nchains] = 0.0;
   sp[(size_t)(2 * D + 2 + NTRI) * nchains] = 0.0;
+  sp[(size_t)(2 * D + 3 + NTRI) * nchains] = ll10;
   if (a.row0) {
     double* o = a.row0 + ((size_t)q * (D + 1)) * C + c;
 #pragma unroll
@@ -270,9 +277,9 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
   double th[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
-  double lik, prior;
+  double lik, prior, ll1;
   phf_sl_log_target(MODEL, pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride, cnt[0],
-                    cnt[1] + cnt[2], pts.pi_bit[pair], temperature[i], th, &lik, &prior);
+                    cnt[1] + cnt[2], pts.pi_bit[pair], temperature[i], th, &lik, &prior, &ll1);
   if (out_lik) out_lik[i] = lik;
   if (out_prior) out_prior[i] = prior;
 }
@@ -327,8 +334,8 @@ extern "C" {
 int phf_version(void) { return PHF_ABI_VERSION; }
 
 int phf_single_level_state_size(int model) {
-  if (model == 1) return 2 * 2 + 3 + 3;
-  if (model == 2) return 2 * 3 + 6 + 3;
+  if (model == 1) return 2 * 2 + 3 + 4;
+  if (model == 2) return 2 * 3 + 6 + 4;
   return phf_fail(PHF_ERR_INVALID_ARGUMENT, "model must be 1 or 2");
 }
 

@@ -123,7 +123,7 @@ class SingleLevelSampler(object):
 
     def enable_moments(self, after_iteration=0):
         """accumulate sum x, sum x^2 of the saved samples with t > after_iteration, per chain, on the device"""
-        self.moments = torch.zeros((2 * (self.d + 1), self.Q * self.C), dtype=torch.float64, device=self.device)
+        self.moments = torch.zeros((2 * (self.d + 1) + 1, self.Q * self.C), dtype=torch.float64, device=self.device)
         self.moments_after = int(after_iteration)
 
     def _config(self, t_end):
@@ -192,7 +192,7 @@ class SingleLevelSampler(object):
 
     def acceptance(self):
         """running acceptance rate (PyHillFit.py:839) per chain"""
-        return self.state[-1].view(self.Q, self.C) / max(self.t, 1)
+        return self.state[2 * self.d + 2 + self.d * (self.d + 1) // 2].view(self.Q, self.C) / max(self.t, 1)
 
     def posterior_moments(self):
         """(mean, variance, n) per chain from the on-device accumulators: [d+1][Q][C]"""
@@ -200,10 +200,18 @@ class SingleLevelSampler(object):
             raise _lib.PhfError("enable_moments() was not called")
         n = self.t // self.thinning - self.moments_after // self.thinning
         k = self.d + 1
-        s1 = self.moments[:k].view(k, self.Q, self.C); s2 = self.moments[k:].view(k, self.Q, self.C)
+        s1 = self.moments[:k].view(k, self.Q, self.C); s2 = self.moments[k:2 * k].view(k, self.Q, self.C)
         mean = s1 / n
         var = (s2 - s1 * mean) / max(n - 1, 1)
         return mean, var, n
+
+    def mean_log_likelihood_t1(self):
+        """[Q][C]: per chain, the mean over the saved post-burn samples of log_data_likelihood(theta, t=1) —
+        compute_log_py_approxn of python/compute_bayes_factors.py:11-27, accumulated inside the sampler kernel"""
+        if self.moments is None:
+            raise _lib.PhfError("enable_moments() was not called")
+        n = self.t // self.thinning - self.moments_after // self.thinning
+        return self.moments[2 * (self.d + 1)].view(self.Q, self.C) / n
 
     def state_dict(self):
         """checkpoint: everything needed to continue bit-identically"""

@@ -34,8 +34,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_and_state_sizes(lib):
     assert lib.phf_version() == 1
-    assert lib.phf_single_level_state_size(1) == 10      # 2+1+2+3+1+1
-    assert lib.phf_single_level_state_size(2) == 15      # 3+1+3+6+1+1
+    assert lib.phf_single_level_state_size(1) == 11      # 2+1+2+3+1+1+1
+    assert lib.phf_single_level_state_size(2) == 16      # 3+1+3+6+1+1+1
     assert lib.phf_single_level_state_size(3) < 0
     assert b"model" in lib.phf_last_error()
     assert lib.phf_hierarchical_state_size(3) == 2 * 11 + 66 + 3 and lib.phf_hierarchical_state_size(6) == 2 * 17 + 153 + 3

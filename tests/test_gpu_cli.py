@@ -81,3 +81,27 @@ def test_pyhilltemp_cli(csv_file, tmp_path):
     # the likelihood weight grows with temperature: hotter rungs sit closer to the data
     hot = np.loadtxt(f)[:, 0].mean()
     assert 5.0 < hot < 7.0
+
+
+def test_bayes_factor_fused_equals_chain_file_sweep(csv_file, tmp_path):
+    """thermodynamic integration (python/compute_bayes_factors.py): the expectation of log L(theta; t=1) per rung that the
+    sampler accumulates on the device equals what the reference's method gets by re-reading the rung's chain file"""
+    from pyhillfit_amd import PyHillTemp, compute_bayes_factors
+    out = str(tmp_path / "output")
+    common = ["--data-file", csv_file, "-d", "0", "-c", "0", "-i", "4000", "-t", "5", "--rungs", "5", "--num-chains", "64", "--output-root", out]
+    for m in ("1", "2"):
+        PyHillTemp.main(common + ["-m", m])
+    bf_dir = str(tmp_path / "BFs") + "/"
+    base = ["--data-file", csv_file, "-d", "0", "-c", "0", "--rungs", "5", "--output-root", out, "--bf-dir", bf_dir]
+    fused = compute_bayes_factors.main(base)
+    swept = compute_bayes_factors.main(base + ["--from-files"])
+    assert fused["sources"] == {1: "fused", 2: "fused"} and swept["sources"] == {1: "chain files", 2: "chain files"}
+    assert np.loadtxt(swept["file"]).shape == () and np.isfinite(fused["B12"]) and fused["B12"] > 0
+    # chain 0's fused sums are the same samples the chain files hold: identical expectation up to summation order
+    for m in (1, 2):
+        with open(os.path.join(out, "crumb_data", "single-level", "Amiodarone", "hERG", "model_%d" % m, "thermodynamic_integration.json")) as f:
+            ti = json.load(f)
+        assert swept["expectations"][m] == pytest.approx(ti["expectation_chain0"], rel=1e-11)
+        assert np.all(np.diff(ti["log_py_pooled"]) > 0)            # hotter rungs fit the data better
+    assert 1e-3 < fused["B12"] < 1e3      # evidence ratio of two nested, similarly good models (better fit vs Occam factor)
+    assert fused["expectations"][1] == pytest.approx(swept["expectations"][1], abs=0.5)   # pooled 64 chains vs chain 0
