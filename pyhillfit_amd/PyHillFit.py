@@ -169,7 +169,7 @@ def main(argv=None):
     rank, local_rank, world = phfdist.init()
     device = args.device or "cuda:%d" % local_rank
     dr.define_model(args.model)                                        # PyHillFit.py:56
-    dr.setup(args.data_file)                                           # :61
+    phfdist.setup_data_file(args.data_file)                            # :61 (rank 0 reads, broadcast to the other GPUs' ranks)
     dr.output_root = args.output_root
     pairs = select_pairs(args)
     if world > 1:                                                      # partition pairs over the GPUs of the node

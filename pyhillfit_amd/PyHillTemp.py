@@ -138,7 +138,7 @@ def main(argv=None):
     rank, local_rank, world = phfdist.init()
     device = args.device or "cuda:%d" % local_rank
     dr.define_model(args.model)                                          # PyHillTemp.py:45
-    dr.setup(args.data_file)                                             # :48
+    phfdist.setup_data_file(args.data_file)                              # :48
     dr.output_root = args.output_root
     if args.all_pairs:
         pairs = [(a, b) for a in dr.drugs for b in dr.channels]

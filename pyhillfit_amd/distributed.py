@@ -96,3 +96,21 @@ def gather_rows(local, dst=0):
     if rank != dst:
         return None
     return [o[:int(s)].cpu().numpy() for o, s in zip(outs, sizes)]
+
+
+def setup_data_file(path, src=0):
+    """dr.setup(path) on every rank with ONE reader: rank `src` parses the file and broadcasts the table
+    (a few tens of KB through RCCL/gloo) — the reference forks workers that inherit the parsed DataFrame
+    (python/PyHillFit.py:61,997-1003)."""
+    from . import doseresponse as dr
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        dr.setup(path)
+        return
+    box = [None]
+    if dist.get_rank() == src:
+        dr.setup(path)
+        t = dr.table
+        box[0] = (list(t.drug), list(t.channel), t.experiment.tolist(), t.dose.tolist(), t.response.tolist())
+    dist.broadcast_object_list(box, src=src)
+    if dist.get_rank() != src:
+        dr.setup_from_table(path, dr.Table(*box[0]))

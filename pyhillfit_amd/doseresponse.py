@@ -100,6 +100,16 @@ def setup(given_file):
     channels = Table._unique(table.channel)
 
 
+def setup_from_table(given_file, tbl):
+    """setup() from rows already in memory (multi-GPU runs: rank 0 reads the file, the others receive the table)"""
+    global file_name, dir_name, table, drugs, channels
+    file_name = given_file
+    dir_name = given_file.split('/')[-1][:-4] if not given_file.endswith(".json") else given_file.split('/')[-1][:-5]
+    table = tbl
+    drugs = Table._unique(table.drug)
+    channels = Table._unique(table.channel)
+
+
 def list_drug_channel_options(args_all):
     """doseresponse.py:40-57 — everything with -a, otherwise the interactive menu."""
     if args_all:

@@ -37,9 +37,12 @@ def _worker(rank, world, port, q):
     from pyhillfit_amd import doseresponse as dr
     r, _, w = pd.init(backend="gloo")
     assert (r, w) == (rank, world) and dist.is_initialized()
+    # only rank 0 may read the data file: hide it from the others
+    path = os.path.join(REPO, "data", "crumb_dataset.json") if rank == 0 else "/nonexistent/crumb_dataset.json"
+    pd.setup_data_file(path, src=0)
+    assert len(dr.drugs) == 30 and len(dr.channels) == 7 and dr.dir_name == "crumb_dataset" and len(dr.table.dose) == 2585
     packed = None
-    if rank == 0:                                   # only rank 0 reads the data file
-        dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    if rank == 0:
         packed = dr.pack_single_level([(d, c) for d in dr.drugs for c in dr.channels])
     got = pd.broadcast_packed_points(packed, "cpu", src=0)
     mine = pd.shard_problems(got.counts[:, 3], world)[rank]

@@ -96,3 +96,37 @@ def test_ladder_and_models(dr):
     dr.define_model(2); assert dr.num_params == 3
     with pytest.raises(ValueError):
         dr.define_model(3)
+
+
+def test_cli_skips_pairs_without_data_or_with_missing_responses(tmp_path, capsys):
+    """python/PyHillFit.py:653-669"""
+    from pyhillfit_amd import PyHillFit
+    from pyhillfit_amd import doseresponse as d
+    p = tmp_path / "tiny.csv"
+    p.write_text("Compound,Channel,Experiment,Dose,Response\nA,X,1,0.1,10\nA,X,1,1,50\nA,X,2,0.1,12\nA,X,2,1,\nB,X,1,0.1,5\nB,X,1,1,40\n")
+    d.setup(str(p))
+    loaded = PyHillFit.load_single_level_pairs([("A", "X"), ("B", "X"), ("B", "Y")])
+    assert [(x[0], x[1]) for x in loaded] == [("B", "X")]
+    out = capsys.readouterr().out
+    assert "Skipping ('A', 'X')" in out and "no entries for B + Y" in out
+    d.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+
+
+def test_best_fit_start_points(dr):
+    from pyhillfit_amd import bestfit
+    ne, _, ex = dr.load_crumb_data("Amiodarone", "hERG")
+    concs, y = dr.concatenate_experiments(ne, ex)
+    th2, ss2 = bestfit.best_fit(concs, y, 2)
+    th1, ss1 = bestfit.best_fit(concs, y, 1)
+    assert ss2 < ss1 and abs(th2[0] - 6.03) < 0.05 and abs(th2[1] - 0.58) < 0.05 and th2[2] == pytest.approx(np.sqrt(ss2 / 12))
+    ne, _, ex = dr.load_crumb_data("Lidocaine", "KvLQT1/mink")          # all responses 0: SS = 0
+    th, ss = bestfit.best_fit(*dr.concatenate_experiments(ne, ex), 2)
+    assert ss < 1e-9 and th[2] == 1.0                                   # not the reference's absorbing sigma0 = 0
+
+
+def test_bench_profile_facts_only_apply_to_the_measured_launch_shape():
+    import bench
+    f = bench.profile_facts("c2", 65536, 2000, 5)
+    assert f["flop_per_iteration"] > 1000 and f["traffic_bytes_per_launch"] > 8e8
+    assert "traffic_bytes_per_launch" not in bench.profile_facts("c2", 65536, 1000, 5)
+    assert bench.profile_facts("zz", 1, 1, 1) == {}
