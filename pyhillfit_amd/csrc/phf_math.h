@@ -47,7 +47,7 @@
  * instructions per term.  On the host both macros are plain C.                                             */
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const double __attribute__((address_space(4))) * phf_ktab;
-#define PHF_KTABLE static __device__ __constant__ const double
+#define PHF_KTABLE static const double   /* internal linkage: addressed pc-relatively (a __constant__ symbol goes through the GOT: one more dependent load per fetch) */
 #define PHF_KLOAD(name) __extension__({ phf_ktab phf_p_ = (phf_ktab)(name); asm volatile("" : "+s"(phf_p_)); phf_p_; })
 #define PHF_FMA_K(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "s"(c)); phf_r_; })
 #else
