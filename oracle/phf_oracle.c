@@ -46,7 +46,7 @@ typedef struct {
 /* ---------------------------------------------------------------- model library (shared source: phf_model.h) */
 static void target_parts(const phfo_problem* pb, const double* th, double* lik, double* prior, double* ll1) {
   phf_sl_log_target(pb->model, pb->ln_conc, pb->response, pb->n_other, pb->n_zero + pb->n_hundred, pb->pi_bit,
-                    pb->temperature, th, lik, prior, ll1);
+                    pb->temperature, th, phf_k_exp, phf_k_log, lik, prior, ll1);
 }
 
 double phfo_log_prior(const phfo_problem* pb, const double* th) { double l, p, a; target_parts(pb, th, &l, &p, &a); return p; }
@@ -126,7 +126,7 @@ static void advance_generic(int d, target_fn target, const void* ctx, const phfo
       log_u = phf_log(u_replay[t - run->t_begin - 1]);
     } else {
       /* PyHillFit.py:831/485 — theta* ~ N(theta, e^loga cov) drawn as theta + e^(loga/2) L z */
-      log_u = phf_mh_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, z);
+      log_u = phf_mh_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, phf_k_log, z);
       for (int i = 0; i < d; ++i) {
         double yv = L[i * (i + 1) / 2 + i] * z[i];
         for (int k = i - 1; k >= 0; --k) yv = phf_fma(L[i * (i + 1) / 2 + k], z[k], yv);
@@ -178,7 +178,7 @@ typedef struct {
 } phfo_hier_problem;
 
 double phfo_hier_log_target(const phfo_hier_problem* pb, const double* th) {
-  return phf_hier_log_target(pb->n_expts, pb->expt_start, pb->ln_conc, pb->response, th, 1, &pb->prior);
+  return phf_hier_log_target(pb->n_expts, pb->expt_start, pb->ln_conc, pb->response, th, 1, &pb->prior, phf_k_exp, phf_k_log);
 }
 
 /* state: th[d], lt, mean[d], L[d(d+1)/2] (factor of the adapted covariance), loga, n_accepted */
@@ -210,7 +210,7 @@ void phfo_hier_advance(const phfo_hier_problem* pb, const phfo_run* run, double*
       for (int i = 0; i < d; ++i) star[i] = star_replay[(t - run->t_begin - 1) * d + i];
       log_u = phf_log(u_replay[t - run->t_begin - 1]);
     } else {
-      log_u = phf_hier_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, z, 1);
+      log_u = phf_hier_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, phf_k_log, z, 1);
       for (int i = 0; i < d; ++i) {                                        /* :485 */
         double yv = L[i * (i + 1) / 2 + i] * z[i];
         for (int k = i - 1; k >= 0; --k) yv = phf_fma(L[i * (i + 1) / 2 + k], z[k], yv);
@@ -282,5 +282,5 @@ void phfo_philox(int64_t n, const uint32_t* ctr_key /* [n][6] */, uint32_t* out 
 /* the normals and log(u) of iteration t of a chain, exactly as the samplers draw them */
 void phfo_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
                 double* z /* [4] */, double* log_u) {
-  *log_u = phf_mh_draws(d, chain_id, problem_id, t, seed_lo, seed_hi, z);
+  *log_u = phf_mh_draws(d, chain_id, problem_id, t, seed_lo, seed_hi, phf_k_log, z);
 }

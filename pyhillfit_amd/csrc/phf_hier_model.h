@@ -68,40 +68,39 @@ PHF_HD double phf_log_from_recip(double x, phf_logred lr, double inv_den, phf_kt
 /* Truncated-Gaussian terms of two points at once (PyHillFit.py:121-125): returns ln(Phi(b0)-Phi(a0)) + ln(Phi(b1)-Phi(a1))
  * where a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma.  Phi(b)-Phi(a) = 1 - [Q(b) + Phi(a)], both tails through
  * erfcx (no cancellation in the tails); four erfcx share one division, the two logs another.                    */
-PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s) {
+PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl) {
   const double a0 = -pred0 * inv_s, b0 = (100.0 - pred0) * inv_s, a1 = -pred1 * inv_s, b1 = (100.0 - pred1) * inv_s;
   const double ya0 = -a0 * PHF_INV_SQRT2, yb0 = b0 * PHF_INV_SQRT2, ya1 = -a1 * PHF_INV_SQRT2, yb1 = b1 * PHF_INV_SQRT2;
   double q[4] = {phf_erfcx_den(ya0), phf_erfcx_den(yb0), phf_erfcx_den(ya1), phf_erfcx_den(yb1)};
   phf_batch_recip(q, 4);
-  const phf_ktab ke = PHF_KLOAD(phf_k_erfcx);
+  PHF_KFETCH(ke, phf_k_erfcx, 24);
   const double ea0 = phf_erfcx_finish_k(ya0, q[0], ke), eb0 = phf_erfcx_finish_k(yb0, q[1], ke);
   const double ea1 = phf_erfcx_finish_k(ya1, q[2], ke), eb1 = phf_erfcx_finish_k(yb1, q[3], ke);
-  const phf_ktab kx = PHF_KLOAD(phf_k_exp);
   const double ga0 = phf_exp_capped_k(-0.5 * a0 * a0, kx, 0), gb0 = phf_exp_capped_k(-0.5 * b0 * b0, kx, 0);
   const double ga1 = phf_exp_capped_k(-0.5 * a1 * a1, kx, 0), gb1 = phf_exp_capped_k(-0.5 * b1 * b1, kx, 0);
   const double m0 = 1.0 - 0.5 * phf_fma(ea0, ga0, eb0 * gb0), m1 = 1.0 - 0.5 * phf_fma(ea1, ga1, eb1 * gb1);
   const phf_logred l0 = phf_log_reduce(m0), l1 = phf_log_reduce(m1);
   double d[2] = {2.0 + l0.f, 2.0 + l1.f};
   phf_batch_recip(d, 2);
-  const phf_ktab kl = PHF_KLOAD(phf_k_log);
   return phf_log_from_recip(m0, l0, d[0], kl) + phf_log_from_recip(m1, l1, d[1], kl);
 }
 
-PHF_HD double phf_trunc_term(double pred, double inv_s) {
+PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl) {
   const double a = -pred * inv_s, b = (100.0 - pred) * inv_s;
   const double ya = -a * PHF_INV_SQRT2, yb = b * PHF_INV_SQRT2;
   double q[2] = {phf_erfcx_den(ya), phf_erfcx_den(yb)};
   phf_batch_recip(q, 2);
-  const phf_ktab ke = PHF_KLOAD(phf_k_erfcx);
+  PHF_KFETCH(ke, phf_k_erfcx, 24);
   const double ea = phf_erfcx_finish_k(ya, q[0], ke), eb = phf_erfcx_finish_k(yb, q[1], ke);
-  const phf_ktab kx = PHF_KLOAD(phf_k_exp);
   const double ga = phf_exp_capped_k(-0.5 * a * a, kx, 1), gb = phf_exp_capped_k(-0.5 * b * b, kx, 1);
-  return phf_log_fast(1.0 - 0.5 * phf_fma(ea, ga, eb * gb));
+  const double m = 1.0 - 0.5 * phf_fma(ea, ga, eb * gb);
+  const phf_logred lr = phf_log_reduce(m);
+  return phf_log_from_recip(m, lr, 1.0 / (2.0 + lr.f), kl);
 }
 
 /* n_expts must be a compile-time constant at the call site (PHF_HIER_MAX_EXPTS at most) when theta lives in registers. */
 PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const double* lc, const double* y,
-                                  const double* th, int ts, const phf_hier_prior* pr) {
+                                  const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
   const int dim = 5 + 2 * n_expts;
   const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
   int bad = (alpha <= pr->loc[0]) | (beta <= pr->loc[1]) | (mu <= pr->loc[2]) | (s <= pr->loc[3]) | (sigma <= pr->loc[4]);
@@ -121,7 +120,6 @@ PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const doub
   for (int k = 0; k < nl; ++k) { lr[k] = phf_log_reduce(lx[k]); rc[2 + k] = 2.0 + lr[k].f; }
   phf_batch_recip(rc, 2 + nl);
   const double inv_s = rc[0], inv_sc = rc[1];
-  const phf_ktab k_log = PHF_KLOAD(phf_k_log);
   double lg[9 + PHF_HIER_CAP];
   PHF_UNROLL
   for (int k = 0; k < nl; ++k) lg[k] = phf_log_from_recip(lx[k], lr[k], rc[2 + k], k_log);
@@ -137,25 +135,25 @@ PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const doub
     int j = expt_start[i];
     const int jend = expt_start[i + 1];
     for (; j + 2 <= jend; j += 2) {                                          /* :117-125, two points at a time */
-      const phf_ktab ke = PHF_KLOAD(phf_k_exp);
+      const phf_ktab ke = k_exp;
       const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
       const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke, 0);
       const double inv = 1.0 / (d0 * d1);
       const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
       const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
-      trunc += phf_trunc_terms_x2(pred0, pred1, inv_s);
+      trunc += phf_trunc_terms_x2(pred0, pred1, inv_s, k_exp, k_log);
     }
     for (; j < jend; ++j) {
-      const double w = 1.0 / (1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), PHF_KLOAD(phf_k_exp), 1));
+      const double w = 1.0 / (1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
       const double pred = phf_fma(-100.0, w, 100.0);
       const double r = y[j] - pred;
       sse = phf_fma(r, r, sse);
-      trunc += phf_trunc_term(pred, inv_s);
+      trunc += phf_trunc_term(pred, inv_s, k_exp, k_log);
     }
     /* log-logistic density of Hill_i (:134-142) and logistic density of pIC50_i (:144-154), logs deferred */
     const double ln_h = lg[9 + i];
-    const phf_ktab kx = PHF_KLOAD(phf_k_exp);
+    const phf_ktab kx = k_exp;
     la[2 * i] = 1.0 + phf_exp_fast_k(beta * (ln_h - ln_alpha), kx);          /* 1 + (Hill_i/alpha)^beta */
     const double z = (pic50 - mu) * inv_sc;
     la[2 * i + 1] = 1.0 + phf_exp_fast_k(-z, kx);
@@ -168,7 +166,7 @@ PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const doub
     PHF_UNROLL
     for (int k = 0; k < 2 * n_expts; ++k) { l2[k] = phf_log_reduce(la[k]); d2[k] = 2.0 + l2[k].f; }
     phf_batch_recip(d2, 2 * n_expts);
-    const phf_ktab kl = PHF_KLOAD(phf_k_log);
+    const phf_ktab kl = k_log;
     PHF_UNROLL
     for (int k = 0; k < 2 * n_expts; ++k) {
       const double v = phf_log_finish_k(l2[k], l2[k].f * d2[k], kl);
@@ -188,15 +186,26 @@ PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const doub
 
 /* Draws of hierarchical MH iteration t: dim standard normals into z[i*zs] (Box-Muller, two pairs per Philox block,
  * blocks 0..ceil(dim/4)-1) and log(u) of the accept uniform (block ceil(dim/4)).                                 */
+PHF_HD void phf_box_muller_k(uint32_t w1, uint32_t w2, double* z0, double* z1, phf_ktab k_log, phf_ktab k_sc) {
+  const double ua = phf_unit_open32(w1);
+  const phf_logred lr = phf_log_reduce(ua);
+  const double rad = phf_sqrt(-2.0 * phf_log_finish_k(lr, lr.f / (2.0 + lr.f), k_log));
+  double sn, cs;
+  phf_sincos_2pi_u32_k(w2, &sn, &cs, k_sc);
+  *z0 = rad * cs;
+  *z1 = rad * sn;
+}
+
 PHF_HD double phf_hier_draws(int dim, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
-                             uint32_t seed_hi, double* z, int zs) {
+                             uint32_t seed_hi, phf_ktab k_log, double* z, int zs) {
+  PHF_KFETCH(k_sc, phf_k_sincos, 10);
   const int nb = (dim + 3) / 4;
   PHF_UNROLL
   for (int b = 0; b < nb; ++b) {
     const phf_u32x4 w = phf_philox4x32_10(chain_id, problem_id, t, (uint32_t)b, seed_lo, seed_hi);
     double z0, z1, z2, z3;
-    phf_box_muller(w.w[0], w.w[1], &z0, &z1);
-    phf_box_muller(w.w[2], w.w[3], &z2, &z3);
+    phf_box_muller_k(w.w[0], w.w[1], &z0, &z1, k_log, k_sc);
+    phf_box_muller_k(w.w[2], w.w[3], &z2, &z3, k_log, k_sc);
     const int i = 4 * b;
     z[i * zs] = z0;
     if (i + 1 < dim) z[(i + 1) * zs] = z1;
@@ -204,7 +213,9 @@ PHF_HD double phf_hier_draws(int dim, uint32_t chain_id, uint32_t problem_id, ui
     if (i + 3 < dim) z[(i + 3) * zs] = z3;
   }
   const phf_u32x4 wu = phf_philox4x32_10(chain_id, problem_id, t, (uint32_t)nb, seed_lo, seed_hi);
-  return phf_log_fast(phf_uniform53(wu.w[0], wu.w[1]));
+  const double u = phf_uniform53(wu.w[0], wu.w[1]);
+  const phf_logred lu = phf_log_reduce(u);
+  return phf_log_from_recip(u, lu, 1.0 / (2.0 + lu.f), k_log);
 }
 
 #endif /* PHF_HIER_MODEL_H */

@@ -85,7 +85,9 @@ __global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) 
   for (int e = 0; e < TRI; ++e) sL[e * kBlock] = sp[(size_t)(2 * D + 1 + e) * nchains];
   double loga = sp[(size_t)(2 * D + 1 + TRI) * nchains];
   double nacc = sp[(size_t)(2 * D + 2 + TRI) * nchains];
-  double sc = phf_exp_fast(0.5 * loga);
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  double sc = phf_exp_fast_k(0.5 * loga, k_exp);
 
   const bool want_moments = a.moments != nullptr;
   const int thin = a.cfg.thinning;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) 
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
     // ---- proposal theta* = theta + e^(loga/2) L z   (PyHillFit.py:485) ----
     double z[D], star[D];
-    const double log_u = phf_hier_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, z, 1);
+    const double log_u = phf_hier_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, z, 1);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       double v = sL[(i * (i + 1) / 2 + i) * kBlock] * z[i];
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) 
       star[i] = phf_fma(sc, v, th[i]);
     }
     // ---- target, accept (:486-492) ----
-    const double lt_star = phf_hier_log_target(NE, s_es, s_lc, s_y, star, 1, &a.prior);
+    const double lt_star = phf_hier_log_target(NE, s_es, s_lc, s_y, star, 1, &a.prior, k_exp, k_log);
     const bool acc = log_u < lt_star - lt;
     if (acc) {
 #pragma unroll
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) 
           w[i] = phf_fma(cs, w[i], -(sn * tik));
         }
       }
-      sc = phf_exp_fast(0.5 * loga);
+      sc = phf_exp_fast_k(0.5 * loga, k_exp);
     }
     // ---- thinning + sample store (:502-503) ----
     if (--until_save == 0) {
@@ -192,7 +194,9 @@ __global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
   double th[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
-  const double lt = phf_hier_log_target(NE, s_es, s_lc, s_y, th, 1, &a.prior);
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  const double lt = phf_hier_log_target(NE, s_es, s_lc, s_y, th, 1, &a.prior, k_exp, k_log);
   double* sp = a.state + g;
 #pragma unroll
   for (int i = 0; i < D; ++i) { sp[(size_t)i * nchains] = th[i]; sp[(size_t)(D + 1 + i) * nchains] = th[i]; }
@@ -222,8 +226,10 @@ __global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_
   double th[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
   out[i] = phf_hier_log_target(NE, pts.expt_start + (size_t)pair * (NE + 1), pts.ln_conc + (size_t)pair * pts.stride,
-                               pts.response + (size_t)pair * pts.stride, th, 1, &prior);
+                               pts.response + (size_t)pair * pts.stride, th, 1, &prior, k_exp, k_log);
 }
 
 int check(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior) {

@@ -9,7 +9,7 @@
  * Shaped for CDNA4's fp64 VALU (measured with tools/microbench.hip on MI355X: v_fma_f64 2.25 ns per
  * wave-instruction per SIMD, v_mov_b64 2.1 ns, IEEE division ~26 ns, v_rcp/v_sqrt_f64 7 ns):
  *   - polynomial steps are literal 3-operand v_fma_f64 with the coefficient in an SGPR pair fetched through the
- *     scalar cache (PHF_KLOAD / PHF_FMA_K below);
+ *     scalar cache or held in VGPRs (PHF_KFETCH / PHF_KFETCH_V below);
  *   - polynomials are split into even/odd halves (two independent dependency chains) so a lone wave on a
  *     SIMD is not latency-bound;
  *   - the *_fast / *_core entry points used inside the kernels are branch-free: range problems are handled by
@@ -38,24 +38,52 @@
 #define PHF_HD static inline __attribute__((always_inline))
 #endif
 
-/* Polynomial coefficients live in constant memory and reach the VALU through the scalar cache:
- *   PHF_KLOAD(table)   one s_load_dwordx{4,8,16} burst into SGPRs, issued where the polynomial starts (the empty
- *                      asm makes the table address opaque, so the loads are neither hoisted out of the MH loop
- *                      nor kept alive across it: ~100 coefficients would otherwise pin 200+ registers);
- *   PHF_FMA_K(p,t,c)   p*t + c as a literal 3-operand v_fma_f64 whose addend is that SGPR pair.
- * hipcc on its own emits "v_mov_b64 acc, coef ; v_fmac_f64 acc, p, t" for a constant addend — two fp64-rate
- * instructions per term.  On the host both macros are plain C.                                             */
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef const double __attribute__((address_space(4))) * phf_ktab;
-#define PHF_KTABLE static const double   /* internal linkage: addressed pc-relatively (a __constant__ symbol goes through the GOT: one more dependent load per fetch) */
-#define PHF_KLOAD(name) __extension__({ phf_ktab phf_p_ = (phf_ktab)(name); asm volatile("" : "+s"(phf_p_)); phf_p_; })
-#define PHF_FMA_K(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "s"(c)); phf_r_; })
+/* Polynomial coefficients and how they reach the VALU (hipcc on its own emits "v_mov_b64 acc, coef ; v_fmac_f64 acc, p, t"
+ * for a constant addend — two fp64-rate instructions per term; and would hoist all ~60 coefficients out of the MH
+ * loop, pinning 120+ registers):
+ *   PHF_FMA_K / PHF_FMA_KV   p*t + c as a literal 3-operand v_fma_f64 with the coefficient in an SGPR / a VGPR pair;
+ *   PHF_KFETCH(k, table, n)  the n coefficients loaded through the scalar cache into SGPRs where the macro stands;
+ *   PHF_KFETCH_V(k, table, n) the n coefficients placed in VGPRs (done once per kernel for the exp and log tables, which
+ *                            every polynomial of an iteration uses: measured, a lone wave per SIMD cannot hide the
+ *                            ~100-cycle scalar-load latency of refetching them).
+ * On the host all of these are plain C.                                                                          */
+#if defined(__HIPCC__)
+#define PHF_UNROLL _Pragma("unroll")
 #else
-typedef const double* phf_ktab;
-#define PHF_KTABLE static const double
-#define PHF_KLOAD(name) (name)
-#define PHF_FMA_K(p, t, c) __builtin_fma((p), (t), (c))
+#define PHF_UNROLL
 #endif
+typedef const double* phf_ktab;   /* coefficients of one polynomial, already in registers (device) / the table itself (host) */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const double __attribute__((address_space(4))) * phf_ktab4;
+/* SGPR-resident: loaded through the scalar cache where the macro stands (erfcx, sin/cos: big, used in one phase) */
+#define PHF_KFETCH(name, table, n)                                                          \
+  double name##_buf[n];                                                                     \
+  {                                                                                         \
+    phf_ktab4 phf_p_ = (phf_ktab4)(table);                                                  \
+    asm volatile("" : "+s"(phf_p_));                                                        \
+    PHF_UNROLL                                                                              \
+    for (int phf_i_ = 0; phf_i_ < (n); ++phf_i_) name##_buf[phf_i_] = phf_p_[phf_i_];       \
+  }                                                                                         \
+  const phf_ktab name = name##_buf
+/* VGPR-resident: materialised once (kernels do it before the MH loop) and kept in vector registers (exp, log: 17
+ * coefficients used by every polynomial of the iteration — no scalar-load latency, no SGPR pressure) */
+#define PHF_KFETCH_V(name, table, n)                                                        \
+  double name##_buf[n];                                                                     \
+  PHF_UNROLL                                                                                \
+  for (int phf_i_ = 0; phf_i_ < (n); ++phf_i_) {                                            \
+    name##_buf[phf_i_] = (table)[phf_i_];                                                   \
+    asm volatile("" : "+v"(name##_buf[phf_i_]));                                            \
+  }                                                                                         \
+  const phf_ktab name = name##_buf
+#define PHF_FMA_K(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "s"(c)); phf_r_; })
+#define PHF_FMA_KV(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "v"(c)); phf_r_; })
+#else
+#define PHF_KFETCH(name, table, n) const phf_ktab name = (table)
+#define PHF_KFETCH_V(name, table, n) const phf_ktab name = (table)
+#define PHF_FMA_K(p, t, c) __builtin_fma((p), (t), (c))
+#define PHF_FMA_KV(p, t, c) __builtin_fma((p), (t), (c))
+#endif
+#define PHF_KTABLE static const double   /* internal linkage: addressed pc-relatively (a __constant__ symbol goes through the GOT: one more dependent load per fetch) */
 
 #define PHF_INF (__builtin_inf())
 #define PHF_NAN (__builtin_nan(""))
@@ -96,27 +124,27 @@ PHF_HD double phf_exp_core_k(double xc, phf_ktab k, int split) {
   double q;
   if (split) {
     double qe = k[8];                             /* even coefficients in r^2 */
-    qe = PHF_FMA_K(qe, r2, k[6]);
-    qe = PHF_FMA_K(qe, r2, k[4]);
-    qe = PHF_FMA_K(qe, r2, k[2]);
-    qe = PHF_FMA_K(qe, r2, k[0]);
+    qe = PHF_FMA_KV(qe, r2, k[6]);
+    qe = PHF_FMA_KV(qe, r2, k[4]);
+    qe = PHF_FMA_KV(qe, r2, k[2]);
+    qe = PHF_FMA_KV(qe, r2, k[0]);
     double qo = k[9];                             /* odd coefficients */
-    qo = PHF_FMA_K(qo, r2, k[7]);
-    qo = PHF_FMA_K(qo, r2, k[5]);
-    qo = PHF_FMA_K(qo, r2, k[3]);
-    qo = PHF_FMA_K(qo, r2, k[1]);
+    qo = PHF_FMA_KV(qo, r2, k[7]);
+    qo = PHF_FMA_KV(qo, r2, k[5]);
+    qo = PHF_FMA_KV(qo, r2, k[3]);
+    qo = PHF_FMA_KV(qo, r2, k[1]);
     q = phf_fma(qo, r, qe);
   } else {
     q = k[9];
-    q = PHF_FMA_K(q, r, k[8]);
-    q = PHF_FMA_K(q, r, k[7]);
-    q = PHF_FMA_K(q, r, k[6]);
-    q = PHF_FMA_K(q, r, k[5]);
-    q = PHF_FMA_K(q, r, k[4]);
-    q = PHF_FMA_K(q, r, k[3]);
-    q = PHF_FMA_K(q, r, k[2]);
-    q = PHF_FMA_K(q, r, k[1]);
-    q = PHF_FMA_K(q, r, k[0]);
+    q = PHF_FMA_KV(q, r, k[8]);
+    q = PHF_FMA_KV(q, r, k[7]);
+    q = PHF_FMA_KV(q, r, k[6]);
+    q = PHF_FMA_KV(q, r, k[5]);
+    q = PHF_FMA_KV(q, r, k[4]);
+    q = PHF_FMA_KV(q, r, k[3]);
+    q = PHF_FMA_KV(q, r, k[2]);
+    q = PHF_FMA_KV(q, r, k[1]);
+    q = PHF_FMA_KV(q, r, k[0]);
   }
   const double p = phf_fma(r2, q, r) + 1.0;
   return __builtin_ldexp(p, ki);                  /* v_ldexp_f64: exact scaling, one rounding if the result is subnormal */
@@ -131,7 +159,7 @@ PHF_HD double phf_exp_capped_k(double x, phf_ktab k, int split) {
   return phf_exp_core_k(__builtin_fmax(x, -746.0), k, split);
 }
 
-PHF_HD double phf_exp_fast(double x) { return phf_exp_fast_k(x, PHF_KLOAD(phf_k_exp)); }
+PHF_HD double phf_exp_fast(double x) { PHF_KFETCH_V(k, phf_k_exp, 10); return phf_exp_fast_k(x, k); }
 
 PHF_HD double phf_exp(double x) {
   const double r = phf_exp_fast(x);
@@ -164,19 +192,19 @@ PHF_HD double phf_log_finish_k(phf_logred lr, double s, phf_ktab k) {
   const double z = s * s;
   const double z2 = z * z;
   double ge = k[6];
-  ge = PHF_FMA_K(ge, z2, k[4]);
-  ge = PHF_FMA_K(ge, z2, k[2]);
-  ge = PHF_FMA_K(ge, z2, k[0]);
+  ge = PHF_FMA_KV(ge, z2, k[4]);
+  ge = PHF_FMA_KV(ge, z2, k[2]);
+  ge = PHF_FMA_KV(ge, z2, k[0]);
   double go = k[5];
-  go = PHF_FMA_K(go, z2, k[3]);
-  go = PHF_FMA_K(go, z2, k[1]);
+  go = PHF_FMA_KV(go, z2, k[3]);
+  go = PHF_FMA_KV(go, z2, k[1]);
   const double g = phf_fma(go, z, ge);
   const double hfsq = 0.5 * f * f;
   const double t = phf_fma(dk, PHF_LN2_LO, s * phf_fma(z, g, hfsq));
   return phf_fma(dk, PHF_LN2_HI, f - (hfsq - t));
 }
 
-PHF_HD double phf_log_finish(phf_logred lr, double s) { return phf_log_finish_k(lr, s, PHF_KLOAD(phf_k_log)); }
+PHF_HD double phf_log_finish(phf_logred lr, double s) { PHF_KFETCH_V(k, phf_k_log, 7); return phf_log_finish_k(lr, s, k); }
 
 /* positive normal finite x only (no checks) */
 PHF_HD double phf_log_core(double x) {
@@ -250,7 +278,7 @@ PHF_HD double phf_erfcx_finish_k(double y, double r, phf_ktab k) {
   return (p * a) * r;
 }
 
-PHF_HD double phf_erfcx_finish(double y, double r) { return phf_erfcx_finish_k(y, r, PHF_KLOAD(phf_k_erfcx)); }
+PHF_HD double phf_erfcx_finish(double y, double r) { PHF_KFETCH(k, phf_k_erfcx, 24); return phf_erfcx_finish_k(y, r, k); }
 
 /* 0 <= y < ~1e150 (no checks) */
 PHF_HD double phf_erfcx_core(double y) { return phf_erfcx_finish(y, 1.0 / phf_erfcx_den(y)); }
@@ -278,18 +306,29 @@ PHF_HD double phf_log_ndtr_nonpos(double x) {
 }
 
 /* two at once, sharing one division for the two erfcx and one for the two logs */
-PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1) {
+PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r1, phf_ktab kl) {
   const double y0 = -x0 * PHF_INV_SQRT2, y1 = -x1 * PHF_INV_SQRT2;
   const double q0 = phf_erfcx_den(y0), q1 = phf_erfcx_den(y1);
   const double iq = 1.0 / (q0 * q1);
-  const phf_ktab ke = PHF_KLOAD(phf_k_erfcx);
+  PHF_KFETCH(ke, phf_k_erfcx, 24);
   const double e0 = phf_erfcx_finish_k(y0, iq * q1, ke), e1 = phf_erfcx_finish_k(y1, iq * q0, ke);
   const phf_logred l0 = phf_log_reduce(0.5 * e0), l1 = phf_log_reduce(0.5 * e1);
   const double d0 = 2.0 + l0.f, d1 = 2.0 + l1.f;
   const double id = 1.0 / (d0 * d1);
-  const phf_ktab kl = PHF_KLOAD(phf_k_log);
   *r0 = phf_fma(-0.5 * x0, x0, phf_log_finish_k(l0, l0.f * (id * d1), kl));
   *r1 = phf_fma(-0.5 * x1, x1, phf_log_finish_k(l1, l1.f * (id * d0), kl));
+}
+
+PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1) {
+  PHF_KFETCH_V(kl, phf_k_log, 7);
+  phf_log_ndtr_nonpos_x2_k(x0, x1, r0, r1, kl);
+}
+
+/* one, with the log table from the caller */
+PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab kl) {
+  const double e = phf_erfcx_core(-x * PHF_INV_SQRT2);
+  const phf_logred lr = phf_log_reduce(0.5 * e);
+  return phf_fma(-0.5 * x, x, phf_log_finish_k(lr, lr.f / (2.0 + lr.f), kl));
 }
 
 /* log Phi(x), any x.  x > 0: log(1 - q), q = erfcx(x/sqrt2) exp(-x^2/2)/2, with the log1p correction term. */
@@ -343,7 +382,7 @@ PHF_HD void phf_sincos_2pi_u32_k(uint32_t w, double* sn, double* cs, phf_ktab k)
   *cs = (h == 0u) ? b : (h == 1u) ? -a : (h == 2u) ? -b : a;
 }
 
-PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) { phf_sincos_2pi_u32_k(w, sn, cs, PHF_KLOAD(phf_k_sincos)); }
+PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) { PHF_KFETCH(k, phf_k_sincos, 10); phf_sincos_2pi_u32_k(w, sn, cs, k); }
 
 /* 53-bit uniform on [0,1) from two words — numpy's random_sample() construction
  * (the reference's npr.rand(), python/PyHillFit.py:834).                                       */

@@ -48,8 +48,8 @@ PHF_HD double phf_censored_z(double pred, double y, double inv_s) {
  * out_ll1 = log_data_likelihood(..., t = 1): what python/compute_bayes_factors.py:18-21 re-evaluates for every saved
  * sample of every rung; it falls out of the same arithmetic here, so the samplers carry it along for free.      */
 PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int n_other, int n_cens,
-                              double pi_bit, double temperature, const double* th, double* out_lik,
-                              double* out_prior, double* out_ll1) {
+                              double pi_bit, double temperature, const double* th, phf_ktab k_exp, phf_ktab k_log,
+                              double* out_lik, double* out_prior, double* out_ll1) {
   const double pic50 = th[0];
   const double hill = (model == 1) ? 1.0 : th[1];
   const double sigma = (model == 1) ? th[1] : th[2];
@@ -62,14 +62,13 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
   const double inv3 = 1.0 / (p1 * dl);
   const double i1 = inv3 * dl;                    /* 1/(sigma ds) */
   const double inv_s = i1 * ds;
-  const phf_ktab k_log = PHF_KLOAD(phf_k_log);
   const double log_sigma = phf_log_finish_k(lr_s, lr_s.f * (i1 * sigma), k_log);
   const double log_sl = phf_log_finish_k(lr_l, lr_l.f * (inv3 * p1), k_log);
 
   double sse = 0.0, cens = 0.0;
   int j = 0;
   for (; j + 4 <= n_other; j += 4) {              /* uncensored points, four at a time (:247) */
-    const phf_ktab ke = PHF_KLOAD(phf_k_exp);
+    const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke, 0), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50, ke, 0);
     const double p01 = d0 * d1, p23 = d2 * d3;
@@ -80,23 +79,23 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
     sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse); sse = phf_fma(r2, r2, sse); sse = phf_fma(r3, r3, sse);
   }
   for (; j < n_other; ++j) {
-    const double r = y[j] - phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, PHF_KLOAD(phf_k_exp), 1));
+    const double r = y[j] - phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1));
     sse = phf_fma(r, r, sse);
   }
   const int n = n_other + n_cens;
   for (; j + 2 <= n; j += 2) {                    /* censored points, two at a time (:244-245) */
-    const phf_ktab ke = PHF_KLOAD(phf_k_exp);
+    const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double inv = 1.0 / (d0 * d1);
     const double z0 = phf_censored_z(phf_hill_percent(inv * d1), y[j], inv_s);
     const double z1 = phf_censored_z(phf_hill_percent(inv * d0), y[j + 1], inv_s);
     double l0, l1;
-    phf_log_ndtr_nonpos_x2(z0, z1, &l0, &l1);
+    phf_log_ndtr_nonpos_x2_k(z0, z1, &l0, &l1, k_log);
     cens += l0; cens += l1;
   }
   for (; j < n; ++j) {
-    const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, PHF_KLOAD(phf_k_exp), 1));
-    cens += phf_log_ndtr_nonpos(phf_censored_z(pred, y[j], inv_s));
+    const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1));
+    cens += phf_log_ndtr_nonpos_k(phf_censored_z(pred, y[j], inv_s), k_log);
   }
   double a = cens - pi_bit;
   a = phf_fma(-(double)n_other, log_sigma, a);                           /* :246 */
@@ -123,7 +122,8 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
  * Box-Muller mate).  The three logarithms share one division.  Truncating the normals at 6.7 / 5.9 sigma keeps
  * the proposal symmetric, which is all Metropolis needs.                                                        */
 PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
-                           uint32_t seed_hi, double* z) {
+                           uint32_t seed_hi, phf_ktab k_log, double* z) {
+  PHF_KFETCH(k_sc, phf_k_sincos, 10);                 /* in flight while Philox runs */
   const phf_u32x4 b = phf_philox4x32_10(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
   double u, ua, ub;
   uint32_t ang_a, ang_b = 0u;
@@ -141,7 +141,6 @@ PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32
   const double pab = da * db;
   const double inv = 1.0 / (pab * du);
   const double iab = inv * du;
-  const phf_ktab k_log = PHF_KLOAD(phf_k_log), k_sc = PHF_KLOAD(phf_k_sincos);
   const double log_ua = phf_log_finish_k(la, la.f * (iab * db), k_log);
   double sn, cs;
   phf_sincos_2pi_u32_k(ang_a, &sn, &cs, k_sc);

@@ -106,8 +106,11 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
   double loga = sp[(size_t)(2 * D + 1 + NTRI) * nchains];
   double nacc = sp[(size_t)(2 * D + 2 + NTRI) * nchains];
   double ll1 = sp[(size_t)(2 * D + 3 + NTRI) * nchains];   // untempered log-likelihood of the current state
+  // exp and log coefficients: in VGPRs for the whole launch (17 doubles)
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
   chol_packed<D>(cov, L);
-  double sc = phf_exp_fast(0.5 * loga);
+  double sc = phf_exp_fast_k(0.5 * loga, k_exp);
 
   double m1[D + 1], m2[D + 1], mll = 0.0;
   const bool want_moments = a.moments != nullptr;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
     // ---- proposal: theta* = theta + e^(loga/2) L z  (PyHillFit.py:831) ----
     double z[4];
-    const double log_u = phf_mh_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, z);
+    const double log_u = phf_mh_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, z);
     double star[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
     }
     // ---- target and accept test (PyHillFit.py:833-838) ----
     double lik_star, prior_star, ll1_star;
-    phf_sl_log_target(MODEL, lc, yv, n_other, n_cens, pi_bit, temperature, star, &lik_star, &prior_star, &ll1_star);
+    phf_sl_log_target(MODEL, lc, yv, n_other, n_cens, pi_bit, temperature, star, k_exp, k_log, &lik_star, &prior_star, &ll1_star);
     const double lt_star = lik_star + prior_star;
     const bool acc = log_u < lt_star - lt;
     if (acc) {
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
       for (int i = 0; i < D; ++i) mean[i] = phf_fma(gs, th[i], omg * mean[i]);
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
       chol_packed<D>(cov, L);
-      sc = phf_exp_fast(0.5 * loga);
+      sc = phf_exp_fast_k(0.5 * loga, k_exp);
     }
     // ---- thinning + sample store (PyHillFit.py:847-848) ----
     if (--until_save == 0) {
@@ -241,8 +244,10 @@ __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
 #pragma unroll
   for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
   double lik0, prior0, ll10;
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
   phf_sl_log_target(MODEL, s_pts, s_pts + a.pts.stride, n_other, n_zero + n_hundred, a.pts.pi_bit[pair], a.prob.temperature[q],
-                    th, &lik0, &prior0, &ll10);
+                    th, k_exp, k_log, &lik0, &prior0, &ll10);
   const double lt = lik0 + prior0;
   double* sp = a.state + g;
 #pragma unroll
@@ -278,8 +283,10 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
   double lik, prior, ll1;
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
   phf_sl_log_target(MODEL, pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride, cnt[0],
-                    cnt[1] + cnt[2], pts.pi_bit[pair], temperature[i], th, &lik, &prior, &ll1);
+                    cnt[1] + cnt[2], pts.pi_bit[pair], temperature[i], th, k_exp, k_log, &lik, &prior, &ll1);
   if (out_lik) out_lik[i] = lik;
   if (out_prior) out_prior[i] = prior;
 }
