@@ -306,11 +306,10 @@ PHF_HD double phf_log_ndtr_nonpos(double x) {
 }
 
 /* two at once, sharing one division for the two erfcx and one for the two logs */
-PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r1, phf_ktab kl) {
+PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r1, phf_ktab ke, phf_ktab kl) {
   const double y0 = -x0 * PHF_INV_SQRT2, y1 = -x1 * PHF_INV_SQRT2;
   const double q0 = phf_erfcx_den(y0), q1 = phf_erfcx_den(y1);
   const double iq = 1.0 / (q0 * q1);
-  PHF_KFETCH(ke, phf_k_erfcx, 24);
   const double e0 = phf_erfcx_finish_k(y0, iq * q1, ke), e1 = phf_erfcx_finish_k(y1, iq * q0, ke);
   const phf_logred l0 = phf_log_reduce(0.5 * e0), l1 = phf_log_reduce(0.5 * e1);
   const double d0 = 2.0 + l0.f, d1 = 2.0 + l1.f;
@@ -320,13 +319,15 @@ PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r
 }
 
 PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1) {
+  PHF_KFETCH(ke, phf_k_erfcx, 24);
   PHF_KFETCH_V(kl, phf_k_log, 7);
-  phf_log_ndtr_nonpos_x2_k(x0, x1, r0, r1, kl);
+  phf_log_ndtr_nonpos_x2_k(x0, x1, r0, r1, ke, kl);
 }
 
 /* one, with the log table from the caller */
-PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab kl) {
-  const double e = phf_erfcx_core(-x * PHF_INV_SQRT2);
+PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab ke, phf_ktab kl) {
+  const double yv = -x * PHF_INV_SQRT2;
+  const double e = phf_erfcx_finish_k(yv, 1.0 / phf_erfcx_den(yv), ke);
   const phf_logred lr = phf_log_reduce(0.5 * e);
   return phf_fma(-0.5 * x, x, phf_log_finish_k(lr, lr.f / (2.0 + lr.f), kl));
 }

@@ -84,18 +84,20 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
   }
   const int n = n_other + n_cens;
   for (; j + 2 <= n; j += 2) {                    /* censored points, two at a time (:244-245) */
+    PHF_KFETCH(k_erfcx, phf_k_erfcx, 24);         /* issued now, needed after the two exponentials */
     const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double inv = 1.0 / (d0 * d1);
     const double z0 = phf_censored_z(phf_hill_percent(inv * d1), y[j], inv_s);
     const double z1 = phf_censored_z(phf_hill_percent(inv * d0), y[j + 1], inv_s);
     double l0, l1;
-    phf_log_ndtr_nonpos_x2_k(z0, z1, &l0, &l1, k_log);
+    phf_log_ndtr_nonpos_x2_k(z0, z1, &l0, &l1, k_erfcx, k_log);
     cens += l0; cens += l1;
   }
   for (; j < n; ++j) {
+    PHF_KFETCH(k_erfcx, phf_k_erfcx, 24);
     const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1));
-    cens += phf_log_ndtr_nonpos_k(phf_censored_z(pred, y[j], inv_s), k_log);
+    cens += phf_log_ndtr_nonpos_k(phf_censored_z(pred, y[j], inv_s), k_erfcx, k_log);
   }
   double a = cens - pi_bit;
   a = phf_fma(-(double)n_other, log_sigma, a);                           /* :246 */
