@@ -89,10 +89,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the sampler has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU over RCCL.  Rehearsal on a single-GPU box: PHF_BENCH_BACKEND=gloo lets several ranks share
+    # device 0 (RCCL refuses two ranks on one GPU); the timing protocol (barrier, MAX over ranks) is the same.
+    backend = os.environ.get("PHF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pyhillfit_amd import doseresponse as dr
     from pyhillfit_amd.sampler import SingleLevelSampler
@@ -196,7 +203,7 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kernel_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))   # HIP events on the launch stream
