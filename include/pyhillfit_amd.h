@@ -119,8 +119,11 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
  * Hierarchical model (python/PyHillFit.py --hierarchical: log_target_distribution :113-193, loop :429-511).
  * theta = [alpha, beta, mu, s, pIC50_1, Hill_1, ..., pIC50_Ne, Hill_Ne, sigma], dim = 5 + 2 Ne (:178-181).
  * One call handles problems whose pairs all have the same number of experiments Ne (1 <= Ne <= PHF_HIER_MAX_EXPTS);
- * the host groups the pairs by Ne (Crumb: Ne = 3..6).                                                         */
-#define PHF_HIER_MAX_EXPTS 8
+ * the host groups the pairs by Ne (Crumb: Ne = 3..6).  Ne <= PHF_HIER_FAST_EXPTS runs kernels compiled per Ne (state in
+ * registers, proposal factor in LDS); larger Ne (the reference's synthetic set has Ne = 50, dim 105) runs a generic
+ * kernel that keeps theta, mean and the factor in the HBM state buffer — correct, not fast.                    */
+#define PHF_HIER_MAX_EXPTS 64
+#define PHF_HIER_FAST_EXPTS 8
 
 /* Points of P pairs, stored experiment by experiment (python/doseresponse.py:60-67 keeps one array per experiment). */
 typedef struct phf_hier_points {

@@ -33,13 +33,10 @@ typedef struct phf_hier_prior {   /* Gamma hyper-priors of (alpha, beta, mu, s, 
 #define PHF_UNROLL
 #endif
 
-/* capacity of the fixed-size work arrays: the device kernels are compiled for Ne <= 8; the host twin also serves the
- * reference's synthetic Ne = 50 data set */
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PHF_HIER_CAP 8
-#else
+/* capacity of the fixed-size work arrays (experiments per pair).  With a compile-time Ne every loop is unrolled and
+ * only the first Ne entries exist (registers); the generic-Ne kernel and the host twin index them at run time
+ * (the reference's synthetic data set has a pair with 50 experiments).                                          */
 #define PHF_HIER_CAP 64
-#endif
 #define PHF_MAX_BATCH (2 + 9 + 2 * PHF_HIER_CAP)
 
 /* v[i] <- 1/v[i] for i < n with ONE division (prefix products, then back-substitution): 3(n-1) multiplications.

@@ -232,17 +232,166 @@ __global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_
                                pts.response + (size_t)pair * pts.stride, th, 1, &prior, k_exp, k_log);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generic path for any Ne <= PHF_HIER_MAX_EXPTS (dim = 5 + 2 Ne known only at run time): theta, mean and the factor stay
+// in the HBM state buffer (struct-of-arrays, coalesced across the lanes of a wave); proposal, normals and the update
+// vector live in LDS, lane-interleaved.  16 chains per block so that 3*dim doubles per chain fit (dim 105 -> 40 KB).
+constexpr int kGenBlock = 16;
+
+__device__ __forceinline__ double gen_target(const HierArgs& a, int ne, int pair, const double* th, int ts, phf_ktab k_exp, phf_ktab k_log) {
+  return phf_hier_log_target(ne, a.pts.expt_start + (size_t)pair * (ne + 1), a.pts.ln_conc + (size_t)pair * a.pts.stride,
+                             a.pts.response + (size_t)pair * a.pts.stride, th, ts, &a.prior, k_exp, k_log);
+}
+
+__global__ __launch_bounds__(kGenBlock) void hier_generic_advance_kernel(const HierArgs a) {
+  extern __shared__ double s_mem[];
+  const int ne = a.pts.n_expts;
+  const int D = 5 + 2 * ne;
+  double* s_star = s_mem + threadIdx.x;                       // element i: s_star[i * kGenBlock]
+  double* s_z = s_star + (size_t)D * kGenBlock;
+  double* s_w = s_z + (size_t)D * kGenBlock;
+  const int q = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - q * a.blocks_per_problem;
+  const int C = a.prob.chains_per_problem;
+  const int c = chunk * kGenBlock + threadIdx.x;
+  if (c >= C) return;
+  const int pair = a.prob.pair_index[q];
+  const uint32_t pid = a.prob.problem_id[q];
+  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
+  const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
+  const size_t nch = (size_t)a.prob.num_problems * C;
+  const size_t g = (size_t)q * C + c;
+  double* th = a.state + g;                                   // element i: th[i * nch]
+  double* plt = th + (size_t)D * nch;
+  double* mean = plt + nch;
+  double* L = mean + (size_t)D * nch;                         // packed lower triangle, element e: L[e * nch]
+  double* ploga = L + (size_t)(D * (D + 1) / 2) * nch;
+  double* pnacc = ploga + nch;
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  double lt = *plt, loga = *ploga, nacc = *pnacc;
+  double sc = phf_exp_fast_k(0.5 * loga, k_exp);
+  const int thin = a.cfg.thinning;
+  int until_save = thin - (int)(a.t_begin % thin);
+  double* out = a.rows ? a.rows + ((size_t)q * (D + 1)) * C + c : nullptr;
+  const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
+  for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
+    const double log_u = phf_hier_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, s_z, kGenBlock);
+    for (int i = 0; i < D; ++i) {
+      double v = L[(size_t)(i * (i + 1) / 2 + i) * nch] * s_z[i * kGenBlock];
+      for (int k = i - 1; k >= 0; --k) v = phf_fma(L[(size_t)(i * (i + 1) / 2 + k) * nch], s_z[k * kGenBlock], v);
+      s_star[i * kGenBlock] = phf_fma(sc, v, th[(size_t)i * nch]);
+    }
+    const double lt_star = gen_target(a, ne, pair, s_star, kGenBlock, k_exp, k_log);
+    const bool acc = log_u < lt_star - lt;
+    if (acc) {
+      for (int i = 0; i < D; ++i) th[(size_t)i * nch] = s_star[i * kGenBlock];
+      lt = lt_star;
+    }
+    nacc += acc ? 1.0 : 0.0;
+    if (t > a.cfg.adapt_start) {
+      const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
+      const double omg = 1.0 - gs;
+      const double sqa = phf_sqrt(omg), sqg = phf_sqrt(gs);
+      for (int i = 0; i < D; ++i) s_w[i * kGenBlock] = sqg * (th[(size_t)i * nch] - mean[(size_t)i * nch]);
+      for (int i = 0; i < D; ++i) mean[(size_t)i * nch] = phf_fma(gs, th[(size_t)i * nch], omg * mean[(size_t)i * nch]);
+      loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
+      for (int k = 0; k < D; ++k) {
+        const double wk = s_w[k * kGenBlock];
+        const double tkk = sqa * L[(size_t)(k * (k + 1) / 2 + k) * nch];
+        const double r = phf_sqrt(phf_fma(tkk, tkk, wk * wk));
+        const double inv = (r > 0.0) ? 1.0 / r : 0.0;
+        const double cs = (r > 0.0) ? tkk * inv : 1.0;
+        const double sn = wk * inv;
+        L[(size_t)(k * (k + 1) / 2 + k) * nch] = r;
+        for (int i = k + 1; i < D; ++i) {
+          const double tik = sqa * L[(size_t)(i * (i + 1) / 2 + k) * nch];
+          const double wi = s_w[i * kGenBlock];
+          L[(size_t)(i * (i + 1) / 2 + k) * nch] = phf_fma(cs, tik, sn * wi);
+          s_w[i * kGenBlock] = phf_fma(cs, wi, -(sn * tik));
+        }
+      }
+      sc = phf_exp_fast_k(0.5 * loga, k_exp);
+    }
+    if (--until_save == 0) {
+      until_save = thin;
+      if (out) {
+        for (int i = 0; i < D; ++i) out[(size_t)i * C] = th[(size_t)i * nch];
+        out[(size_t)D * C] = lt;
+        out += row_stride;
+      }
+      if (a.moments && t > a.moments_after) {
+        for (int i = 0; i < D; ++i) {
+          const double x = th[(size_t)i * nch];
+          a.moments[(size_t)i * nch + g] += x;
+          a.moments[(size_t)(D + 1 + i) * nch + g] = phf_fma(x, x, a.moments[(size_t)(D + 1 + i) * nch + g]);
+        }
+        a.moments[(size_t)D * nch + g] += lt;
+        a.moments[(size_t)(2 * D + 1) * nch + g] = phf_fma(lt, lt, a.moments[(size_t)(2 * D + 1) * nch + g]);
+      }
+    }
+  }
+  *plt = lt; *ploga = loga; *pnacc = nacc;
+}
+
+__global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a) {
+  const int ne = a.pts.n_expts;
+  const int D = 5 + 2 * ne;
+  const int q = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - q * a.blocks_per_problem;
+  const int C = a.prob.chains_per_problem;
+  const int c = chunk * 64 + threadIdx.x;
+  if (c >= C) return;
+  const int pair = a.prob.pair_index[q];
+  const size_t nch = (size_t)a.prob.num_problems * C;
+  const size_t g = (size_t)q * C + c;
+  double* sp = a.state + g;
+  for (int i = 0; i < D; ++i) {
+    const double v = a.theta0[(size_t)i * nch + g];
+    sp[(size_t)i * nch] = v; sp[(size_t)(D + 1 + i) * nch] = v;
+    for (int j = 0; j <= i; ++j)
+      sp[(size_t)(2 * D + 1 + i * (i + 1) / 2 + j) * nch] = (i != j) ? 0.0 : phf_sqrt(a.cov_scale * __builtin_fabs(v));
+  }
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  const double lt = gen_target(a, ne, pair, sp, (int)nch, k_exp, k_log);
+  sp[(size_t)D * nch] = lt;
+  const int tri = D * (D + 1) / 2;
+  sp[(size_t)(2 * D + 1 + tri) * nch] = 0.0;
+  sp[(size_t)(2 * D + 2 + tri) * nch] = 0.0;
+  if (a.row0) {
+    double* o = a.row0 + ((size_t)q * (D + 1)) * C + c;
+    for (int i = 0; i < D; ++i) o[(size_t)i * C] = sp[(size_t)i * nch];
+    o[(size_t)D * C] = lt;
+  }
+}
+
+__global__ __launch_bounds__(64) void hier_generic_log_target_kernel(const phf_hier_points pts, const phf_hier_prior prior, int64_t m,
+                                                                     const int32_t* pair_index, const double* theta, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= m) return;
+  const int ne = pts.n_expts;
+  const int pair = pair_index[i];
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  out[i] = phf_hier_log_target(ne, pts.expt_start + (size_t)pair * (ne + 1), pts.ln_conc + (size_t)pair * pts.stride,
+                               pts.response + (size_t)pair * pts.stride, theta + i, (int)m, &prior, k_exp, k_log);
+}
+
 int check(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior) {
   if (!pts || !prior) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null hierarchical points/prior");
   if (pts->n_expts < 1 || pts->n_expts > PHF_HIER_MAX_EXPTS)
-    return phf_fail(PHF_ERR_UNSUPPORTED, "hierarchical sampler supports 1..8 experiments per pair");
+    return phf_fail(PHF_ERR_UNSUPPORTED, "hierarchical sampler supports 1..64 experiments per pair");
   if (pts->num_pairs <= 0 || pts->stride <= 0 || !pts->ln_conc || !pts->response || !pts->expt_start)
     return phf_fail(PHF_ERR_INVALID_ARGUMENT, "incomplete phf_hier_points");
   if (prob) {
     if (prob->num_problems <= 0 || prob->chains_per_problem <= 0 || !prob->pair_index || !prob->problem_id)
       return phf_fail(PHF_ERR_INVALID_ARGUMENT, "incomplete phf_problems");
-    const int64_t bpp = (prob->chains_per_problem + kBlock - 1) / kBlock;
+    const int blk = (pts->n_expts > PHF_HIER_FAST_EXPTS) ? kGenBlock : kBlock;
+    const int64_t bpp = (prob->chains_per_problem + blk - 1) / blk;
     if (bpp * prob->num_problems > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
+    if ((int64_t)prob->num_problems * prob->chains_per_problem > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains");
   }
   return PHF_OK;
 }
@@ -283,8 +432,37 @@ int launch_init(const HierArgs& a, hipStream_t stream) {
     default: return FN<8>(__VA_ARGS__);                             \
   }
 
-int dispatch_advance(const HierArgs& a, hipStream_t s) { PHF_DISPATCH_NE(a.pts.n_expts, launch_advance, a, s) }
-int dispatch_init(const HierArgs& a, hipStream_t s) { PHF_DISPATCH_NE(a.pts.n_expts, launch_init, a, s) }
+int launch_generic_advance(HierArgs a, hipStream_t stream) {
+  const int D = 5 + 2 * a.pts.n_expts;
+  const size_t lds = (size_t)3 * D * kGenBlock * 8;
+  if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "dimension too large for the generic hierarchical kernel");
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_generic_advance_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    configured = true;
+  }
+  a.blocks_per_problem = (a.prob.chains_per_problem + kGenBlock - 1) / kGenBlock;
+  hipLaunchKernelGGL(hier_generic_advance_kernel, dim3((unsigned)(a.blocks_per_problem * a.prob.num_problems)), dim3(kGenBlock), lds, stream, a);
+  return phf_check_launch("phf_hierarchical_advance (generic Ne)");
+}
+
+int launch_generic_init(HierArgs a, hipStream_t stream) {
+  a.blocks_per_problem = (a.prob.chains_per_problem + 63) / 64;
+  hipLaunchKernelGGL(hier_generic_init_kernel, dim3((unsigned)(a.blocks_per_problem * a.prob.num_problems)), dim3(64), 0, stream, a);
+  return phf_check_launch("phf_hierarchical_init (generic Ne)");
+}
+
+int dispatch_advance(const HierArgs& a, hipStream_t s) {
+  if (a.pts.n_expts > PHF_HIER_FAST_EXPTS) return launch_generic_advance(a, s);
+  PHF_DISPATCH_NE(a.pts.n_expts, launch_advance, a, s)
+}
+int dispatch_init(const HierArgs& a, hipStream_t s) {
+  if (a.pts.n_expts > PHF_HIER_FAST_EXPTS) return launch_generic_init(a, s);
+  PHF_DISPATCH_NE(a.pts.n_expts, launch_init, a, s)
+}
 
 template <int NE>
 int launch_log_target(const phf_hier_points& pts, const phf_hier_prior& prior, int64_t m, const int32_t* pair_index,
@@ -299,7 +477,7 @@ int launch_log_target(const phf_hier_points& pts, const phf_hier_prior& prior, i
 extern "C" {
 
 int phf_hierarchical_state_size(int n_expts) {
-  if (n_expts < 1 || n_expts > PHF_HIER_MAX_EXPTS) return phf_fail(PHF_ERR_UNSUPPORTED, "hierarchical sampler supports 1..8 experiments per pair");
+  if (n_expts < 1 || n_expts > PHF_HIER_MAX_EXPTS) return phf_fail(PHF_ERR_UNSUPPORTED, "hierarchical sampler supports 1..64 experiments per pair");
   const int d = 5 + 2 * n_expts;
   return 2 * d + d * (d + 1) / 2 + 3;
 }
@@ -337,6 +515,12 @@ int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior
   if (int rc = check(pts, nullptr, prior)) return rc;
   if (m < 0 || !pair_index || !theta || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_hierarchical_log_target");
   if (m == 0) return PHF_OK;
+  if (m > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many evaluations for one call");
+  if (pts->n_expts > PHF_HIER_FAST_EXPTS) {
+    hipLaunchKernelGGL(hier_generic_log_target_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *pts, *prior, m,
+                       pair_index, theta, out);
+    return phf_check_launch("phf_hierarchical_log_target (generic Ne)");
+  }
   PHF_DISPATCH_NE(pts->n_expts, launch_log_target, *pts, *prior, m, pair_index, theta, out, (hipStream_t)stream)
 }
 

@@ -26,7 +26,7 @@ ELKINS_PIC50_MUS = np.array([5.235, 5.765, 6.060, 5.315, 5.571, 7.378, 7.248, 5.
                              6.217, 5.927, 7.414, 4.860])
 ELKINS_PIC50_SIGMAS = np.array([0.0760, 0.1388, 0.1459, 0.2044, 0.1597, 0.2216, 0.1856, 0.1560, 0.1034, 0.1033, 0.1914,
                                 0.1498, 0.1464, 0.1053, 0.1342, 0.1808, 0.0860])
-MAX_EXPTS = 8     # PHF_HIER_MAX_EXPTS
+MAX_EXPTS = 64    # PHF_HIER_MAX_EXPTS (Ne <= 8: kernels compiled per Ne; above: generic kernel, state in HBM)
 
 
 def prior_params():

@@ -39,7 +39,8 @@ def test_version_and_state_sizes(lib):
     assert lib.phf_single_level_state_size(3) < 0
     assert b"model" in lib.phf_last_error()
     assert lib.phf_hierarchical_state_size(3) == 2 * 11 + 66 + 3 and lib.phf_hierarchical_state_size(6) == 2 * 17 + 153 + 3
-    assert lib.phf_hierarchical_state_size(9) == -3 and lib.phf_hierarchical_state_size(0) == -3
+    assert lib.phf_hierarchical_state_size(50) == 2 * 105 + 105 * 106 // 2 + 3
+    assert lib.phf_hierarchical_state_size(65) == -3 and lib.phf_hierarchical_state_size(0) == -3
 
 
 def test_argument_validation_without_gpu(lib):

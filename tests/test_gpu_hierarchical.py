@@ -46,7 +46,7 @@ def test_hier_log_target_vs_reference_golden_and_twin(gpu, golden_meta, oracle_p
         pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
         assert np.array_equal(got, np.array([pk.log_target(t) for t in th]), equal_nan=True)
         done += 1
-    assert done >= 7
+    assert done == 8          # includes the synthetic Ne = 50 pair (dim 105) through the generic-Ne kernel
 
 
 @pytest.mark.parametrize("names", [[("Amiodarone", "hERG"), ("Lidocaine", "KvLQT1/mink")], [("Amitriptyline", "Kv4.3"), ("Cibenzoline", "Kv4.3")]])
@@ -111,3 +111,33 @@ def test_hierarchical_cli_and_statistics(gpu, tmp_path):
         w = ref["%s_hERG" % sm["drug"]]
         assert abs(sm["pooled_mean"][0] - w["alpha_mean"]) < 0.12 * w["alpha_mean"] + 0.03
         assert abs(sm["pooled_mean"][2] - w["mu_mean"]) < 0.015 * w["mu_mean"] + 0.03
+
+
+def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):
+    """pairs with more than 8 experiments (the reference's synthetic set: Ne = 50, dim 105, 200 points) run the generic
+    kernel (theta / mean / factor in the HBM state buffer): same bits as the twin, across a launch cut"""
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import gamma_table
+    shapes, scales, locs = H.prior_params()
+    p = oracle_pair("Lie-docaine", "Channel", "synthetic")
+    packed = H.PackedHierPoints([p.experiments])
+    ne = packed.n_expts
+    assert ne == 50
+    d = 5 + 2 * ne
+    theta0 = np.concatenate([[1., 5., 4., .3], np.tile([4.0, 1.0], ne), [6.0]])
+    C, T, thin, adapt = 20, 90, 3, 30
+    s = H.HierarchicalSampler(packed, [0], C, thinning=thin, seed=42, adapt_start=adapt, problem_ids=[3], chain_id_base=100, device=gpu)
+    s.init(theta0, cov_scale=0.01)
+    row0 = s.row0.cpu().numpy()
+    chain = np.concatenate([s.advance(k).cpu().numpy() for k in (adapt + 5, T - adapt - 5)])
+    state = s.state.cpu().numpy().reshape(s.S, 1, C)
+    pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+    gam = gamma_table(T)
+    for c in (0, 7, C - 1):
+        st = pk.init_state(theta0, 0.01)
+        assert np.array_equal(row0[0, :, c], np.concatenate([theta0, [st[d]]]))
+        rows = pk.advance(st, 0, T, thin, adapt, gam, seed=42, chain_id=100 + c, problem_id=3)
+        assert np.array_equal(chain[:, 0, :, c], rows)
+        assert np.array_equal(state[:, 0, c], st)
+    assert np.isfinite(chain).all() and (np.diff(chain[:, 0, 0, :], axis=0) != 0).any()
