@@ -43,8 +43,9 @@ def profile_facts(workload, chains, iters, thinning):
     return out
 
 
-def cpu_baseline(iterations=15000):
-    """rank 0 only, N=1 only: the oracle timed on the host.  'port' = the numpy/scipy restatement of the reference
+def cpu_baseline(iterations=300000):
+    """rank 0 only, N=1 only: the oracle timed on the host (about 10 s + 5 s of CPU work).
+    'port' = the numpy/scipy restatement of the reference
     loop (python/PyHillTemp.py:57-125 with numpy's legacy RNG, like the reference), one core, same pair/model.
     The scalar C twin's rate is reported next to it."""
     from oracle import pyhillfit_oracle as orc
@@ -58,7 +59,7 @@ def cpu_baseline(iterations=15000):
     dt = time.perf_counter() - t0
     pk = co.PackedPair(concs, y, 2, 1.0)
     st = pk.init_state([6.0, 0.8, 8.0], False, 0.05)
-    n_c = 2000000
+    n_c = 20000000
     gam = co.gamma_table(n_c)
     t0 = time.perf_counter()
     pk.advance(st, 0, n_c, 5, 3000, False, gam, seed=25)
