@@ -353,37 +353,42 @@ PHF_HD double phf_ndtr(double x) {
 }
 
 /* ------------------------------------------------------------------------------------------------ sin/cos
- * sin and cos of 2*pi*w/2^32 for a 32-bit integer w: exact octant reduction in the integer domain,
- * |x| <= pi/8 kernels of degree 11/12 (approximation error 5e-18), exact rotations.                           */
-PHF_KTABLE phf_k_sincos[10] = { /* sin: S(z) coefficients of z^0..z^4, then cos: C(z) of z^0..z^4 */
-    -0x1.5555555555554p-3, 0x1.111111110fd1dp-7, -0x1.a01a018fee5fbp-13, 0x1.71ddf0ef66ef1p-19, -0x1.ad54503fdffb8p-26,
-    0x1.5555555555555p-5, -0x1.6c16c16c160afp-10, 0x1.a01a0196dbfc7p-16, -0x1.27e4d184456c9p-22, 0x1.1e5217c71f176p-29};
+ * sin and cos of 2*pi*w/2^32 for a 32-bit integer w: exact quadrant reduction in the integer domain,
+ * |x| <= pi/4 kernels of degree 13/14 (approximation error 2e-17), rotation by swap + sign-bit flips (no branches). */
+PHF_KTABLE phf_k_sincos[12] = { /* sin: S(z) coefficients of z^0..z^5, then cos: C(z) of z^0..z^5, |x| <= pi/4 */
+    -0x1.5555555555555p-3, 0x1.1111111110bb1p-7, -0x1.a01a019e8357dp-13, 0x1.71de37961e4c6p-19, -0x1.ae600a926c89ap-26,
+    0x1.5e0af186af739p-33,
+    0x1.5555555555555p-5, -0x1.6c16c16c16966p-10, 0x1.a01a019f4e867p-16, -0x1.27e4fa17a41b4p-22, 0x1.1eeb68b109173p-29,
+    -0x1.907d7aebd5e3dp-37};
 
 PHF_HD void phf_sincos_2pi_u32_k(uint32_t w, double* sn, double* cs, phf_ktab k) {
-  const uint32_t q = ((w >> 28) + 1u) >> 1;                 /* nearest multiple of pi/4: 0..8 */
-  const int32_t rem = (int32_t)(w - (q << 29));              /* [-2^28, 2^28); q = 8 wraps to the same value */
+  const uint32_t q = ((w >> 29) + 1u) >> 1;                 /* nearest multiple of pi/2: 0..4 */
+  const int32_t rem = (int32_t)(w - (q << 30));              /* [-2^29, 2^29); q = 4 wraps to the same value */
   const double x = (double)rem * PHF_2PI_2M32;
   const double z = x * x;
-  double ps = k[4];
+  double ps = k[5];
+  ps = PHF_FMA_K(ps, z, k[4]);
   ps = PHF_FMA_K(ps, z, k[3]);
   ps = PHF_FMA_K(ps, z, k[2]);
   ps = PHF_FMA_K(ps, z, k[1]);
   ps = PHF_FMA_K(ps, z, k[0]);
-  double pc = k[9];
+  double pc = k[11];
+  pc = PHF_FMA_K(pc, z, k[10]);
+  pc = PHF_FMA_K(pc, z, k[9]);
   pc = PHF_FMA_K(pc, z, k[8]);
   pc = PHF_FMA_K(pc, z, k[7]);
   pc = PHF_FMA_K(pc, z, k[6]);
-  pc = PHF_FMA_K(pc, z, k[5]);
   const double s = phf_fma(x * z, ps, x);
   const double c = phf_fma(z * z, pc, phf_fma(-0.5, z, 1.0));
-  const double a = (q & 1u) ? PHF_INV_SQRT2 * (s + c) : s;  /* sin(x + (q&1) pi/4) */
-  const double b = (q & 1u) ? PHF_INV_SQRT2 * (c - s) : c;  /* cos(x + (q&1) pi/4) */
-  const uint32_t h = (q >> 1) & 3u;                          /* quarter turns */
-  *sn = (h == 0u) ? a : (h == 1u) ? b : (h == 2u) ? -a : -b;
-  *cs = (h == 0u) ? b : (h == 1u) ? -a : (h == 2u) ? -b : a;
+  /* quarter turns h = q mod 4: (sin, cos) = (s,c), (c,-s), (-s,-c), (-c,s): a swap and two sign flips (sign-bit xor) */
+  const uint32_t h = q & 3u;
+  const double a = (h & 1u) ? c : s;
+  const double b = (h & 1u) ? s : c;
+  *sn = phf_from_bits(phf_bits(a) ^ ((uint64_t)(h >> 1) << 63));
+  *cs = phf_from_bits(phf_bits(b) ^ ((uint64_t)(((h + 1u) >> 1) & 1u) << 63));
 }
 
-PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) { PHF_KFETCH(k, phf_k_sincos, 10); phf_sincos_2pi_u32_k(w, sn, cs, k); }
+PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) { PHF_KFETCH(k, phf_k_sincos, 12); phf_sincos_2pi_u32_k(w, sn, cs, k); }
 
 /* 53-bit uniform on [0,1) from two words — numpy's random_sample() construction
  * (the reference's npr.rand(), python/PyHillFit.py:834).                                       */
