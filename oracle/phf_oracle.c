@@ -70,9 +70,10 @@ static void chol_packed(int d, const double* c, double* l) {
       double s = c[i * (i + 1) / 2 + j];
       for (int k = 0; k < j; ++k) s = phf_fma(-l[i * (i + 1) / 2 + k], l[j * (j + 1) / 2 + k], s);
       if (i == j) {
-        const double r = (s > 0.0) ? phf_sqrt(s) : 0.0;
+        const double sp = __builtin_fmax(s, 0.0);
+        const double r = phf_sqrt(sp);
         l[i * (i + 1) / 2 + i] = r;
-        inv[i] = (s > 0.0) ? 1.0 / r : 0.0;
+        inv[i] = (sp > 0.0) ? 1.0 / r : 0.0;
       } else {
         l[i * (i + 1) / 2 + j] = s * inv[j];
       }

@@ -33,10 +33,12 @@ __device__ __forceinline__ void chol_packed(const double* c, double* l) {
       double s = c[i * (i + 1) / 2 + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) s = phf_fma(-l[i * (i + 1) / 2 + k], l[j * (j + 1) / 2 + k], s);
-      if (i == j) {
-        const double r = (s > 0.0) ? phf_sqrt(s) : 0.0;
+      if (i == j) {   // sqrt and reciprocal are computed unconditionally (no divergent branch); a non-positive pivot selects 0
+        const double sp = __builtin_fmax(s, 0.0);
+        const double r = phf_sqrt(sp);
+        const double ir = 1.0 / r;
         l[i * (i + 1) / 2 + i] = r;
-        inv[i] = (s > 0.0) ? 1.0 / r : 0.0;
+        inv[i] = (sp > 0.0) ? ir : 0.0;
       } else {
         l[i * (i + 1) / 2 + j] = s * inv[j];
       }
