@@ -195,7 +195,7 @@ PHF_HD void phf_box_muller_k(uint32_t w1, uint32_t w2, double* z0, double* z1, p
 
 PHF_HD double phf_hier_draws(int dim, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
                              uint32_t seed_hi, phf_ktab k_log, double* z, int zs) {
-  PHF_KFETCH(k_sc, phf_k_sincos, 12);
+  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   const int nb = (dim + 3) / 4;
   PHF_UNROLL
   for (int b = 0; b < nb; ++b) {

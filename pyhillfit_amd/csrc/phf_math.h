@@ -367,17 +367,17 @@ PHF_HD void phf_sincos_2pi_u32_k(uint32_t w, double* sn, double* cs, phf_ktab k)
   const double x = (double)rem * PHF_2PI_2M32;
   const double z = x * x;
   double ps = k[5];
-  ps = PHF_FMA_K(ps, z, k[4]);
-  ps = PHF_FMA_K(ps, z, k[3]);
-  ps = PHF_FMA_K(ps, z, k[2]);
-  ps = PHF_FMA_K(ps, z, k[1]);
-  ps = PHF_FMA_K(ps, z, k[0]);
+  ps = PHF_FMA_KV(ps, z, k[4]);
+  ps = PHF_FMA_KV(ps, z, k[3]);
+  ps = PHF_FMA_KV(ps, z, k[2]);
+  ps = PHF_FMA_KV(ps, z, k[1]);
+  ps = PHF_FMA_KV(ps, z, k[0]);
   double pc = k[11];
-  pc = PHF_FMA_K(pc, z, k[10]);
-  pc = PHF_FMA_K(pc, z, k[9]);
-  pc = PHF_FMA_K(pc, z, k[8]);
-  pc = PHF_FMA_K(pc, z, k[7]);
-  pc = PHF_FMA_K(pc, z, k[6]);
+  pc = PHF_FMA_KV(pc, z, k[10]);
+  pc = PHF_FMA_KV(pc, z, k[9]);
+  pc = PHF_FMA_KV(pc, z, k[8]);
+  pc = PHF_FMA_KV(pc, z, k[7]);
+  pc = PHF_FMA_KV(pc, z, k[6]);
   const double s = phf_fma(x * z, ps, x);
   const double c = phf_fma(z * z, pc, phf_fma(-0.5, z, 1.0));
   /* quarter turns h = q mod 4: (sin, cos) = (s,c), (c,-s), (-s,-c), (-c,s): a swap and two sign flips (sign-bit xor) */
@@ -388,7 +388,7 @@ PHF_HD void phf_sincos_2pi_u32_k(uint32_t w, double* sn, double* cs, phf_ktab k)
   *cs = phf_from_bits(phf_bits(b) ^ ((uint64_t)(((h + 1u) >> 1) & 1u) << 63));
 }
 
-PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) { PHF_KFETCH(k, phf_k_sincos, 12); phf_sincos_2pi_u32_k(w, sn, cs, k); }
+PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) { PHF_KFETCH_V(k, phf_k_sincos, 12); phf_sincos_2pi_u32_k(w, sn, cs, k); }
 
 /* 53-bit uniform on [0,1) from two words — numpy's random_sample() construction
  * (the reference's npr.rand(), python/PyHillFit.py:834).                                       */

@@ -124,8 +124,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
  * Box-Muller mate).  The three logarithms share one division.  Truncating the normals at 6.7 / 5.9 sigma keeps
  * the proposal symmetric, which is all Metropolis needs.                                                        */
 PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
-                           uint32_t seed_hi, phf_ktab k_log, double* z) {
-  PHF_KFETCH(k_sc, phf_k_sincos, 12);                 /* in flight while Philox runs */
+                           uint32_t seed_hi, phf_ktab k_log, phf_ktab k_sc, double* z) {
   const phf_u32x4 b = phf_philox4x32_10(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
   double u, ua, ub;
   uint32_t ang_a, ang_b = 0u;

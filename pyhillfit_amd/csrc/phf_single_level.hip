@@ -71,7 +71,7 @@ __device__ __forceinline__ void stage_points(const phf_points& pts, int pair, do
   __syncthreads();
 }
 
-template <int MODEL>
+template <int MODEL, bool MOMENTS>
 __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a) {
   constexpr int D = Dim<MODEL>::d;
   constexpr int NTRI = D * (D + 1) / 2;
@@ -111,11 +111,12 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
   // exp and log coefficients: in VGPRs for the whole launch (17 doubles)
   PHF_KFETCH_V(k_exp, phf_k_exp, 10);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   chol_packed<D>(cov, L);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
 
   double m1[D + 1], m2[D + 1], mll = 0.0;
-  const bool want_moments = a.moments != nullptr;
+  constexpr bool want_moments = MOMENTS;               // compiled out (and its 18 VGPRs freed) when no moments are requested
   if (want_moments) {
 #pragma unroll
     for (int i = 0; i <= D; ++i) {
@@ -128,13 +129,14 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
   const int thin = a.cfg.thinning;
   int until_save = thin - (int)(a.t_begin % thin);   // iterations until the next t with t % thin == 0
   // rows[r][q][f][c]
-  double* out = a.rows ? a.rows + ((size_t)q * (D + 1)) * C + c : nullptr;
+  const bool save_rows = a.rows != nullptr;             // wave-uniform (scalar) test, not a per-lane pointer compare
+  double* out = a.rows + ((size_t)q * (D + 1)) * C + c;
   const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
 
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
     // ---- proposal: theta* = theta + e^(loga/2) L z  (PyHillFit.py:831) ----
     double z[4];
-    const double log_u = phf_mh_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, z);
+    const double log_u = phf_mh_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, k_sc, z);
     double star[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
     // ---- thinning + sample store (PyHillFit.py:847-848) ----
     if (--until_save == 0) {
       until_save = thin;
-      if (out) {
+      if (save_rows) {
 #pragma unroll
         for (int i = 0; i < D; ++i) out[(size_t)i * C] = th[i];
         out[(size_t)D * C] = lt;
@@ -375,8 +377,13 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
   const dim3 grid((unsigned)(a.blocks_per_problem * prob->num_problems)), block(kBlock);
   const size_t lds = (size_t)pts->stride * 16;
-  if (cfg->model == 1) hipLaunchKernelGGL(mh_advance_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(mh_advance_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+  if (cfg->model == 1) {
+    if (moments) hipLaunchKernelGGL((mh_advance_kernel<1, true>), grid, block, lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mh_advance_kernel<1, false>), grid, block, lds, (hipStream_t)stream, a);
+  } else {
+    if (moments) hipLaunchKernelGGL((mh_advance_kernel<2, true>), grid, block, lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mh_advance_kernel<2, false>), grid, block, lds, (hipStream_t)stream, a);
+  }
   return phf_check_launch("phf_single_level_advance");
 }
 
