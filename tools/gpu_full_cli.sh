@@ -1,0 +1,27 @@
+#!/bin/bash
+# End-to-end drop-in run at the reference's defaults (500 000 iterations, thinning 5, burn-in 1/4) on all 210 Crumb pairs.
+set -u
+mkdir -p gpurun_out /tmp/phf_cli
+python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+from pyhillfit_amd import doseresponse as dr
+dr.setup("data/crumb_dataset.json"); dr.table.to_csv("/tmp/phf_cli/crumb_data.csv")
+PY
+for mode in "-m 2" "-m 1" "-m 2 --hierarchical"; do
+  tag=$(echo $mode | tr -d ' -')
+  SECONDS=0; timeout -k 10 900 python python/PyHillFit.py --data-file /tmp/phf_cli/crumb_data.csv $mode -a --num-chains 64 --output-root /tmp/phf_cli/output > gpurun_out/cli_$tag.log 2>&1
+  echo "$mode rc=$? wall=${SECONDS}s"
+done
+find /tmp/phf_cli/output -name "*chain*.txt" | wc -l
+du -sh /tmp/phf_cli/output
+python - <<'PY'
+import json, glob, numpy as np
+for pat, name in (("/tmp/phf_cli/output/crumb_data/single-level/*/*/model_2/temperature_1/chain/*_summary.json", "model 2"),
+                  ("/tmp/phf_cli/output/crumb_data/single-level/*/*/model_1/temperature_1/chain/*_summary.json", "model 1"),
+                  ("/tmp/phf_cli/output/crumb_data/hierarchical/*/*/*_expts/chain/*_summary.json", "hierarchical")):
+    fs = glob.glob(pat)
+    ss = [json.load(open(f)) for f in fs]
+    if ss:
+        print(name, len(ss), "pairs; sampler MH samples/s:", "%.3g" % ss[0]["mh_samples_per_second"], "mean acceptance %.3f" % np.mean([s["acceptance"] for s in ss]))
+PY
