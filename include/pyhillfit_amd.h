@@ -179,6 +179,23 @@ int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* strea
 /* The four Philox words of n (counter, key) tuples: in device uint32 [n][6], out device uint32 [n][4]. */
 int phf_debug_philox(int64_t n, const uint32_t* counter_key, uint32_t* out, void* stream);
 
+/* ---- posterior-predictive curves -------------------------------------------------------------------
+ * Replaces construct_posterior_predictive_cdfs (python/construct_hierarchical_cdfs.py:32-58): for every problem q
+ * and every hierarchical sample (alpha, beta, mu, s) add fisk.cdf/pdf(hill_x; c=beta, scale=alpha) and
+ * logistic.cdf/pdf(pic50_x; mu, s) into running sums; the caller divides by the number of samples (:54-57).
+ *   rows     device [num_rows][num_problems][row_stride][num_chains] — the row buffer phf_hierarchical_advance wrote
+ *            (row_stride = dim+1; columns 0..3 = alpha, beta, mu, s), or any tensor of that shape (a chain read back
+ *            from a reference-format file: row_stride 4, num_chains 1).  Chains 0..chains_used-1 of every row are used.
+ *   hill_x, pic50_x  device [grid_points]  (the reference: 501 points on [0,4] and [-2,12], :33-39)
+ *   chunk    samples per partial sum (fixes the order of the additions; 4096 is a good value)
+ *   sums     device [num_problems][4][grid_points], curves in the order hill cdf, pic50 cdf, hill pdf, pic50 pdf;
+ *            ADDED to (zero it before the first call; call once per segment of rows)
+ *   scratch  device, at least phf_predictive_scratch_bytes(num_problems, num_rows*chains_used, grid_points, chunk) */
+size_t phf_predictive_scratch_bytes(int num_problems, int64_t samples_per_problem, int grid_points, int chunk);
+int phf_predictive_accumulate(int num_problems, const double* rows, int64_t num_rows, int row_stride, int num_chains,
+                              int chains_used, int grid_points, const double* hill_x, const double* pic50_x, int chunk,
+                              double* sums, double* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

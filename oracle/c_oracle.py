@@ -183,3 +183,18 @@ class PackedHierPair:
         lib().phfo_hier_advance(C.byref(self.pb), C.byref(run), _p(st), _p(out), _p(sr) if sr is not None else None,
                                 _p(ur) if ur is not None else None)
         return out
+
+
+def predictive_accumulate(rows, chains_used, hill_x, pic50_x, chunk, sums=None):
+    """twin of phf_predictive_accumulate: rows [num_rows][Q][row_stride][C] -> sums [Q][4][G] (added to `sums`)."""
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    nr, Q, rs, Cn = rows.shape
+    hill_x = np.ascontiguousarray(hill_x, dtype=np.float64); pic50_x = np.ascontiguousarray(pic50_x, dtype=np.float64)
+    G = len(hill_x)
+    out = np.zeros((Q, 4, G)) if sums is None else np.ascontiguousarray(sums, dtype=np.float64).copy()
+    L = lib()
+    L.phfo_predictive_accumulate.restype = None
+    L.phfo_predictive_accumulate.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_void_p]
+    L.phfo_predictive_accumulate(Q, _p(rows), nr, rs, Cn, int(chains_used), G, _p(hill_x), _p(pic50_x), int(chunk), _p(out))
+    return out

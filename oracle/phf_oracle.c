@@ -23,6 +23,7 @@
 
 #include "../pyhillfit_amd/csrc/phf_model.h"
 #include "../pyhillfit_amd/csrc/phf_hier_model.h"
+#include "../pyhillfit_amd/csrc/phf_predictive_model.h"
 
 typedef struct {
   int32_t model;                        /* 1: (pIC50, sigma), Hill = 1;  2: (pIC50, Hill, sigma) */
@@ -284,4 +285,54 @@ void phfo_philox(int64_t n, const uint32_t* ctr_key /* [n][6] */, uint32_t* out 
 void phfo_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
                 double* z /* [4] */, double* log_u) {
   *log_u = phf_mh_draws(d, chain_id, problem_id, t, seed_lo, seed_hi, phf_k_log, phf_k_sincos, z);
+}
+
+/* ---- posterior-predictive curves: twin of phf_predictive_accumulate (python/construct_hierarchical_cdfs.py:32-58) ----
+ * rows host [num_rows][num_problems][row_stride][num_chains]; sums host [num_problems][4][grid_points], added to.
+ * Same order of additions as the kernels: samples in order inside a chunk, then chunk sums left to right.       */
+void phfo_predictive_accumulate(int num_problems, const double* rows, int64_t num_rows, int row_stride, int num_chains,
+                                int chains_used, int grid_points, const double* hill_x, const double* pic50_x,
+                                int chunk, double* sums) {
+  const int64_t samples = num_rows * chains_used;
+  const size_t col = (size_t)num_chains;
+  /* a lane of the kernel owns grid points t and t+256 of its 512-point tile; they share one reciprocal, so the
+     twin pairs them the same way */
+  for (int q = 0; q < num_problems; ++q)
+    for (int g0 = 0; g0 < (grid_points + 511) / 512 * 256; ++g0) {
+      double lnx[2], inv_x[2], px[2];
+      int g[2], live[2];
+      for (int j = 0; j < 2; ++j) {
+        const int gj = (g0 / 256) * 512 + j * 256 + g0 % 256;
+        live[j] = gj < grid_points;
+        g[j] = live[j] ? gj : grid_points - 1;
+        phf_pred_hill_axis(hill_x[g[j]], &lnx[j], &inv_x[j]);
+        px[j] = pic50_x[g[j]];
+      }
+      if (!live[0]) continue;
+      double tot[2][PHF_PRED_CURVES];
+      for (int j = 0; j < 2; ++j)
+        for (int f = 0; f < PHF_PRED_CURVES; ++f) tot[j][f] = sums[((size_t)q * PHF_PRED_CURVES + f) * grid_points + g[j]];
+      for (int64_t m0 = 0; m0 < samples; m0 += chunk) {
+        const int64_t m1 = m0 + chunk < samples ? m0 + chunk : samples;
+        double acc[2][PHF_PRED_CURVES] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        for (int64_t m = m0; m < m1; ++m) {
+          const int64_t r = m / chains_used;
+          const int c = (int)(m - r * chains_used);
+          const double* p = rows + ((size_t)(r * num_problems + q) * row_stride) * col + c;
+          double lna, b, mu, inv_s;
+          phf_pred_prepare(p[0], p[col], p[2 * col], p[3 * col], &lna, &b, &mu, &inv_s);
+          phf_pred_accumulate2(lna, b, mu, inv_s, lnx, inv_x, px, phf_k_exp, acc);
+        }
+        for (int j = 0; j < 2; ++j)
+          for (int f = 0; f < PHF_PRED_CURVES; ++f) tot[j][f] += acc[j][f];
+      }
+      for (int j = 0; j < 2; ++j) {
+        if (!live[j]) continue;
+        for (int f = 0; f < PHF_PRED_CURVES; ++f) {
+          double v = tot[j][f];
+          if ((f == 0 || f == 2) && !(hill_x[g[j]] > 0.0)) v = 0.0;
+          sums[((size_t)q * PHF_PRED_CURVES + f) * grid_points + g[j]] = v;
+        }
+      }
+    }
 }

@@ -299,3 +299,40 @@ def hierarchical_chain(experiments, theta0, iterations, thinning, draws):
 def drop_burn_in(chain, burn_in_fraction):
     """PyHillFit.py:861-864 / PyHillTemp.py:71,125 (Python-2 integer division)."""
     return chain[chain.shape[0] // burn_in_fraction:]
+
+
+# ---- posterior-predictive curves (python/construct_hierarchical_cdfs.py:32-58,133-149) ---------------------------------
+PRED_GRID_POINTS = 501
+PRED_HILL_RANGE = (0., 4.)
+PRED_PIC50_RANGE = (-2., 12.)
+
+
+def predictive_grids():
+    """construct_hierarchical_cdfs.py:33-39"""
+    return (np.linspace(PRED_HILL_RANGE[0], PRED_HILL_RANGE[1], PRED_GRID_POINTS),
+            np.linspace(PRED_PIC50_RANGE[0], PRED_PIC50_RANGE[1], PRED_GRID_POINTS))
+
+
+def predictive_cdfs(alphas, betas, mus, ss, block=2000):
+    """construct_posterior_predictive_cdfs (:32-58): sample means of fisk(c=beta, scale=alpha) and logistic(mu, s) CDFs and
+    PDFs on the two grids.  The reference adds one sample at a time; here blocks of samples are evaluated at once and
+    added in the same order (np.add.reduce over the sample axis is pairwise, so agreement is to rounding, ~1e-15)."""
+    import scipy.stats as st
+    hill_x, pic50_x = predictive_grids()
+    n = len(alphas)
+    sums = np.zeros((4, PRED_GRID_POINTS))
+    for i in range(0, n, block):
+        a, b, m, s = (np.asarray(v[i:i + block], dtype=float)[:, None] for v in (alphas, betas, mus, ss))
+        sums[0] += st.fisk.cdf(hill_x[None, :], c=b, scale=a, loc=0).sum(axis=0)
+        sums[2] += st.fisk.pdf(hill_x[None, :], c=b, scale=a, loc=0).sum(axis=0)
+        sums[1] += st.logistic.cdf(pic50_x[None, :], m, s).sum(axis=0)
+        sums[3] += st.logistic.pdf(pic50_x[None, :], m, s).sum(axis=0)
+    sums /= n
+    return hill_x, sums[0], pic50_x, sums[1], sums[2], sums[3]
+
+
+def predictive_samples(hill_x, hill_cdf, pic50_x, pic50_cdf, num_samples, rng):
+    """:133-137 — inverse-CDF draws by linear interpolation: all Hill uniforms first, then all pIC50 uniforms."""
+    hu = rng.rand(num_samples)
+    pu = rng.rand(num_samples)
+    return np.interp(hu, hill_cdf, hill_x), np.interp(pu, pic50_cdf, pic50_x)

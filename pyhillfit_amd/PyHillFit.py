@@ -49,6 +49,9 @@ def build_parser():
     new.add_argument("--num-chains", type=int, default=64, help="independent chains per (drug, channel) pair")
     new.add_argument("--seed", type=int, default=25, help="Philox seed (the reference seeds numpy with 25)")
     new.add_argument("--device", type=str, default=None, help="HIP device, default cuda:<LOCAL_RANK>")
+    new.add_argument("--predictive-cdfs", action='store_true', default=False, help="hierarchical: also write the posterior-predictive CDFs and (Hill,pIC50) samples of construct_hierarchical_cdfs.py, accumulated on the GPU during sampling")
+    new.add_argument("--cdf-chains", type=int, default=0, help="chains per pair feeding --predictive-cdfs (0 = all; 1 = chain 0 only, what the reference's script computes from the chain file)")
+    new.add_argument("--write-workers", type=int, default=None, help="processes formatting the chain text files (default: this rank's host cores - 1, at most 16; 0 = write in the main process)")
     new.add_argument("--save-all-chains", action='store_true', default=False, help="also write every chain to a .npy next to the chain file")
     new.add_argument("--segment", type=int, default=20000, help="MH iterations per kernel launch")
     new.add_argument("--output-root", type=str, default="output", help="root of the output tree (reference: ./output)")
@@ -113,6 +116,7 @@ def run_single_level(pairs, args, device, rank=0, world=1):
     s.enable_moments(after_iteration=max(burn * thinning - 1, 0))      # moments over exactly the rows that are written
     s.reserve(total_iterations)
     keep_all = args.save_all_chains
+    writers = chainio.WriterPool(args.write_workers)                   # started now: the processes boot while the GPU samples
     d = s.d
     kept = torch.empty((saved_iterations, Q, d + 1, C if keep_all else 1), dtype=torch.float64,
                        device=device if keep_all else "cpu")
@@ -135,9 +139,9 @@ def run_single_level(pairs, args, device, rank=0, world=1):
     summaries = []
     for q, (d_clean, c_clean, chain_file) in enumerate(files):
         chain0 = kept[:, q, :, 0].cpu().numpy()
-        chainio.save_single_level_chain(chain_file, chainio.drop_burn_in(chain0, args.burn_in_fraction), d_clean, c_clean, model)
+        writers.submit(chainio.save_single_level_chain, chain_file, chainio.drop_burn_in(chain0, args.burn_in_fraction), d_clean, c_clean, model)
         if keep_all:
-            np.save(chain_file[:-4] + "_all_chains.npy", chainio.drop_burn_in(kept[:, q].cpu().numpy(), args.burn_in_fraction))
+            np.save(chain_file[:-4] + "_all_chains.npy", chainio.drop_burn_in(kept[:, q].cpu().numpy(), args.burn_in_fraction))   # binary: no formatting to spread
         pooled_mean = mean[:, q].mean(axis=1)
         pooled_sd = np.sqrt(var[:, q].mean(axis=1) + mean[:, q].var(axis=1))
         summ = {"drug": d_clean, "channel": c_clean, "model": model, "chains": C, "iterations": total_iterations,
@@ -150,6 +154,7 @@ def run_single_level(pairs, args, device, rank=0, world=1):
             json.dump(summ, f, indent=1)
         summaries.append(summ)
         print("\n\n{} + {} complete!\n\n".format(d_clean, c_clean))      # PyHillFit.py:970
+    writers.close()
     return summaries
 
 
@@ -168,6 +173,8 @@ def main(argv=None):
     args = parser.parse_args(argv)
     rank, local_rank, world = phfdist.init()
     device = args.device or "cuda:%d" % local_rank
+    if args.write_workers is None:
+        args.write_workers = chainio.default_write_workers(world)
     dr.define_model(args.model)                                        # PyHillFit.py:56
     phfdist.setup_data_file(args.data_file)                            # :61 (rank 0 reads, broadcast to the other GPUs' ranks)
     dr.output_root = args.output_root

@@ -46,6 +46,7 @@ def build_parser():
     new.add_argument("--rungs", type=int, default=None, help="n of the ladder (i/n)^c, default doseresponse.n = 40 (41 rungs)")
     new.add_argument("--all-pairs", action='store_true', default=False, help="run every drug x channel pair instead of -d/-c")
     new.add_argument("--device", type=str, default=None)
+    new.add_argument("--write-workers", type=int, default=None, help="processes formatting the chain text files (default: host cores - 1, at most 16; 0 = main process)")
     new.add_argument("--segment", type=int, default=20000)
     new.add_argument("--output-root", type=str, default="output")
     return parser
@@ -80,6 +81,7 @@ def run_tempered(pairs, temperatures, args, device):
     s.reserve(total_iterations)
     kept = torch.empty((num_saved, Q, d + 1), dtype=torch.float64)
     kept[0] = s.row0[:, :, 0].cpu()
+    writers = chainio.WriterPool(args.write_workers if args.write_workers is not None else chainio.default_write_workers())
     seg = max(thinning, args.segment - args.segment % thinning)
     buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
     done, r = 0, 1
@@ -102,7 +104,7 @@ def run_tempered(pairs, temperatures, args, device):
             q = ip * R + ir
             d_clean, c_clean, chain_file, _ = dr.nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature)
             print("chain_file:", chain_file)
-            chainio.save_tempered_chain(chain_file, kept[burn:, q].numpy())                         # :125,169
+            writers.submit(chainio.save_tempered_chain, chain_file, kept[burn:, q].numpy())         # :125,169
             out.append({"drug": d_clean, "channel": c_clean, "temperature": float(temperature),
                         "pooled_mean": mean[:, q].mean(axis=1).tolist(), "chain_file": chain_file,
                         "log_py_pooled": float(ll1[q].mean()), "log_py_chain0": float(ll1[q, 0])})
@@ -115,6 +117,7 @@ def run_tempered(pairs, temperatures, args, device):
         ti["expectation_chain0"] = float(dr.trapezium_rule(ti["temperatures"], ti["log_py_chain0"]))
         with open(thermodynamic_integration_file(model, drug, channel), "w") as f:
             json.dump(ti, f, indent=1)
+    writers.close()
     with open(dr.output_root + "/" + dr.dir_name + "/tempered_summary_model_%d.json" % model, "w") as f:
         json.dump({"mcmc_seconds": mcmc_time, "chains": C, "rungs": out}, f, indent=1)
     return out

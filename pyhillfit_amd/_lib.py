@@ -12,7 +12,7 @@ ABI_VERSION = 1
 EXPORTS = ["phf_version", "phf_last_error", "phf_single_level_state_size", "phf_single_level_init",
            "phf_single_level_advance", "phf_single_level_log_target", "phf_debug_math", "phf_debug_philox",
            "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance",
-           "phf_hierarchical_log_target"]
+           "phf_hierarchical_log_target", "phf_predictive_scratch_bytes", "phf_predictive_accumulate"]
 
 
 class PhfError(RuntimeError):
@@ -66,6 +66,9 @@ def load():
     lib.phf_single_level_log_target.argtypes = [C.POINTER(Points), i32, i64, vp, vp, vp, vp, vp, vp]
     lib.phf_debug_math.argtypes = [i32, i64, vp, vp, vp]
     lib.phf_debug_philox.argtypes = [i64, vp, vp, vp]
+    lib.phf_predictive_scratch_bytes.argtypes = [i32, i64, i32, i32]
+    lib.phf_predictive_scratch_bytes.restype = C.c_size_t
+    lib.phf_predictive_accumulate.argtypes = [i32, vp, i64, i32, i32, i32, i32, vp, vp, i32, vp, vp, C.c_size_t, vp]
     _lib = lib
     return lib
 

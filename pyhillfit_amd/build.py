@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpyhillfit_amd.so")
-SOURCES = ["phf_capi.hip", "phf_single_level.hip", "phf_hierarchical.hip"]
+SOURCES = ["phf_capi.hip", "phf_single_level.hip", "phf_hierarchical.hip", "phf_predictive.hip"]
 HEADERS = ["phf_common.h", "phf_math.h", "phf_philox.h", "phf_model.h", "phf_hier_model.h", os.path.join("..", "..", "include", "pyhillfit_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

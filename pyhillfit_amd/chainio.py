@@ -1,7 +1,63 @@
 """Chain files: the output contract of the sampling step (python/PyHillFit.py:861-867,423-426,514-525;
 python/PyHillTemp.py:165-169).  Text via np.savetxt's default '%.18e', '#' comment headers, so the reference's
 downstream readers (np.loadtxt with usecols, last column = log-target) work unchanged."""
+import multiprocessing as mp
+import os
+from concurrent.futures import ProcessPoolExecutor
+
 import numpy as np
+
+
+class WriterPool(object):
+    """np.savetxt at '%.18e' formats ~60 MB of text per second and core, which is the bottleneck once sampling takes
+    seconds (7.5 MB of text per single-level chain, 10-14 MB per hierarchical one, 630 files for the
+    three -a runs).  Files are therefore written by `workers` processes that are SPAWNED (fresh interpreters: the
+    parent has initialised HIP, a forked copy of it must not exist) and never import torch; arrays travel pickled.
+    workers <= 0 writes synchronously in the caller.  close() waits and re-raises the first failure."""
+
+    def __init__(self, workers):
+        self.pool = ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) if workers > 0 else None
+        self.pending = []
+
+    def submit(self, fn, *args):
+        if self.pool is None:
+            fn(*args)
+        else:
+            self.pending.append(self.pool.submit(fn, *args))
+
+    def close(self):
+        try:
+            for f in self.pending:
+                f.result()
+        finally:
+            self.pending = []
+            if self.pool is not None:
+                self.pool.shutdown()
+                self.pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def default_write_workers(world=1):
+    """host cores of this rank's share, minus the one driving the GPU; at most 16"""
+    return max(0, min(16, (os.cpu_count() or 1) // max(world, 1) - 1))
+
+
+def load_chain(chain_file, usecols=None):
+    """Reader side of the contract (compute_bayes_factors.py:14, construct_hierarchical_cdfs.py:79: np.loadtxt with
+    usecols): rows of the reference-format text file, '#' headers skipped."""
+    return np.loadtxt(chain_file, usecols=usecols, ndmin=2)
+
+
+def load_all_chains(chain_file):
+    """The binary side file written by --save-all-chains: [rows][columns][chains], or None when it does not exist."""
+    path = chain_file[:-4] + "_all_chains.npy"
+    return np.load(path, mmap_mode="r") if os.path.exists(path) else None
 
 
 def drop_burn_in(chain, burn_in_fraction):
@@ -32,12 +88,26 @@ def save_hierarchical_chain(chain_file, chain):
         np.savetxt(outfile, chain)
 
 
-def save_alpha_mu_samples(samples_file, chain, num_samples, burn, drug, channel, rng):
-    """PyHillFit.py:519-525 — num_samples random post-burn rows, columns (alpha, mu)."""
+def pick_alpha_mu_rows(chain, num_samples, burn, rng):
+    """PyHillFit.py:519-521 — num_samples random post-burn rows, columns (alpha, mu); drawn in the caller so that the
+    RandomState advances there whoever writes the file."""
     indices = rng.randint(burn, chain.shape[0], num_samples)
+    return chain[indices][:, [0, 2]]
+
+
+def save_alpha_mu_samples(samples_file, rows, drug, channel):
+    """PyHillFit.py:522-525."""
     with open(samples_file, 'w') as outfile:
-        outfile.write('# {} (alpha,mu) samples from hierarchical MCMC for {} + {}\n'.format(num_samples, drug, channel))
-        np.savetxt(outfile, chain[indices][:, [0, 2]])
+        outfile.write('# {} (alpha,mu) samples from hierarchical MCMC for {} + {}\n'.format(len(rows), drug, channel))
+        np.savetxt(outfile, rows)
+
+
+def save_table(path, table, header_line):
+    """np.savetxt with an optional literal first line (construct_hierarchical_cdfs.py:130-131,144-149)."""
+    with open(path, 'w') as outfile:
+        if header_line:
+            outfile.write(header_line)
+        np.savetxt(outfile, table)
 
 
 def save_best_fit_params(path, theta0, model):

@@ -9,8 +9,9 @@ Philox streams are addressed by global (problem id, chain id), so results do not
 import os
 
 import numpy as np
-import torch
-import torch.distributed as dist
+
+# torch is imported inside the functions: the chain-file writer processes (chainio.WriterPool) re-import the CLI
+# module that imports this one, and must stay GPU- and torch-free.
 
 
 def env_world():
@@ -19,6 +20,8 @@ def env_world():
 
 def init(backend=None):
     """Initialise the default process group from the torchrun environment (no-op for a single process)."""
+    import torch
+    import torch.distributed as dist
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
@@ -55,6 +58,8 @@ def shard_chains(num_chains, rank, world):
 def broadcast_packed_points(packed, device, src=0):
     """Rank `src` holds a doseresponse.PackedPoints; everybody returns an identical copy.
     (the 'scatter the dataset' step: 4 small tensors, one broadcast each)"""
+    import torch
+    import torch.distributed as dist
     from .doseresponse import PackedPoints
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return packed
@@ -82,6 +87,8 @@ def broadcast_packed_points(packed, device, src=0):
 def gather_rows(local, dst=0):
     """Gather per-problem rows [n_local, k] (n_local may differ per rank) to rank dst; returns list of arrays on dst.
     (the 'gather samples/summaries' step)"""
+    import torch
+    import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [local.cpu().numpy()]
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -102,6 +109,7 @@ def setup_data_file(path, src=0):
     """dr.setup(path) on every rank with ONE reader: rank `src` parses the file and broadcasts the table
     (a few tens of KB through RCCL/gloo) — the reference forks workers that inherit the parsed DataFrame
     (python/PyHillFit.py:61,997-1003)."""
+    import torch.distributed as dist
     from . import doseresponse as dr
     if not dist.is_initialized() or dist.get_world_size() == 1:
         dr.setup(path)

@@ -309,6 +309,21 @@ def nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature):
     return drug, channel, chain_file, images_dir
 
 
+def hierarchical_posterior_predictive_cdf_files(drug, channel, Ne):
+    """doseresponse.py:93-99 (names as cleaned by hierarchical_output_dirs_and_chain_file)."""
+    cdf_dir = '{}/{}/hierarchical/{}/{}/{}_expts/cdfs/'.format(output_root, dir_name, drug, channel, Ne)
+    _mk(cdf_dir)
+    return (cdf_dir + '{}_{}_{}_posterior_predictive_hill_cdf.txt'.format(dir_name, drug, channel),
+            cdf_dir + '{}_{}_{}_posterior_predictive_pic50_cdf.txt'.format(dir_name, drug, channel))
+
+
+def hierarchical_hill_and_pic50_samples_for_AP_file(drug, channel):
+    """doseresponse.py:101-106."""
+    output_dir = '{}/{}/hierarchical/posterior_predictive_hill_pic50_samples/'.format(output_root, dir_name)
+    _mk(output_dir)
+    return output_dir + '{}_{}_{}_hill_pic50_samples.txt'.format(dir_name, drug, channel)
+
+
 def alpha_mu_downsampling(drug, channel):
     """doseresponse.py:130-135."""
     output_dir = '{}/{}/hierarchical/alpha_mu_samples/'.format(output_root, dir_name)

@@ -249,6 +249,12 @@ def _fit_pic50_hill(concs, responses):
     return res.x ** 2 + lowers, float(res.fun)
 
 
+def cdf_chains(args, num_chains):
+    """how many chains of every pair feed the posterior-predictive curves: --cdf-chains, default all"""
+    n = getattr(args, "cdf_chains", 0)
+    return num_chains if n <= 0 else min(n, num_chains)
+
+
 # ---- driver ------------------------------------------------------------------------------------------------------------
 def run_hierarchical(pairs, args, device, rank=0, world=1):
     """All pairs of this rank — replaces python/PyHillFit.py:213-642 run per pair."""
@@ -261,7 +267,8 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
             num_expts, experiment_numbers, experiments = dr.load_crumb_data(drug, channel)
         except Exception:
             print("Problem loading data for {} + {} --- skipping".format(drug, channel)); continue
-        if 0 < args.num_expts < num_expts:                            # :228-231
+        fitted_all = not (0 < args.num_expts < num_expts)
+        if not fitted_all:                                            # :228-231
             num_expts = args.num_expts
             experiments = experiments[:num_expts]
         experiments = experiments[:num_expts] if len(experiments) > num_expts else experiments
@@ -269,12 +276,14 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         if ne > MAX_EXPTS:
             print("{} + {}: {} experiments exceed the {} supported by the hierarchical kernels --- skipping".format(drug, channel, ne, MAX_EXPTS))
             continue
-        groups.setdefault(ne, []).append((drug, channel, experiments, all_pairs.index((drug, channel))))
+        groups.setdefault(ne, []).append((drug, channel, experiments, all_pairs.index((drug, channel)), fitted_all))
     summaries = []
     total_iterations, thinning = args.iterations, args.thinning
     saved_iterations = total_iterations // thinning + 1                # :469
     burn = saved_iterations // 4                                       # :472
     rng = np.random.RandomState(args.seed)
+    rng_pred = np.random.RandomState(1)                                # construct_hierarchical_cdfs.py:12-13
+    writers = chainio.WriterPool(getattr(args, "write_workers", 0))    # started now: the processes boot while the GPU samples
     # one sampler and one HIP stream per Ne group: the groups are independent, their launches overlap on the GPU
     runs = []
     for ne, members in sorted(groups.items()):
@@ -290,7 +299,13 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         kept[0] = s.row0[:, :, 0].cpu()
         seg = max(thinning, args.segment - args.segment % thinning)
         buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
-        runs.append(dict(ne=ne, members=members, theta0=theta0, s=s, kept=kept, buf=buf, seg=seg, r=1,
+        curves = None
+        if getattr(args, "predictive_cdfs", False):                    # construct_hierarchical_cdfs.py fused into the run
+            from .predictive import PredictiveCurves
+            curves = PredictiveCurves(Q, device)
+            if burn == 0:
+                curves.accumulate(s.row0.unsqueeze(0).contiguous(), cdf_chains(args, C))
+        runs.append(dict(ne=ne, members=members, theta0=theta0, s=s, kept=kept, buf=buf, seg=seg, r=1, curves=curves,
                          stream=torch.cuda.Stream(device=device)))
     torch.cuda.synchronize(device)
     start = time.time()
@@ -302,7 +317,11 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
             s = run["s"]
             nr = s.rows_between(s.t, s.t + k)
             with torch.cuda.stream(run["stream"]):
-                pending.append((run, nr, s.advance(k, out=run["buf"][:nr])))
+                rows = s.advance(k, out=run["buf"][:nr])
+                first = max(0, burn - run["r"])                        # saved rows before `burn` are the burn-in (:84-86 of the CDF script)
+                if run["curves"] is not None and first < nr:
+                    run["curves"].accumulate(rows[first:], cdf_chains(args, args.num_chains))
+                pending.append((run, nr, rows))
         for run, nr, rows in pending:          # ... then collect chain 0 of each pair
             with torch.cuda.stream(run["stream"]):
                 run["kept"][run["r"]:run["r"] + nr] = rows[:, :, :, 0].cpu()
@@ -317,11 +336,15 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         mean, var, _ = s.posterior_moments()
         mean, var = mean.cpu().numpy(), var.cpu().numpy()
         acc = s.acceptance().cpu().numpy()
-        for q, (drug, channel, experiments, _) in enumerate(members):
+        for q, (drug, channel, experiments, _, fitted_all) in enumerate(members):
             d_clean, c_clean, output_dir, chain_dir, figs_dir, chain_file = dr.hierarchical_output_dirs_and_chain_file(drug, channel, ne)
             chain0 = kept[:, q].numpy()
-            chainio.save_hierarchical_chain(chain_file, chain0)                                     # :423-426,514-515
-            chainio.save_alpha_mu_samples(dr.alpha_mu_downsampling(d_clean, c_clean), chain0, args.num_APs, burn, d_clean, c_clean, rng)  # :519-525
+            writers.submit(chainio.save_hierarchical_chain, chain_file, chain0)                     # :423-426,514-515
+            writers.submit(chainio.save_alpha_mu_samples, dr.alpha_mu_downsampling(d_clean, c_clean),
+                           chainio.pick_alpha_mu_rows(chain0, args.num_APs, burn, rng), d_clean, c_clean)   # :519-525
+            if run["curves"] is not None:
+                from .predictive import save_cdfs_and_samples
+                save_cdfs_and_samples(writers, d_clean, c_clean, ne, run["curves"].result(q), args.num_APs, rng_pred, fitted_all)
             summ = {"drug": d_clean, "channel": c_clean, "num_expts": ne, "chains": C, "iterations": total_iterations,
                     "pooled_mean": mean[:, q].mean(axis=1).tolist(),
                     "pooled_sd": np.sqrt(var[:, q].mean(axis=1) + mean[:, q].var(axis=1)).tolist(),
@@ -330,4 +353,5 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
             with open(chain_file[:-4] + "_summary.json", "w") as f:
                 json.dump(summ, f, indent=1)
             summaries.append(summ)
+    writers.close()
     return summaries

@@ -130,3 +130,36 @@ def test_bench_profile_facts_only_apply_to_the_measured_launch_shape():
     assert f["flop_per_iteration"] > 1000 and f["traffic_bytes_per_launch"] > 8e8
     assert "traffic_bytes_per_launch" not in bench.profile_facts("c2", 65536, 1000, 5)
     assert bench.profile_facts("zz", 1, 1, 1) == {}
+
+
+def test_writer_pool_files_equal_the_synchronous_ones(tmp_path):
+    """chain files written by spawned worker processes are byte-identical to np.savetxt in the caller, in the reference's
+    format (header lines, '%.18e'), and readable the way the reference's downstream scripts read them"""
+    from pyhillfit_amd import chainio
+    rng = np.random.RandomState(3)
+    chains = [rng.standard_normal((200 + 10 * i, 4)) for i in range(5)]
+    hier = rng.standard_normal((300, 12))
+    for workers, sub in ((0, "sync"), (2, "pool")):
+        os.makedirs(str(tmp_path / sub))
+        with chainio.WriterPool(workers) as w:
+            for i, c in enumerate(chains):
+                w.submit(chainio.save_single_level_chain, str(tmp_path / sub / ("c%d.txt" % i)), c, "Drug", "hERG", 2)
+            w.submit(chainio.save_hierarchical_chain, str(tmp_path / sub / "h.txt"), hier)
+            w.submit(chainio.save_alpha_mu_samples, str(tmp_path / sub / "am.txt"),
+                     chainio.pick_alpha_mu_rows(hier, 50, 75, np.random.RandomState(1)), "Drug", "hERG")
+    for name in ["c%d.txt" % i for i in range(5)] + ["h.txt", "am.txt"]:
+        a = open(str(tmp_path / "sync" / name), "rb").read()
+        assert a == open(str(tmp_path / "pool" / name), "rb").read(), name
+    assert np.array_equal(chainio.load_chain(str(tmp_path / "pool" / "c2.txt")), chains[2])
+    assert np.array_equal(chainio.load_chain(str(tmp_path / "pool" / "h.txt"), usecols=range(4)), hier[:, :4])
+    assert chainio.load_chain(str(tmp_path / "pool" / "am.txt")).shape == (50, 2)
+    first = open(str(tmp_path / "pool" / "h.txt")).readline()
+    assert first.startswith("# Hill ~ log-logistic")
+
+
+def test_writer_pool_reports_a_failed_write(tmp_path):
+    from pyhillfit_amd import chainio
+    w = chainio.WriterPool(1)
+    w.submit(chainio.save_tempered_chain, str(tmp_path / "no_such_dir" / "x.txt"), np.zeros((2, 2)))
+    with pytest.raises(OSError):
+        w.close()

@@ -190,3 +190,17 @@ def test_hierarchical_posterior_is_consistent_with_reference_samples(oracle_pair
         assert abs(s[:, 0].mean() - w["alpha_mean"]) < 0.12 * w["alpha_mean"] + 3 * w["alpha_sd"] / np.sqrt(w["n"] / 10.)
         assert abs(s[:, 2].mean() - w["mu_mean"]) < 0.01 * abs(w["mu_mean"]) + 3 * w["mu_sd"] / np.sqrt(w["n"] / 10.)
         assert s[:, 0].std() == pytest.approx(w["alpha_sd"], rel=0.35) and s[:, 2].std() == pytest.approx(w["mu_sd"], rel=0.35)
+
+
+@pytest.mark.parametrize("name", ["posterior_like", "wide_and_edges", "single_sample"])
+def test_predictive_twin_matches_reference_function(name):
+    """the C twin of phf_predictive_accumulate against golden G7 (reference function, scipy.stats arithmetic)"""
+    g = np.load(os.path.join(GOLDEN, "g7_predictive_cdfs.npz"))
+    s = g[name + "_samples"]
+    rows = s[:, None, :, None]
+    for chunk in (50, 4096):
+        sums = co.predictive_accumulate(rows, 1, g[name + "_hill_x"], g[name + "_pic50_x"], chunk)[0] / len(s)
+        for f, k in enumerate(("hill_cdf", "pic50_cdf", "hill_pdf", "pic50_pdf")):
+            ref = g[name + "_" + k]
+            assert np.all(np.abs(sums[f] - ref) <= 1e-70 + 1e-11 * np.abs(ref)), (name, k, chunk)
+        assert sums[0][0] == 0.0 and sums[2][0] == 0.0

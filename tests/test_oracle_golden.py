@@ -118,3 +118,25 @@ def test_thinning_and_burn_in(golden_meta, oracle_pair):
 def test_temperature_ladder():
     lad = orc.temperature_ladder()
     assert len(lad) == 41 and lad[0] == 0 and lad[-1] == 1 and lad[1] == (1 / 40) ** 3
+
+
+@pytest.mark.parametrize("name", ["posterior_like", "wide_and_edges", "single_sample"])
+def test_predictive_cdfs_restatement_equals_reference_function(name):
+    """G7: construct_posterior_predictive_cdfs (construct_hierarchical_cdfs.py:32-58) executed on seeded samples"""
+    g = np.load(os.path.join(GOLDEN, "g7_predictive_cdfs.npz"))
+    s = g[name + "_samples"]
+    hx, hc, px, pc, hp, pp = orc.predictive_cdfs(s[:, 0], s[:, 1], s[:, 2], s[:, 3], block=97)
+    assert np.array_equal(hx, g[name + "_hill_x"]) and np.array_equal(px, g[name + "_pic50_x"])
+    for got, k in ((hc, "hill_cdf"), (pc, "pic50_cdf"), (hp, "hill_pdf"), (pp, "pic50_pdf")):
+        np.testing.assert_allclose(got, g[name + "_" + k], rtol=1e-13, atol=1e-300)
+
+
+def test_predictive_samples_are_inverse_cdf_draws():
+    g = np.load(os.path.join(GOLDEN, "g7_predictive_cdfs.npz"))
+    hx, hc, px, pc = (g["posterior_like_" + k] for k in ("hill_x", "hill_cdf", "pic50_x", "pic50_cdf"))
+    hs, ps = orc.predictive_samples(hx, hc, px, pc, 2000, np.random.RandomState(1))
+    u = np.random.RandomState(1).rand(4000)
+    for smp, x, c, uu in ((hs, hx, hc, u[:2000]), (ps, px, pc, u[2000:])):   # Hill uniforms first, then pIC50 (:133-134)
+        inside = (uu > c[0] + 1e-9) & (uu < c[-1] - 1e-9)                   # outside the tabulated range np.interp clamps
+        assert inside.sum() > 1900
+        assert np.allclose(np.interp(smp[inside], x, c), uu[inside], atol=1e-9)
