@@ -8,11 +8,16 @@ sys.path.insert(0, os.getcwd())
 from pyhillfit_amd import doseresponse as dr
 dr.setup("data/crumb_dataset.json"); dr.table.to_csv("/tmp/phf_cli/crumb_data.csv")
 PY
-for mode in "-m 2" "-m 1" "-m 2 --hierarchical"; do
+for mode in "-m 2" "-m 1" "-m 2 --hierarchical --predictive-cdfs"; do
   tag=$(echo $mode | tr -d ' -')
   SECONDS=0; timeout -k 10 900 python python/PyHillFit.py --data-file /tmp/phf_cli/crumb_data.csv $mode -a --num-chains 64 --output-root /tmp/phf_cli/output > gpurun_out/cli_$tag.log 2>&1
   echo "$mode rc=$? wall=${SECONDS}s"
 done
+SECONDS=0; timeout -k 10 900 python python/construct_hierarchical_cdfs.py --data-file /tmp/phf_cli/crumb_data.csv -a --num-cores 15 --output-root /tmp/phf_cli/output2 > gpurun_out/cli_cdfs_nofiles.log 2>&1
+echo "construct_hierarchical_cdfs (no chain files: every pair reported and skipped) rc=$? wall=${SECONDS}s"
+SECONDS=0; timeout -k 10 900 python python/construct_hierarchical_cdfs.py --data-file /tmp/phf_cli/crumb_data.csv -a --num-cores 15 --output-root /tmp/phf_cli/output > gpurun_out/cli_cdfs.log 2>&1
+echo "construct_hierarchical_cdfs rc=$? wall=${SECONDS}s"
+find /tmp/phf_cli/output -name "*cdf.txt" | wc -l
 find /tmp/phf_cli/output -name "*chain*.txt" | wc -l
 du -sh /tmp/phf_cli/output
 python - <<'PY'
