@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PHF_ABI_VERSION 1
+#define PHF_ABI_VERSION 2
 
 enum {
   PHF_OK = 0,
@@ -33,19 +33,27 @@ enum {
   PHF_ERR_UNSUPPORTED = -3
 };
 
-/* Dose-response points of P (drug, channel) pairs for the single-level (non-hierarchical) models.
+/* Dose-response data of P (drug, channel) pairs for the single-level (non-hierarchical) models.
  * Replaces the per-pair arrays built at python/PyHillFit.py:661-683 (concs, responses, the three boolean
- * masks and pi_bit).  Points of a pair are stored masked-group by masked-group: first the n_other points with
- * 0 < y < 100 (where_r_other), then the n_zero points with y == 0 (where_r_0), then the n_hundred points with
- * y == 100 (where_r_100), each group in file order; points outside [0,100] belong to no mask and are dropped,
- * exactly as the reference ignores them.                                                                      */
+ * masks and pi_bit).  A pair is a list of ENTRIES (ln concentration, response, weight), stored masked-group by
+ * masked-group: first the k_other entries with 0 < y < 100 (where_r_other), then the k_zero entries with y == 0
+ * (where_r_0), then the k_hundred entries with y == 100 (where_r_100); points outside [0,100] belong to no mask
+ * and are dropped, exactly as the reference ignores them.
+ * An entry stands for `weight` data points measured at the same concentration (the Crumb set repeats 4 doses
+ * over 3-6 experiments).  The likelihood sums of doseresponse.py:244-247 regroup exactly —
+ *     sum_j (y_j - pred)^2 = sum_j (y_j - ybar)^2 + w (ybar - pred)^2,      sum_j log Phi(z(pred)) = w log Phi(z(pred))
+ * — so an uncensored entry carries the MEAN response of its points, and extra[1] the theta-independent within-group
+ * sum of squares.  One entry per point (weight 1, extra[1] = 0) is equally valid; merging only saves arithmetic. */
 typedef struct phf_points {
   int32_t num_pairs;        /* P */
-  int32_t stride;           /* doubles per pair row in ln_conc/response (>= n_other+n_zero+n_hundred) */
+  int32_t stride;           /* doubles per pair row in ln_conc/response/weight (>= k_other+k_zero+k_hundred) */
   const double* ln_conc;    /* device [P][stride]  natural log of the dose in uM (-inf for dose 0) */
-  const double* response;   /* device [P][stride]  percent inhibition */
-  const int32_t* counts;    /* device [P][4]       n_other, n_zero, n_hundred, n_total (incl. dropped points) */
+  const double* response;   /* device [P][stride]  percent inhibition (mean over the entry's points) */
+  const double* weight;     /* device [P][stride]  number of data points the entry stands for */
+  const int32_t* counts;    /* device [P][4]       k_other, k_zero, k_hundred entries, n_total data rows (incl. dropped points) */
   const double* pi_bit;     /* device [P]          0.5*n_total*ln(2 pi), python/doseresponse.py:299-301 */
+  const double* extra;      /* device [P][2]       number of uncensored POINTS (sum of their weights; the n ln sigma term,
+                                                   doseresponse.py:246), within-group sum of squares of the merged points */
 } phf_points;
 
 /* The batch of independent Markov chains one call advances: Q problems x C chains.

@@ -15,7 +15,8 @@ def build():
 
 class Problem(C.Structure):
     _fields_ = [("model", C.c_int32), ("n_other", C.c_int32), ("n_zero", C.c_int32), ("n_hundred", C.c_int32),
-                ("ln_conc", C.c_void_p), ("response", C.c_void_p), ("pi_bit", C.c_double), ("temperature", C.c_double)]
+                ("ln_conc", C.c_void_p), ("response", C.c_void_p), ("weight", C.c_void_p), ("n_other_points", C.c_double),
+                ("ss_within", C.c_double), ("pi_bit", C.c_double), ("temperature", C.c_double)]
 
 
 class Run(C.Structure):
@@ -61,18 +62,44 @@ def gamma_table(n):
     return np.array([1.0 / (s + 1.0) ** 0.6 for s in range(n + 1)], dtype=np.float64)
 
 
-class PackedPair:
-    """One pair in the kernel's order: 'other' points, then y==0 points, then y==100 points."""
+def _merged(concs, y):
+    """replicates at one concentration -> (conc, mean, count) in first-appearance order, and the within-group sum of
+    squares; correctly rounded sums (math.fsum), so any implementation of this grouping gives the same doubles"""
+    import math
+    seen = []
+    for cv in concs:
+        if cv not in seen:
+            seen.append(cv)
+    cc, yy, ww, terms = [], [], [], []
+    for cv in seen:
+        v = [float(b) for a, b in zip(concs, y) if a == cv]
+        m = v[0] if len(v) == 1 else math.fsum(v) / len(v)
+        cc.append(float(cv)); yy.append(m); ww.append(float(len(v)))
+        if len(v) > 1:
+            terms += [(b - m) * (b - m) for b in v]
+    return cc, yy, ww, math.fsum(terms)
 
-    def __init__(self, concs, responses, model, temperature=1.0):
+
+class PackedPair:
+    """One pair in the kernel's order: 'other' entries, then y==0 entries, then y==100 entries (an entry = the points
+    of that kind at one concentration, see include/pyhillfit_amd.h); merge=False keeps one entry per point."""
+
+    def __init__(self, concs, responses, model, temperature=1.0, merge=True):
         concs = np.asarray(concs, float); y = np.asarray(responses, float)
         other = (0 < y) & (y < 100); zero = y == 0; hund = y == 100
-        order = np.concatenate([np.nonzero(other)[0], np.nonzero(zero)[0], np.nonzero(hund)[0]])
+        cc, yy, ww, ks, ss = [], [], [], [], 0.0
+        for mask in (other, zero, hund):
+            if merge:
+                a, b, w, s_ = _merged(list(concs[mask]), list(y[mask]))
+            else:
+                a, b, w, s_ = list(concs[mask]), list(y[mask]), [1.0] * int(mask.sum()), 0.0
+            cc += a; yy += b; ww += w; ks.append(len(a)); ss += s_
         with np.errstate(divide="ignore"):
-            self.ln_conc = np.ascontiguousarray(np.log(concs[order]))
-        self.response = np.ascontiguousarray(y[order])
-        self.pb = Problem(model, int(other.sum()), int(zero.sum()), int(hund.sum()), _p(self.ln_conc),
-                          _p(self.response), 0.5 * len(y) * np.log(2 * np.pi), float(temperature))
+            self.ln_conc = np.ascontiguousarray(np.log(np.array(cc, dtype=float)))
+        self.response = np.ascontiguousarray(np.array(yy, dtype=float))
+        self.weight = np.ascontiguousarray(np.array(ww, dtype=float))
+        self.pb = Problem(model, ks[0], ks[1], ks[2], _p(self.ln_conc), _p(self.response), _p(self.weight),
+                          float(other.sum()), ss, 0.5 * len(y) * np.log(2 * np.pi), float(temperature))
         self.d = 2 if model == 1 else 3
 
     def log_target(self, theta):

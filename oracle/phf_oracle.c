@@ -27,9 +27,12 @@
 
 typedef struct {
   int32_t model;                        /* 1: (pIC50, sigma), Hill = 1;  2: (pIC50, Hill, sigma) */
-  int32_t n_other, n_zero, n_hundred;   /* points are stored in that order */
+  int32_t n_other, n_zero, n_hundred;   /* entries are stored in that order */
   const double* ln_conc;                /* natural log of the dose */
-  const double* response;
+  const double* response;               /* (mean) response of the entry's points */
+  const double* weight;                 /* number of points the entry stands for */
+  double n_other_points;                /* sum of the weights of the uncensored entries */
+  double ss_within;                     /* within-entry sum of squares of merged replicate points */
   double pi_bit;                        /* doseresponse.py:299-301 */
   double temperature;
 } phfo_problem;
@@ -46,8 +49,8 @@ typedef struct {
 
 /* ---------------------------------------------------------------- model library (shared source: phf_model.h) */
 static void target_parts(const phfo_problem* pb, const double* th, double* lik, double* prior, double* ll1) {
-  phf_sl_log_target(pb->model, pb->ln_conc, pb->response, pb->n_other, pb->n_zero + pb->n_hundred, pb->pi_bit,
-                    pb->temperature, th, phf_k_exp, phf_k_log, lik, prior, ll1);
+  phf_sl_log_target(pb->model, pb->ln_conc, pb->response, pb->weight, pb->n_other, pb->n_zero + pb->n_hundred,
+                    pb->n_other_points, pb->ss_within, pb->pi_bit, pb->temperature, th, phf_k_exp, phf_k_log, lik, prior, ll1);
 }
 
 double phfo_log_prior(const phfo_problem* pb, const double* th) { double l, p, a; target_parts(pb, th, &l, &p, &a); return p; }

@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpyhillfit_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/pyhillfit_amd.h declares
 EXPORTS = ["phf_version", "phf_last_error", "phf_single_level_state_size", "phf_single_level_init",
@@ -21,7 +21,7 @@ class PhfError(RuntimeError):
 
 class Points(C.Structure):
     _fields_ = [("num_pairs", C.c_int32), ("stride", C.c_int32), ("ln_conc", C.c_void_p), ("response", C.c_void_p),
-                ("counts", C.c_void_p), ("pi_bit", C.c_void_p)]
+                ("weight", C.c_void_p), ("counts", C.c_void_p), ("pi_bit", C.c_void_p), ("extra", C.c_void_p)]
 
 
 class Problems(C.Structure):

@@ -10,8 +10,14 @@
  * group — 1/(1+x) of the Hill curve, the erfcx and log reciprocals — are shared through a product tree
  * (one division + a few multiplies instead of one division each; ~26 ns vs ~2 ns per wave-instruction).
  *
- * Point layout (include/pyhillfit_amd.h, phf_points): n_other uncensored points first (0 < y < 100), then the
+ * Entry layout (include/pyhillfit_amd.h, phf_points): n_other uncensored entries first (0 < y < 100), then the
  * n_cens censored ones (y == 0, then y == 100).  Arrays must be readable up to index n_other + n_cens - 1.
+ * An entry stands for w data points at one concentration.  The reference's sums over points (:244-247) regroup
+ * exactly: the curve depends on the point only through its concentration, so for replicates at one concentration
+ *     sum_j (y_j - pred)^2 = sum_j (y_j - ybar)^2 + w (ybar - pred)^2      (uncensored; first term constant in theta)
+ *     sum_j log Phi(z(pred)) = w log Phi(z(pred))                            (censored)
+ * and the per-iteration cost scales with the number of distinct concentrations (Crumb: 4 doses x 3-6 experiments).
+ * w = 1, ybar = y, ss_within = 0 is the unmerged form.
  */
 #ifndef PHF_MODEL_H
 #define PHF_MODEL_H
@@ -47,8 +53,9 @@ PHF_HD double phf_censored_z(double pred, double y, double inv_s) {
  * model 1: th = (pIC50, sigma), Hill = 1;  model 2: th = (pIC50, Hill, sigma).
  * out_ll1 = log_data_likelihood(..., t = 1): what python/compute_bayes_factors.py:18-21 re-evaluates for every saved
  * sample of every rung; it falls out of the same arithmetic here, so the samplers carry it along for free.      */
-PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int n_other, int n_cens,
-                              double pi_bit, double temperature, const double* th, phf_ktab k_exp, phf_ktab k_log,
+PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, const double* w, int n_other, int n_cens,
+                              double n_other_points, double ss_within, double pi_bit, double temperature,
+                              const double* th, phf_ktab k_exp, phf_ktab k_log,
                               double* out_lik, double* out_prior, double* out_ll1) {
   const double pic50 = th[0];
   const double hill = (model == 1) ? 1.0 : th[1];
@@ -65,9 +72,9 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
   const double log_sigma = phf_log_finish_k(lr_s, lr_s.f * (i1 * sigma), k_log);
   const double log_sl = phf_log_finish_k(lr_l, lr_l.f * (inv3 * p1), k_log);
 
-  double sse = 0.0, cens = 0.0;
+  double sse = ss_within, cens = 0.0;
   int j = 0;
-  for (; j + 4 <= n_other; j += 4) {              /* uncensored points, four at a time (:247) */
+  for (; j + 4 <= n_other; j += 4) {              /* uncensored entries, four at a time (:247) */
     const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke, 0), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50, ke, 0);
@@ -76,14 +83,33 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
     const double i01 = inv * p23, i23 = inv * p01;
     const double r0 = y[j] - phf_hill_percent(i01 * d1), r1 = y[j + 1] - phf_hill_percent(i01 * d0);
     const double r2 = y[j + 2] - phf_hill_percent(i23 * d3), r3 = y[j + 3] - phf_hill_percent(i23 * d2);
-    sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse); sse = phf_fma(r2, r2, sse); sse = phf_fma(r3, r3, sse);
+    sse = phf_fma(w[j] * r0, r0, sse); sse = phf_fma(w[j + 1] * r1, r1, sse);
+    sse = phf_fma(w[j + 2] * r2, r2, sse); sse = phf_fma(w[j + 3] * r3, r3, sse);
   }
-  for (; j < n_other; ++j) {
+  const int rem = n_other - j;                    /* 0..3 left: still one division */
+  if (rem == 3) {
+    const phf_ktab ke = k_exp;
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
+    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke, 0);
+    const double p01 = d0 * d1;
+    const double inv = 1.0 / (p01 * d2);
+    const double i01 = inv * d2;
+    const double r0 = y[j] - phf_hill_percent(i01 * d1), r1 = y[j + 1] - phf_hill_percent(i01 * d0);
+    const double r2 = y[j + 2] - phf_hill_percent(inv * p01);
+    sse = phf_fma(w[j] * r0, r0, sse); sse = phf_fma(w[j + 1] * r1, r1, sse); sse = phf_fma(w[j + 2] * r2, r2, sse);
+  } else if (rem == 2) {
+    const phf_ktab ke = k_exp;
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
+    const double inv = 1.0 / (d0 * d1);
+    const double r0 = y[j] - phf_hill_percent(inv * d1), r1 = y[j + 1] - phf_hill_percent(inv * d0);
+    sse = phf_fma(w[j] * r0, r0, sse); sse = phf_fma(w[j + 1] * r1, r1, sse);
+  } else if (rem == 1) {
     const double r = y[j] - phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1));
-    sse = phf_fma(r, r, sse);
+    sse = phf_fma(w[j] * r, r, sse);
   }
+  j = n_other;
   const int n = n_other + n_cens;
-  for (; j + 2 <= n; j += 2) {                    /* censored points, two at a time (:244-245) */
+  for (; j + 2 <= n; j += 2) {                    /* censored entries, two at a time (:244-245) */
     PHF_KFETCH(k_erfcx, phf_k_erfcx, 24);         /* issued now, needed after the two exponentials */
     const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
@@ -92,15 +118,15 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, int 
     const double z1 = phf_censored_z(phf_hill_percent(inv * d0), y[j + 1], inv_s);
     double l0, l1;
     phf_log_ndtr_nonpos_x2_k(z0, z1, &l0, &l1, k_erfcx, k_log);
-    cens += l0; cens += l1;
+    cens = phf_fma(w[j], l0, cens); cens = phf_fma(w[j + 1], l1, cens);
   }
   for (; j < n; ++j) {
     PHF_KFETCH(k_erfcx, phf_k_erfcx, 24);
     const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1));
-    cens += phf_log_ndtr_nonpos_k(phf_censored_z(pred, y[j], inv_s), k_erfcx, k_log);
+    cens = phf_fma(w[j], phf_log_ndtr_nonpos_k(phf_censored_z(pred, y[j], inv_s), k_erfcx, k_log), cens);
   }
   double a = cens - pi_bit;
-  a = phf_fma(-(double)n_other, log_sigma, a);                           /* :246 */
+  a = phf_fma(-n_other_points, log_sigma, a);                            /* :246 */
   a = phf_fma(-sse, 0.5 * inv_s * inv_s, a);                             /* :247 */
   double lik = temperature * a;                                          /* :248 */
   if (sigma <= PHF_SIGMA_FLOOR) { lik = -PHF_INF; a = -PHF_INF; }        /* :238-240 */

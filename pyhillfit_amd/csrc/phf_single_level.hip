@@ -58,7 +58,7 @@ struct AdvanceArgs {
   int32_t blocks_per_problem;
 };
 
-// stage one pair's points into LDS (lc = s_pts, y = s_pts + stride); returns counts
+// stage one pair's entries into LDS (lc = s_pts, y = s_pts + stride, w = s_pts + 2 stride); returns counts
 __device__ __forceinline__ void stage_points(const phf_points& pts, int pair, double* s_pts, int& n_other,
                                              int& n_zero, int& n_hundred) {
   const int32_t* cnt = pts.counts + 4 * pair;
@@ -67,6 +67,7 @@ __device__ __forceinline__ void stage_points(const phf_points& pts, int pair, do
   for (int j = threadIdx.x; j < n; j += kBlock) {
     s_pts[j] = pts.ln_conc[(size_t)pair * pts.stride + j];
     s_pts[pts.stride + j] = pts.response[(size_t)pair * pts.stride + j];
+    s_pts[2 * pts.stride + j] = pts.weight[(size_t)pair * pts.stride + j];
   }
   __syncthreads();
 }
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
   const int n_cens = n_zero + n_hundred;
   const double* lc = s_pts;
   const double* yv = s_pts + a.pts.stride;
+  const double* wv = s_pts + 2 * a.pts.stride;
   const double pi_bit = a.pts.pi_bit[pair];
+  const double n_other_points = a.pts.extra[2 * pair], ss_within = a.pts.extra[2 * pair + 1];
   const double temperature = a.prob.temperature[q];
   const uint32_t pid = a.prob.problem_id[q];
   const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void mh_advance_kernel(const AdvanceArgs a)
     }
     // ---- target and accept test (PyHillFit.py:833-838) ----
     double lik_star, prior_star, ll1_star;
-    phf_sl_log_target(MODEL, lc, yv, n_other, n_cens, pi_bit, temperature, star, k_exp, k_log, &lik_star, &prior_star, &ll1_star);
+    phf_sl_log_target(MODEL, lc, yv, wv, n_other, n_cens, n_other_points, ss_within, pi_bit, temperature, star, k_exp, k_log, &lik_star, &prior_star, &ll1_star);
     const double lt_star = lik_star + prior_star;
     const bool acc = log_u < lt_star - lt;
     if (acc) {
@@ -250,7 +253,8 @@ __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
   double lik0, prior0, ll10;
   PHF_KFETCH_V(k_exp, phf_k_exp, 10);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
-  phf_sl_log_target(MODEL, s_pts, s_pts + a.pts.stride, n_other, n_zero + n_hundred, a.pts.pi_bit[pair], a.prob.temperature[q],
+  phf_sl_log_target(MODEL, s_pts, s_pts + a.pts.stride, s_pts + 2 * a.pts.stride, n_other, n_zero + n_hundred,
+                    a.pts.extra[2 * pair], a.pts.extra[2 * pair + 1], a.pts.pi_bit[pair], a.prob.temperature[q],
                     th, k_exp, k_log, &lik0, &prior0, &ll10);
   const double lt = lik0 + prior0;
   double* sp = a.state + g;
@@ -289,8 +293,9 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
   double lik, prior, ll1;
   PHF_KFETCH_V(k_exp, phf_k_exp, 10);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
-  phf_sl_log_target(MODEL, pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride, cnt[0],
-                    cnt[1] + cnt[2], pts.pi_bit[pair], temperature[i], th, k_exp, k_log, &lik, &prior, &ll1);
+  phf_sl_log_target(MODEL, pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride,
+                    pts.weight + (size_t)pair * pts.stride, cnt[0], cnt[1] + cnt[2], pts.extra[2 * pair], pts.extra[2 * pair + 1],
+                    pts.pi_bit[pair], temperature[i], th, k_exp, k_log, &lik, &prior, &ll1);
   if (out_lik) out_lik[i] = lik;
   if (out_prior) out_prior[i] = prior;
 }
@@ -328,11 +333,11 @@ __global__ void debug_philox_kernel(int64_t n, const uint32_t* ck, uint32_t* out
 int check_common(const phf_points* pts, const phf_problems* prob, int model) {
   if (!pts || !prob) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null points/problems");
   if (model != 1 && model != 2) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "model must be 1 or 2");
-  if (pts->num_pairs <= 0 || pts->stride <= 0 || !pts->ln_conc || !pts->response || !pts->counts || !pts->pi_bit)
+  if (pts->num_pairs <= 0 || pts->stride <= 0 || !pts->ln_conc || !pts->response || !pts->weight || !pts->counts || !pts->pi_bit || !pts->extra)
     return phf_fail(PHF_ERR_INVALID_ARGUMENT, "incomplete phf_points");
   if (prob->num_problems <= 0 || prob->chains_per_problem <= 0 || !prob->pair_index || !prob->temperature || !prob->problem_id)
     return phf_fail(PHF_ERR_INVALID_ARGUMENT, "incomplete phf_problems");
-  if ((size_t)pts->stride * 16 > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "pair does not fit in LDS");
+  if ((size_t)pts->stride * 24 > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "pair does not fit in LDS");
   const int64_t bpp = (prob->chains_per_problem + kBlock - 1) / kBlock;
   if (bpp * prob->num_problems > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
   return PHF_OK;
@@ -357,7 +362,7 @@ int phf_single_level_init(const phf_points* pts, const phf_problems* prob, int m
   InitArgs a{*pts, *prob, cov_identity, cov_scale, theta0, state, row0, 0};
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
   const dim3 grid((unsigned)(a.blocks_per_problem * prob->num_problems)), block(kBlock);
-  const size_t lds = (size_t)pts->stride * 16;
+  const size_t lds = (size_t)pts->stride * 24;
   if (model == 1) hipLaunchKernelGGL(mh_init_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(mh_init_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
   return phf_check_launch("phf_single_level_init");
@@ -376,7 +381,7 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
   AdvanceArgs a{*pts, *prob, *cfg, t_begin, t_end, state, rows, moments, moments_after, 0};
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
   const dim3 grid((unsigned)(a.blocks_per_problem * prob->num_problems)), block(kBlock);
-  const size_t lds = (size_t)pts->stride * 16;
+  const size_t lds = (size_t)pts->stride * 24;
   if (cfg->model == 1) {
     if (moments) hipLaunchKernelGGL((mh_advance_kernel<1, true>), grid, block, lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((mh_advance_kernel<1, false>), grid, block, lds, (hipStream_t)stream, a);

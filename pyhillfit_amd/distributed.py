@@ -57,7 +57,7 @@ def shard_chains(num_chains, rank, world):
 
 def broadcast_packed_points(packed, device, src=0):
     """Rank `src` holds a doseresponse.PackedPoints; everybody returns an identical copy.
-    (the 'scatter the dataset' step: 4 small tensors, one broadcast each)"""
+    (the 'scatter the dataset' step: 6 small tensors, one broadcast each)"""
     import torch
     import torch.distributed as dist
     from .doseresponse import PackedPoints
@@ -72,15 +72,17 @@ def broadcast_packed_points(packed, device, src=0):
     P, stride = int(shape[0]), int(shape[1])
     if rank == src:
         bufs = [torch.from_numpy(packed.ln_conc).to(dev), torch.from_numpy(packed.response).to(dev),
-                torch.from_numpy(packed.counts).to(dev), torch.from_numpy(packed.pi_bit).to(dev)]
+                torch.from_numpy(packed.weight).to(dev), torch.from_numpy(packed.counts).to(dev),
+                torch.from_numpy(packed.pi_bit).to(dev), torch.from_numpy(packed.extra).to(dev)]
     else:
-        bufs = [torch.empty((P, stride), dtype=torch.float64, device=dev), torch.empty((P, stride), dtype=torch.float64, device=dev),
-                torch.empty((P, 4), dtype=torch.int32, device=dev), torch.empty(P, dtype=torch.float64, device=dev)]
+        f64 = dict(dtype=torch.float64, device=dev)
+        bufs = [torch.empty((P, stride), **f64), torch.empty((P, stride), **f64), torch.empty((P, stride), **f64),
+                torch.empty((P, 4), dtype=torch.int32, device=dev), torch.empty(P, **f64), torch.empty((P, 2), **f64)]
     for b in bufs:
         dist.broadcast(b, src)
     out = PackedPoints.__new__(PackedPoints)
     out.num_pairs, out.stride = P, stride
-    out.ln_conc, out.response, out.counts, out.pi_bit = [b.cpu().numpy() for b in bufs]
+    out.ln_conc, out.response, out.weight, out.counts, out.pi_bit, out.extra = [b.cpu().numpy() for b in bufs]
     return out
 
 

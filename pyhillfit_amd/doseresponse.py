@@ -196,11 +196,33 @@ def define_model(model):
 
 
 # ---- packing for the kernels ----------------------------------------------------------------------------------
+def merge_replicates(concs, y):
+    """Entries of one masked group: the points that share a concentration (exact equality, first-appearance order)
+    become (conc, mean response, count); also returns sum over groups of sum_j (y_j - mean)^2, the part of the sum of
+    squares that does not depend on the curve (see include/pyhillfit_amd.h, phf_points).  Correctly rounded (fsum)."""
+    import math
+    groups, order = {}, []
+    for cval, yval in zip(concs, y):
+        k = float(cval)
+        if k not in groups:
+            groups[k] = []; order.append(k)
+        groups[k].append(float(yval))
+    cc, yy, ww, within = [], [], [], []
+    for k in order:
+        v = groups[k]
+        m = v[0] if len(v) == 1 else math.fsum(v) / len(v)
+        cc.append(k); yy.append(m); ww.append(float(len(v)))
+        if len(v) > 1:
+            within.extend((a - m) * (a - m) for a in v)
+    return np.array(cc), np.array(yy), np.array(ww), math.fsum(within)
+
+
 class PackedPoints(object):
     """numpy image of include/pyhillfit_amd.h `phf_points` for a list of pairs."""
 
-    def __init__(self, pairs):
-        """pairs: list of (concs, responses) arrays, one per (drug, channel) pair, file order."""
+    def __init__(self, pairs, merge=True):
+        """pairs: list of (concs, responses) arrays, one per (drug, channel) pair, file order.
+        merge: replicate points at one concentration become one weighted entry (same likelihood, less arithmetic)."""
         self.num_pairs = len(pairs)
         groups = []
         for concs, y in pairs:
@@ -208,28 +230,40 @@ class PackedPoints(object):
             if concs.shape != y.shape:
                 raise ValueError("concs/responses length mismatch")
             is0, is100, other = response_masks(y)
-            order = np.concatenate([np.nonzero(other)[0], np.nonzero(is0)[0], np.nonzero(is100)[0]])
-            groups.append((concs[order], y[order], int(other.sum()), int(is0.sum()), int(is100.sum()), len(y)))
+            parts, ss_within = [], 0.0
+            for mask in (other, is0, is100):
+                if merge:
+                    cc, yy, ww, ss = merge_replicates(concs[mask], y[mask])
+                    ss_within += ss
+                else:
+                    cc, yy, ww = concs[mask], y[mask], np.ones(int(mask.sum()))
+                parts.append((cc, yy, ww))
+            groups.append((np.concatenate([p_[0] for p_ in parts]), np.concatenate([p_[1] for p_ in parts]),
+                           np.concatenate([p_[2] for p_ in parts]), [len(p_[0]) for p_ in parts], int(other.sum()), ss_within, len(y)))
         self.stride = max(1, max(len(g[0]) for g in groups))
         self.ln_conc = np.zeros((self.num_pairs, self.stride))
         self.response = np.zeros((self.num_pairs, self.stride))
+        self.weight = np.zeros((self.num_pairs, self.stride))
         self.counts = np.zeros((self.num_pairs, 4), dtype=np.int32)
         self.pi_bit = np.zeros(self.num_pairs)
-        for p, (cc, yy, n_other, n0, n100, ntot) in enumerate(groups):
+        self.extra = np.zeros((self.num_pairs, 2))
+        for p, (cc, yy, ww, ks, n_other_points, ss_within, ntot) in enumerate(groups):
             with np.errstate(divide="ignore"):
                 self.ln_conc[p, :len(cc)] = np.log(cc)
             self.response[p, :len(yy)] = yy
-            self.counts[p] = (n_other, n0, n100, ntot)
+            self.weight[p, :len(ww)] = ww
+            self.counts[p] = (ks[0], ks[1], ks[2], ntot)
             self.pi_bit[p] = 0.5 * ntot * np.log(2 * np.pi)
+            self.extra[p] = (float(n_other_points), ss_within)
 
 
-def pack_single_level(drug_channel_pairs):
+def pack_single_level(drug_channel_pairs, merge=True):
     """[(drug, channel), ...] of the loaded table -> PackedPoints (PyHillFit.py:654-683 per pair)."""
     out = []
     for drug, channel in drug_channel_pairs:
         num_expts, _, experiments = load_crumb_data(drug, channel)
         out.append(concatenate_experiments(num_expts, experiments))
-    return PackedPoints(out)
+    return PackedPoints(out, merge=merge)
 
 
 # ---- GPU-evaluated model functions with the reference's signatures ---------------------------------------------

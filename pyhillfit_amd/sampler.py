@@ -43,10 +43,12 @@ class DevicePoints(object):
         self.device = torch.device(device)
         self.ln_conc = torch.from_numpy(packed.ln_conc).to(self.device)
         self.response = torch.from_numpy(packed.response).to(self.device)
+        self.weight = torch.from_numpy(packed.weight).to(self.device)
         self.counts = torch.from_numpy(packed.counts).to(self.device)
         self.pi_bit = torch.from_numpy(packed.pi_bit).to(self.device)
+        self.extra = torch.from_numpy(packed.extra).to(self.device)
         self.struct = _lib.Points(packed.num_pairs, packed.stride, self.ln_conc.data_ptr(), self.response.data_ptr(),
-                                  self.counts.data_ptr(), self.pi_bit.data_ptr())
+                                  self.weight.data_ptr(), self.counts.data_ptr(), self.pi_bit.data_ptr(), self.extra.data_ptr())
 
 
 def log_target_batch(packed, model, pair_index, temperature, theta, device="cuda"):

@@ -43,8 +43,8 @@ def test_csv_round_trip(dr, tmp_path):
 
 def test_packing_groups_points_like_the_masks(dr, g4_pairs):
     names = list(g4_pairs)
-    pk = dr.pack_single_level(names)
-    assert pk.num_pairs == 210 and pk.stride == 20
+    pk = dr.pack_single_level(names, merge=False)          # one entry per point
+    assert pk.num_pairs == 210 and pk.stride == 20 and np.all(pk.weight[pk.weight != 0] == 1) and np.all(pk.extra[:, 1] == 0)
     for p, key in enumerate(names):
         g = g4_pairs[key]
         n_other, n0, n100, ntot = pk.counts[p]
@@ -57,6 +57,34 @@ def test_packing_groups_points_like_the_masks(dr, g4_pairs):
     # the -2.6 response (crumb_data.csv:155) is in no mask: dropped from the points, still counted in pi_bit
     p = names.index(("Amitriptyline", "Kv4.3"))
     assert pk.counts[p].tolist() == [17, 1, 0, 19]
+    assert pk.extra[p, 0] == 17
+
+
+def test_merged_entries_carry_the_same_likelihood_sums(dr, g4_pairs):
+    """replicates at one concentration become one weighted entry: counts, weighted residual sums and the censored
+    multiplicities of every Crumb pair are those of the point-by-point sums (doseresponse.py:244-247)"""
+    names = list(g4_pairs)
+    pk = dr.pack_single_level(names)
+    assert pk.stride < 20 and pk.counts[:, :3].sum() < 0.5 * sum(g4_pairs[k]["n_other"] + g4_pairs[k]["n0"] + g4_pairs[k]["n100"] for k in names)
+    rng = np.random.RandomState(0)
+    for p, key in enumerate(names):
+        g = g4_pairs[key]
+        k_other, k0, k100, ntot = pk.counts[p]
+        y = np.array(g["responses"]); c = np.array(g["concs"])
+        other = (y > 0) & (y < 100)
+        assert pk.extra[p, 0] == g["n_other"] == pk.weight[p, :k_other].sum()
+        assert pk.weight[p, k_other:k_other + k0].sum() == g["n0"] and pk.weight[p, k_other + k0:k_other + k0 + k100].sum() == g["n100"]
+        assert np.all(pk.response[p, k_other:k_other + k0] == 0) and np.all(pk.response[p, k_other + k0:k_other + k0 + k100] == 100)
+        lc = pk.ln_conc[p, :k_other]
+        assert len(set(lc)) == k_other == len(set(c[other]))
+        # any curve that depends on the point through its concentration only
+        f = lambda lnc: 50 + 30 * np.sin(lnc * rng_a + rng_b)
+        rng_a, rng_b = rng.uniform(0.5, 2), rng.uniform(0, 6)
+        want = np.sum((y[other] - f(np.log(c[other]))) ** 2)
+        got = pk.extra[p, 1] + np.sum(pk.weight[p, :k_other] * (pk.response[p, :k_other] - f(lc)) ** 2)
+        assert got == pytest.approx(want, rel=1e-13, abs=1e-10)
+    p = names.index(("Amiodarone", "hERG"))                  # 3 doses x 3 uncensored + 1 dose x 3 zeros
+    assert pk.counts[p].tolist() == [3, 1, 0, 12] and pk.weight[p, :4].tolist() == [3, 3, 3, 3]
 
 
 def test_zero_dose_and_empty_groups():
