@@ -49,7 +49,8 @@ def _worker(rank, world, port, q):
     # stand-in for per-problem summaries computed on this rank's shard
     local = torch.tensor(np.column_stack([mine, got.pi_bit[mine]]), dtype=torch.float64)
     rows = pd.gather_rows(local, dst=0)
-    q.put((rank, got.num_pairs, got.stride, float(got.ln_conc.sum()), int(got.counts.sum()), None if rows is None else [r_.tolist() for r_ in rows]))
+    q.put((rank, got.num_pairs, got.stride, float(got.ln_conc.sum()) + float(got.weight.sum()) + float(got.extra.sum()), int(got.counts.sum()),
+           None if rows is None else [r_.tolist() for r_ in rows], float(got.weight.sum()), float(got.extra[:, 0].sum())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,7 +65,8 @@ def test_broadcast_and_gather_world_size_2():
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(60); assert p.exitcode == 0
-    assert res[0][1:5] == res[1][1:5] and res[0][1] == 210 and res[0][2] == 20       # identical data set on both ranks
+    assert res[0][1:5] == res[1][1:5] and res[0][1] == 210 and res[0][2] == 8        # identical data set on both ranks (<= 8 entries per pair)
+    assert res[0][6:] == res[1][6:] and res[1][6] == 2584 and res[1][7] == 1805      # weights = points inside [0,100]; uncensored points
     rows = res[0][5]
     assert res[1][5] is None and len(rows) == 2
     ids = np.sort(np.concatenate([np.array(r_)[:, 0] for r_ in rows]))
