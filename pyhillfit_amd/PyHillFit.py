@@ -91,17 +91,20 @@ def run_single_level(pairs, args, device, rank=0, world=1):
     import torch
     from .sampler import SingleLevelSampler
     model, temperature = args.model, 1                                 # PyHillFit.py:57
+    t_begin = time.time()
     loaded = load_single_level_pairs(pairs)
     if not loaded:
         return []
     # ---- start points + best-fit files (PyHillFit.py:699-746) ----
+    writers = chainio.WriterPool(args.write_workers)                   # one pool for the start-point fits and the file formatting
+    fits = writers.map(bestfit.best_fit, [(concs, responses, model) for _, _, concs, responses in loaded])
     theta0, files = [], []
-    for drug, channel, concs, responses in loaded:
-        th0, ss = bestfit.best_fit(concs, responses, model)
+    for (drug, channel, concs, responses), (th0, ss) in zip(loaded, fits):
         d_clean, c_clean, chain_file, images_dir = dr.nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature)
         chainio.save_best_fit_params(images_dir + "{}_{}_best_fit_params.txt".format(d_clean, c_clean), th0, model)
         theta0.append(th0); files.append((d_clean, c_clean, chain_file))
     if args.best_fit_only:
+        writers.close()
         return []
     total_iterations, thinning = args.iterations, args.thinning
     assert total_iterations % thinning == 0                            # PyHillFit.py:805
@@ -116,7 +119,6 @@ def run_single_level(pairs, args, device, rank=0, world=1):
     s.enable_moments(after_iteration=max(burn * thinning - 1, 0))      # moments over exactly the rows that are written
     s.reserve(total_iterations)
     keep_all = args.save_all_chains
-    writers = chainio.WriterPool(args.write_workers)                   # started now: the processes boot while the GPU samples
     d = s.d
     kept = torch.empty((saved_iterations, Q, d + 1, C if keep_all else 1), dtype=torch.float64,
                        device=device if keep_all else "cpu")
@@ -124,6 +126,7 @@ def run_single_level(pairs, args, device, rank=0, world=1):
     seg = max(thinning, args.segment - args.segment % thinning)
     buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
     done, r = 0, 1
+    torch.cuda.synchronize(device)
     start = time.time()
     while done < total_iterations:
         k = min(seg, total_iterations - done)
@@ -155,6 +158,8 @@ def run_single_level(pairs, args, device, rank=0, world=1):
         summaries.append(summ)
         print("\n\n{} + {} complete!\n\n".format(d_clean, c_clean))      # PyHillFit.py:970
     writers.close()
+    print("timing [rank {}]: data + start points {:.1f} s, sampling {:.1f} s ({} chains x {} iterations), chain files {:.1f} s".format(
+        rank, start - t_begin, elapsed, Q * C, total_iterations, time.time() - start - elapsed))
     return summaries
 
 

@@ -4,6 +4,7 @@ downstream readers (np.loadtxt with usecols, last column = log-target) work unch
 import multiprocessing as mp
 import os
 from concurrent.futures import ProcessPoolExecutor
+from concurrent.futures.process import BrokenProcessPool
 
 import numpy as np
 
@@ -11,24 +12,49 @@ import numpy as np
 class WriterPool(object):
     """np.savetxt at '%.18e' formats ~60 MB of text per second and core, which is the bottleneck once sampling takes
     seconds (7.5 MB of text per single-level chain, 10-14 MB per hierarchical one, 630 files for the
-    three -a runs).  Files are therefore written by `workers` processes that are SPAWNED (fresh interpreters: the
-    parent has initialised HIP, a forked copy of it must not exist) and never import torch; arrays travel pickled.
-    workers <= 0 writes synchronously in the caller.  close() waits and re-raises the first failure."""
+    three -a runs).  Files are therefore written — and the start-point fits run — by `workers` processes that are
+    SPAWNED (fresh interpreters: the parent has initialised HIP, a forked copy of it must not exist) and never import
+    torch; arrays travel pickled.  workers <= 0 works synchronously in the caller, and so does a pool whose processes
+    cannot start (spawn re-imports the main script, which an interactive session does not have): every job is a pure
+    function of its arguments, so it is simply redone here.  close() waits and re-raises the first failure."""
 
     def __init__(self, workers):
         self.pool = ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) if workers > 0 else None
         self.pending = []
 
+    def _broken(self):
+        print("chainio.WriterPool: worker processes unavailable, continuing in the main process")
+        self.pool.shutdown(wait=False)
+        self.pool = None
+
     def submit(self, fn, *args):
-        if self.pool is None:
-            fn(*args)
-        else:
-            self.pending.append(self.pool.submit(fn, *args))
+        if self.pool is not None:
+            try:
+                self.pending.append((self.pool.submit(fn, *args), fn, args))
+                return
+            except BrokenProcessPool:
+                self._broken()
+        fn(*args)
+
+    def map(self, fn, arg_tuples):
+        """[fn(*args) for args in arg_tuples], spread over the workers (the start-point fits: pure numpy/scipy functions)"""
+        arg_tuples = list(arg_tuples)
+        if self.pool is not None and len(arg_tuples) > 1:
+            try:
+                return [f.result() for f in [self.pool.submit(fn, *a) for a in arg_tuples]]
+            except BrokenProcessPool:
+                self._broken()
+        return [fn(*a) for a in arg_tuples]
 
     def close(self):
         try:
-            for f in self.pending:
-                f.result()
+            for k, (f, fn, args) in enumerate(self.pending):
+                try:
+                    f.result()
+                except BrokenProcessPool:
+                    if self.pool is not None:
+                        self._broken()
+                    fn(*args)
         finally:
             self.pending = []
             if self.pool is not None:

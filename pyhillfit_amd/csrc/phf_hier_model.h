@@ -43,6 +43,7 @@ typedef struct phf_hier_prior {   /* Gamma hyper-priors of (alpha, beta, mu, s, 
  * n must be a compile-time constant at the call site (fully unrolled, static register indices).                 */
 PHF_HD void phf_batch_recip(double* v, int n) {
   double pre[PHF_MAX_BATCH];
+  if (n <= 0) return;
   pre[0] = v[0];
   PHF_UNROLL
   for (int i = 1; i < n; ++i) pre[i] = pre[i - 1] * v[i];

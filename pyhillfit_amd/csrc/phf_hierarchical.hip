@@ -396,17 +396,26 @@ int check(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_p
   return PHF_OK;
 }
 
+constexpr int kMaxDevices = 64;
+
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  return (dev >= 0 && dev < kMaxDevices) ? dev : 0;
+}
+
 template <int NE>
 int launch_advance(const HierArgs& a, hipStream_t stream) {
   const size_t lds = Lds<NE>::bytes(a.pts.stride);
   if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
-  static bool configured = false;
-  if (!configured) {
+  static bool configured[kMaxDevices] = {};                      // the attribute is per function AND per device
+  const int dev = current_device();
+  if (!configured[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_advance_kernel<NE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
       (void)hipGetLastError();
     }
-    configured = true;
+    configured[dev] = true;
   }
   const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
   hipLaunchKernelGGL(hier_advance_kernel<NE>, grid, block, lds, stream, a);
@@ -436,13 +445,14 @@ int launch_generic_advance(HierArgs a, hipStream_t stream) {
   const int D = 5 + 2 * a.pts.n_expts;
   const size_t lds = (size_t)3 * D * kGenBlock * 8;
   if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "dimension too large for the generic hierarchical kernel");
-  static bool configured = false;
-  if (!configured) {
+  static bool configured[kMaxDevices] = {};
+  const int dev = current_device();
+  if (!configured[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_generic_advance_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
       (void)hipGetLastError();
     }
-    configured = true;
+    configured[dev] = true;
   }
   a.blocks_per_problem = (a.prob.chains_per_problem + kGenBlock - 1) / kGenBlock;
   hipLaunchKernelGGL(hier_generic_advance_kernel, dim3((unsigned)(a.blocks_per_problem * a.prob.num_problems)), dim3(kGenBlock), lds, stream, a);

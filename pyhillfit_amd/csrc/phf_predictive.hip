@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void pred_partial_kernel(const PredArgs a
       const int64_t m = m0 + i;
       const int64_t r = m / a.chains_used;
       const int c = (int)(m - r * a.chains_used);
-      const double* p = a.rows + ((size_t)(r * a.num_problems + q) * a.row_stride) * col + c;
+      const double* p = a.rows + (((size_t)r * a.num_problems + q) * a.row_stride) * col + c;
       phf_pred_prepare(p[0], p[col], p[2 * col], p[3 * col], &s_par[0][i], &s_par[1][i], &s_par[2][i], &s_par[3][i]);
     }
     __syncthreads();
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kThreads) void pred_partial_kernel(const PredArgs a
   PHF_UNROLL
   for (int j = 0; j < 2; ++j) {
     if (g[j] >= a.grid_points) continue;
-    double* out = a.partial + ((size_t)(q * a.num_chunks + chunk) * PHF_PRED_CURVES) * a.grid_points + g[j];
+    double* out = a.partial + (((size_t)q * a.num_chunks + chunk) * PHF_PRED_CURVES) * a.grid_points + g[j];
     PHF_UNROLL
     for (int f = 0; f < PHF_PRED_CURVES; ++f) out[(size_t)f * a.grid_points] = acc[j][f];
   }

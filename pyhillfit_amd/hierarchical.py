@@ -10,8 +10,6 @@ import time
 
 import numpy as np
 import torch
-from scipy.optimize import minimize
-import scipy.stats as st
 
 from . import _lib, bestfit, chainio
 from . import doseresponse as dr
@@ -207,46 +205,8 @@ class HierarchicalSampler(object):
         return mean, (s2 - s1 * mean) / max(n - 1, 1), n
 
 
-# ---- start point (replaces the CMA-ES / scipy fits of PyHillFit.py:243-257,310-336) ----------------------------------
-def first_iteration(experiments, locs):
-    """theta0 = [alpha, beta, mu, s, pIC50_1, Hill_1, ..., sigma] as the reference builds it (:336), with
-    deterministic least-squares / maximum-likelihood fits instead of CMA-ES."""
-    best_fits = []
-    for ex in experiments:                                           # :243-257  per-experiment (pIC50, Hill) fit
-        th, ss = _fit_pic50_hill(ex[:, 0], ex[:, 1])
-        best_fits.append([th[0], th[1], np.sqrt(ss / len(ex))])      # initial_sigma, :101-102,255
-    best_fits = np.array(best_fits)
-    sigma_cur = np.mean(best_fits[:, -1])                            # :303-305
-    if sigma_cur <= locs[3]:
-        sigma_cur = locs[3] + 0.1
-    hills = np.maximum(best_fits[:, 1], 1e-3)
-    nll = lambda x: -np.sum(st.fisk.logpdf(hills, c=abs(x[1]) + 1e-9, scale=abs(x[0]) + 1e-9))   # :310-324 (product of pdfs)
-    res = minimize(nll, np.array([max(np.median(hills), 0.1), 3.0]), method="Nelder-Mead", options={"xatol": 1e-8, "fatol": 1e-10})
-    alpha_cur, beta_cur = abs(res.x[0]), min(abs(res.x[1]), 20.0)
-    if alpha_cur <= locs[0]:
-        alpha_cur = locs[0] + 0.1
-    if beta_cur <= locs[1]:
-        beta_cur = locs[1] + 0.1
-    mu_cur, s_cur = st.logistic.fit(best_fits[:, 0])                 # :330
-    if mu_cur <= locs[2]:
-        mu_cur = locs[2] + 0.1
-    if s_cur <= locs[3]:
-        s_cur = locs[3] + 0.1
-    return np.concatenate(([alpha_cur, beta_cur, mu_cur, s_cur], best_fits[:, :-1].flatten(), [sigma_cur]))
-
-
-def _fit_pic50_hill(concs, responses):
-    """sum-of-squares fit with pIC50 >= -2, Hill >= 0 (pic50_hill_priors_lowers, PyHillFit.py:218,253)."""
-    lowers = np.array([-2., 0.])
-    p_grid = np.linspace(-2.0, 12.0, 57); h_grid = np.exp(np.linspace(np.log(0.05), np.log(10.0), 30))
-    with np.errstate(all="ignore"):
-        pred = bestfit._curve(concs[None, None, :], p_grid[:, None, None], h_grid[None, :, None])
-        ss = np.sum((pred - responses) ** 2, axis=2)
-    ip, ih = np.unravel_index(np.argmin(ss), ss.shape)
-    x0 = np.sqrt(np.array([p_grid[ip], h_grid[ih]]) - lowers)
-    res = minimize(lambda x: bestfit.sum_of_square_diffs(x ** 2 + lowers, concs, responses), x0, method="Nelder-Mead",
-                   options={"xatol": 1e-9, "fatol": 1e-11, "maxiter": 6000})
-    return res.x ** 2 + lowers, float(res.fun)
+# ---- start point: bestfit.hierarchical_first_iteration (torch-free, so that it can run in the worker processes) --------
+first_iteration = bestfit.hierarchical_first_iteration
 
 
 def cdf_chains(args, num_chains):
@@ -258,6 +218,7 @@ def cdf_chains(args, num_chains):
 # ---- driver ------------------------------------------------------------------------------------------------------------
 def run_hierarchical(pairs, args, device, rank=0, world=1):
     """All pairs of this rank — replaces python/PyHillFit.py:213-642 run per pair."""
+    t_begin = time.time()
     shapes, scales, locs = prior_params()
     prior = make_prior(shapes, scales, locs)
     groups = {}
@@ -283,12 +244,12 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     burn = saved_iterations // 4                                       # :472
     rng = np.random.RandomState(args.seed)
     rng_pred = np.random.RandomState(1)                                # construct_hierarchical_cdfs.py:12-13
-    writers = chainio.WriterPool(getattr(args, "write_workers", 0))    # started now: the processes boot while the GPU samples
+    writers = chainio.WriterPool(getattr(args, "write_workers", 0))    # one pool for the start-point fits and the file formatting
     # one sampler and one HIP stream per Ne group: the groups are independent, their launches overlap on the GPU
     runs = []
     for ne, members in sorted(groups.items()):
         packed = PackedHierPoints([m[2] for m in members])
-        theta0 = np.array([first_iteration(m[2], locs) for m in members])
+        theta0 = np.array(writers.map(bestfit.hierarchical_first_iteration, [(m[2], locs) for m in members]))
         Q, C, d = len(members), args.num_chains, 5 + 2 * ne
         s = HierarchicalSampler(packed, list(range(Q)), C, thinning=thinning, seed=args.seed, prior=prior,
                                 problem_ids=[m[3] for m in members], device=device)
@@ -354,4 +315,6 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
                 json.dump(summ, f, indent=1)
             summaries.append(summ)
     writers.close()
+    print("timing [rank {}]: data + start points {:.1f} s, sampling {:.1f} s ({} chains x {} iterations), chain files {:.1f} s".format(
+        rank, start - t_begin, elapsed, total_chains, total_iterations, time.time() - start - elapsed))
     return summaries

@@ -11,8 +11,14 @@ PY
 for mode in "-m 2" "-m 1" "-m 2 --hierarchical --predictive-cdfs"; do
   tag=$(echo $mode | tr -d ' -')
   SECONDS=0; timeout -k 10 900 python python/PyHillFit.py --data-file /tmp/phf_cli/crumb_data.csv $mode -a --num-chains 64 --output-root /tmp/phf_cli/output > gpurun_out/cli_$tag.log 2>&1
-  echo "$mode rc=$? wall=${SECONDS}s"
+  echo "$mode rc=$? wall=${SECONDS}s"; grep "^timing" gpurun_out/cli_$tag.log
 done
+for m in 1 2; do
+  SECONDS=0; timeout -k 10 600 python python/PyHillTemp.py --data-file /tmp/phf_cli/crumb_data.csv -m $m -d 0 -c 0 --num-chains 64 --output-root /tmp/phf_cli/output > gpurun_out/cli_temp_m$m.log 2>&1
+  echo "PyHillTemp -m $m -d 0 -c 0 (41 rungs) rc=$? wall=${SECONDS}s"; grep "MCMC time" gpurun_out/cli_temp_m$m.log
+done
+SECONDS=0; timeout -k 10 300 python python/compute_bayes_factors.py --data-file /tmp/phf_cli/crumb_data.csv -d 0 -c 0 --output-root /tmp/phf_cli/output --bf-dir /tmp/phf_cli/BFs/ > gpurun_out/cli_bf.log 2>&1
+echo "compute_bayes_factors rc=$? wall=${SECONDS}s"; tail -n 2 gpurun_out/cli_bf.log; cat /tmp/phf_cli/BFs/*B12.txt 2>/dev/null | head -5
 SECONDS=0; timeout -k 10 900 python python/construct_hierarchical_cdfs.py --data-file /tmp/phf_cli/crumb_data.csv -a --num-cores 15 --output-root /tmp/phf_cli/output2 > gpurun_out/cli_cdfs_nofiles.log 2>&1
 echo "construct_hierarchical_cdfs (no chain files: every pair reported and skipped) rc=$? wall=${SECONDS}s"
 SECONDS=0; timeout -k 10 900 python python/construct_hierarchical_cdfs.py --data-file /tmp/phf_cli/crumb_data.csv -a --num-cores 15 --output-root /tmp/phf_cli/output > gpurun_out/cli_cdfs.log 2>&1
