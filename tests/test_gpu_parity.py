@@ -219,6 +219,33 @@ def test_posterior_means_within_one_percent_of_reference(gpu, dr):
             np.testing.assert_allclose(pooled_sd[:s.d, q], w["sd"][:s.d], rtol=0.2)
 
 
+def test_posteriors_of_other_pair_shapes_match_reference(gpu, dr):
+    """G5b (tests/golden/make_golden_posteriors_extra.py, reference do_mcmc, 200k iterations each): 20 points with both kinds
+    of censoring, the pair with the out-of-range response, a 6-point pair, an all-zero pair, model 1 with a saturated point.
+    Pooled means of 1 024 chains within 1 % + 4 batch-means standard errors of the reference's single chain."""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    with open(os.path.join(GOLDEN, "g5b_posteriors.json")) as f:
+        g5b = json.load(f)
+    for model in (1, 2):
+        want = [w for w in g5b if w["model"] == model]
+        names = [(w["drug"], w["channel"]) for w in want]
+        packed = dr.pack_single_level(names)
+        s = SingleLevelSampler(packed, model, list(range(len(names))), [1.0] * len(want), 1024, thinning=5, seed=11,
+                               reset_mean_at_adapt_start=True, device=gpu)
+        s.init(np.ones(s.d), cov_identity=True, cov_scale=1.0)
+        s.enable_moments(after_iteration=50000)
+        s.advance(200000, save=False)
+        mean, var, n = s.posterior_moments()
+        pooled = mean.mean(dim=2).cpu().numpy()
+        pooled_sd = torch.sqrt(var.mean(dim=2) + mean.var(dim=2)).cpu().numpy()
+        for q, w in enumerate(want):
+            k = s.d + 1                                                    # parameters and the log-target column
+            err = np.abs(pooled[:k, q] - w["mean"][:k])
+            tol = 0.01 * np.abs(w["mean"][:k]) + 4 * np.array(w["batch_means_se"][:k])
+            assert np.all(err <= tol), (w["drug"], w["channel"], model, pooled[:k, q], w["mean"], tol)
+            np.testing.assert_allclose(pooled_sd[:s.d, q], w["sd"][:s.d], rtol=0.15)
+
+
 def test_prior_only_rung_known_answer(gpu, dr):
     """t = 0 (first rung of the ladder): chains must sample the prior — pIC50 ~ -3+Exp(mean 5), Hill ~ U(0,10),
     sigma ~ 1e-3+Gamma(5, 1.49975): means (2, 5, 7.49975), sds (5, 2.887, 3.354)."""
