@@ -50,7 +50,7 @@ typedef struct {
 /* ---------------------------------------------------------------- model library (shared source: phf_model.h) */
 static void target_parts(const phfo_problem* pb, const double* th, double* lik, double* prior, double* ll1) {
   phf_sl_log_target(pb->model, pb->ln_conc, pb->response, pb->weight, pb->n_other, pb->n_zero + pb->n_hundred,
-                    pb->n_other_points, pb->ss_within, pb->pi_bit, pb->temperature, th, phf_k_exp, phf_k_log, lik, prior, ll1);
+                    pb->n_other_points, pb->ss_within, pb->pi_bit, pb->temperature, th, phf_k_exp, phf_k_log, 0, 0, lik, prior, ll1);
 }
 
 double phfo_log_prior(const phfo_problem* pb, const double* th) { double l, p, a; target_parts(pb, th, &l, &p, &a); return p; }

@@ -75,9 +75,20 @@ typedef const double __attribute__((address_space(4))) * phf_ktab4;
     asm volatile("" : "+v"(name##_buf[phf_i_]));                                            \
   }                                                                                         \
   const phf_ktab name = name##_buf
+/* `name` = `resident` when `have` (a compile-time constant) is non-zero, else fetched like PHF_KFETCH */
+#define PHF_KFETCH_UNLESS(name, have, resident, table, n)                                   \
+  double name##_buf[n];                                                                     \
+  if (!(have)) {                                                                            \
+    phf_ktab4 phf_p_ = (phf_ktab4)(table);                                                  \
+    asm volatile("" : "+s"(phf_p_));                                                        \
+    PHF_UNROLL                                                                              \
+    for (int phf_i_ = 0; phf_i_ < (n); ++phf_i_) name##_buf[phf_i_] = phf_p_[phf_i_];       \
+  }                                                                                         \
+  const phf_ktab name = (have) ? (resident) : name##_buf
 #define PHF_FMA_K(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "s"(c)); phf_r_; })
 #define PHF_FMA_KV(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "v"(c)); phf_r_; })
 #else
+#define PHF_KFETCH_UNLESS(name, have, resident, table, n) const phf_ktab name = (have) ? (resident) : (table)
 #define PHF_KFETCH(name, table, n) const phf_ktab name = (table)
 #define PHF_KFETCH_V(name, table, n) const phf_ktab name = (table)
 #define PHF_FMA_K(p, t, c) __builtin_fma((p), (t), (c))
@@ -247,35 +258,42 @@ PHF_KTABLE phf_k_erfcx[24] = { /* (1+2y) erfcx(y) in t = (y-4)/(y+4), coefficien
     0x1.355884b1ca9fcp-24, 0x1.8f0920c7d5e28p-24, -0x1.1f8f10ba20f78p-26, -0x1.dff032d300316p-28,
     0x1.c2e324cb33784p-30, 0.0};
 
-PHF_HD double phf_erfcx_finish_k(double y, double r, phf_ktab k) {
+/* the coefficient operand of a Horner step: from an SGPR pair (table fetched through the scalar cache) or a VGPR pair */
+#define PHF_FMA_KX(p, t, c, in_vgpr) ((in_vgpr) ? PHF_FMA_KV(p, t, c) : PHF_FMA_K(p, t, c))
+
+PHF_HD double phf_erfcx_finish_kx(double y, double r, phf_ktab k, int in_vgpr) {
   const double a = y + 4.0, b = phf_fma(2.0, y, 1.0);
   const double t = ((y - 4.0) * b) * r;
   const double t2 = t * t;
-  double pe = k[22];
-  pe = PHF_FMA_K(pe, t2, k[20]);
-  pe = PHF_FMA_K(pe, t2, k[18]);
-  pe = PHF_FMA_K(pe, t2, k[16]);
-  pe = PHF_FMA_K(pe, t2, k[14]);
-  pe = PHF_FMA_K(pe, t2, k[12]);
-  pe = PHF_FMA_K(pe, t2, k[10]);
-  pe = PHF_FMA_K(pe, t2, k[8]);
-  pe = PHF_FMA_K(pe, t2, k[6]);
-  pe = PHF_FMA_K(pe, t2, k[4]);
-  pe = PHF_FMA_K(pe, t2, k[2]);
-  pe = PHF_FMA_K(pe, t2, k[0]);
-  double po = k[21];
-  po = PHF_FMA_K(po, t2, k[19]);
-  po = PHF_FMA_K(po, t2, k[17]);
-  po = PHF_FMA_K(po, t2, k[15]);
-  po = PHF_FMA_K(po, t2, k[13]);
-  po = PHF_FMA_K(po, t2, k[11]);
-  po = PHF_FMA_K(po, t2, k[9]);
-  po = PHF_FMA_K(po, t2, k[7]);
-  po = PHF_FMA_K(po, t2, k[5]);
-  po = PHF_FMA_K(po, t2, k[3]);
-  po = PHF_FMA_K(po, t2, k[1]);
+  double pe = k[22], po = k[21];
+  PHF_UNROLL
+  for (int i = 20; i >= 0; i -= 2) {               /* even and odd chains alternate: neighbours are independent */
+    pe = PHF_FMA_KX(pe, t2, k[i], in_vgpr);
+    if (i >= 2) po = PHF_FMA_KX(po, t2, k[i - 1], in_vgpr);
+  }
   const double p = phf_fma(po, t, pe);
   return (p * a) * r;
+}
+
+PHF_HD double phf_erfcx_finish_k(double y, double r, phf_ktab k) { return phf_erfcx_finish_kx(y, r, k, 0); }
+
+/* two arguments at once: the four Horner chains advance in turn */
+PHF_HD void phf_erfcx_finish_x2_kx(double y0, double r0, double y1, double r1, phf_ktab k, int in_vgpr, double* e0, double* e1) {
+  const double a0 = y0 + 4.0, b0 = phf_fma(2.0, y0, 1.0), a1 = y1 + 4.0, b1 = phf_fma(2.0, y1, 1.0);
+  const double t0 = ((y0 - 4.0) * b0) * r0, t1 = ((y1 - 4.0) * b1) * r1;
+  const double s0 = t0 * t0, s1 = t1 * t1;
+  double pe0 = k[22], pe1 = k[22], po0 = k[21], po1 = k[21];
+  PHF_UNROLL
+  for (int i = 20; i >= 0; i -= 2) {
+    pe0 = PHF_FMA_KX(pe0, s0, k[i], in_vgpr);
+    pe1 = PHF_FMA_KX(pe1, s1, k[i], in_vgpr);
+    if (i >= 2) {
+      po0 = PHF_FMA_KX(po0, s0, k[i - 1], in_vgpr);
+      po1 = PHF_FMA_KX(po1, s1, k[i - 1], in_vgpr);
+    }
+  }
+  *e0 = (phf_fma(po0, t0, pe0) * a0) * r0;
+  *e1 = (phf_fma(po1, t1, pe1) * a1) * r1;
 }
 
 PHF_HD double phf_erfcx_finish(double y, double r) { PHF_KFETCH(k, phf_k_erfcx, 24); return phf_erfcx_finish_k(y, r, k); }
@@ -306,16 +324,21 @@ PHF_HD double phf_log_ndtr_nonpos(double x) {
 }
 
 /* two at once, sharing one division for the two erfcx and one for the two logs */
-PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r1, phf_ktab ke, phf_ktab kl) {
+PHF_HD void phf_log_ndtr_nonpos_x2_kx(double x0, double x1, double* r0, double* r1, phf_ktab ke, int ke_in_vgpr, phf_ktab kl) {
   const double y0 = -x0 * PHF_INV_SQRT2, y1 = -x1 * PHF_INV_SQRT2;
   const double q0 = phf_erfcx_den(y0), q1 = phf_erfcx_den(y1);
   const double iq = 1.0 / (q0 * q1);
-  const double e0 = phf_erfcx_finish_k(y0, iq * q1, ke), e1 = phf_erfcx_finish_k(y1, iq * q0, ke);
+  double e0, e1;
+  phf_erfcx_finish_x2_kx(y0, iq * q1, y1, iq * q0, ke, ke_in_vgpr, &e0, &e1);
   const phf_logred l0 = phf_log_reduce(0.5 * e0), l1 = phf_log_reduce(0.5 * e1);
   const double d0 = 2.0 + l0.f, d1 = 2.0 + l1.f;
   const double id = 1.0 / (d0 * d1);
   *r0 = phf_fma(-0.5 * x0, x0, phf_log_finish_k(l0, l0.f * (id * d1), kl));
   *r1 = phf_fma(-0.5 * x1, x1, phf_log_finish_k(l1, l1.f * (id * d0), kl));
+}
+
+PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r1, phf_ktab ke, phf_ktab kl) {
+  phf_log_ndtr_nonpos_x2_kx(x0, x1, r0, r1, ke, 0, kl);
 }
 
 PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1) {
@@ -325,12 +348,14 @@ PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1)
 }
 
 /* one, with the log table from the caller */
-PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab ke, phf_ktab kl) {
+PHF_HD double phf_log_ndtr_nonpos_kx(double x, phf_ktab ke, int ke_in_vgpr, phf_ktab kl) {
   const double yv = -x * PHF_INV_SQRT2;
-  const double e = phf_erfcx_finish_k(yv, 1.0 / phf_erfcx_den(yv), ke);
+  const double e = phf_erfcx_finish_kx(yv, 1.0 / phf_erfcx_den(yv), ke, ke_in_vgpr);
   const phf_logred lr = phf_log_reduce(0.5 * e);
   return phf_fma(-0.5 * x, x, phf_log_finish_k(lr, lr.f / (2.0 + lr.f), kl));
 }
+
+PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab ke, phf_ktab kl) { return phf_log_ndtr_nonpos_kx(x, ke, 0, kl); }
 
 /* log Phi(x), any x.  x > 0: log(1 - q), q = erfcx(x/sqrt2) exp(-x^2/2)/2, with the log1p correction term. */
 PHF_HD double phf_log_ndtr(double x) {

@@ -55,8 +55,11 @@ PHF_HD double phf_censored_z(double pred, double y, double inv_s) {
  * sample of every rung; it falls out of the same arithmetic here, so the samplers carry it along for free.      */
 PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, const double* w, int n_other, int n_cens,
                               double n_other_points, double ss_within, double pi_bit, double temperature,
-                              const double* th, phf_ktab k_exp, phf_ktab k_log,
+                              const double* th, phf_ktab k_exp, phf_ktab k_log, phf_ktab k_erfcx_resident, int erfcx_resident,
                               double* out_lik, double* out_prior, double* out_ll1) {
+  /* erfcx_resident != 0: k_erfcx_resident holds the 24 erfcx coefficients in VGPRs (kernels that own the whole register
+   * file keep them there for the launch); 0: fetched through the scalar cache at each use (48 SGPRs, only while needed).
+   * A literal at every call site, so that the choice is made at compile time. */
   const double pic50 = th[0];
   const double hill = (model == 1) ? 1.0 : th[1];
   const double sigma = (model == 1) ? th[1] : th[2];
@@ -110,20 +113,20 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
   j = n_other;
   const int n = n_other + n_cens;
   for (; j + 2 <= n; j += 2) {                    /* censored entries, two at a time (:244-245) */
-    PHF_KFETCH(k_erfcx, phf_k_erfcx, 24);         /* issued now, needed after the two exponentials */
+    PHF_KFETCH_UNLESS(k_erfcx, erfcx_resident, k_erfcx_resident, phf_k_erfcx, 24);   /* issued now, needed after the two exponentials */
     const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double inv = 1.0 / (d0 * d1);
     const double z0 = phf_censored_z(phf_hill_percent(inv * d1), y[j], inv_s);
     const double z1 = phf_censored_z(phf_hill_percent(inv * d0), y[j + 1], inv_s);
     double l0, l1;
-    phf_log_ndtr_nonpos_x2_k(z0, z1, &l0, &l1, k_erfcx, k_log);
+    phf_log_ndtr_nonpos_x2_kx(z0, z1, &l0, &l1, k_erfcx, erfcx_resident, k_log);
     cens = phf_fma(w[j], l0, cens); cens = phf_fma(w[j + 1], l1, cens);
   }
   for (; j < n; ++j) {
-    PHF_KFETCH(k_erfcx, phf_k_erfcx, 24);
+    PHF_KFETCH_UNLESS(k_erfcx, erfcx_resident, k_erfcx_resident, phf_k_erfcx, 24);
     const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1));
-    cens = phf_fma(w[j], phf_log_ndtr_nonpos_k(phf_censored_z(pred, y[j], inv_s), k_erfcx, k_log), cens);
+    cens = phf_fma(w[j], phf_log_ndtr_nonpos_kx(phf_censored_z(pred, y[j], inv_s), k_erfcx, erfcx_resident, k_log), cens);
   }
   double a = cens - pi_bit;
   a = phf_fma(-n_other_points, log_sigma, a);                            /* :246 */
