@@ -130,7 +130,7 @@ def main():
             groups.setdefault(len(ex), []).append(ex)
         shapes, scales, locs = H.prior_params()
         samplers = []
-        for ne, exs in sorted(groups.items()):
+        for ne, exs in sorted(groups.items(), reverse=True):
             hs = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(len(exs))), C, thinning=a.thinning, seed=25,
                                        chain_id_base=rank * C, device=dev)
             hs.init(np.array([H.first_iteration(e, locs) for e in exs]), cov_scale=0.01)

@@ -97,8 +97,11 @@ PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl
 }
 
 /* n_expts must be a compile-time constant at the call site (PHF_HIER_MAX_EXPTS at most) when theta lives in registers. */
-PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const double* lc, const double* y,
-                                  const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
+/* fixed_n > 0: every experiment has exactly fixed_n points (a literal at the call site: the point loops then unroll and
+ * an iteration of the sampler is straight-line code; 147 of the 210 Crumb pairs are 3 experiments x 4 points);
+ * 0: experiment i's points are expt_start[i] .. expt_start[i+1]-1.  Same operations in the same order either way. */
+PHF_HD double phf_hier_log_target_n(int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
+                                    const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
   const int dim = 5 + 2 * n_expts;
   const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
   int bad = (alpha <= pr->loc[0]) | (beta <= pr->loc[1]) | (mu <= pr->loc[2]) | (s <= pr->loc[3]) | (sigma <= pr->loc[4]);
@@ -130,8 +133,9 @@ PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const doub
     const double pic50 = th[(4 + 2 * i) * ts], hill = th[(5 + 2 * i) * ts];
     bad |= (hill < 0.0) | (pic50 < PHF_HIER_PIC50_LOWER);
     const double ln_ic50 = PHF_LN10 * (6.0 - pic50);
-    int j = expt_start[i];
-    const int jend = expt_start[i + 1];
+    int j = fixed_n ? i * fixed_n : expt_start[i];
+    const int jend = fixed_n ? (i + 1) * fixed_n : expt_start[i + 1];
+    PHF_UNROLL
     for (; j + 2 <= jend; j += 2) {                                          /* :117-125, two points at a time */
       const phf_ktab ke = k_exp;
       const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
@@ -171,7 +175,7 @@ PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const doub
       hyper -= 2.0 * ((la[k] > 0x1p1000) ? PHF_INF : v);                     /* overflowed power: log(inf) = inf */
     }
   }
-  const int n_pts = expt_start[n_expts];
+  const int n_pts = fixed_n ? n_expts * fixed_n : expt_start[n_expts];
   double total = -(phf_fma((double)n_pts, log_sigma, sse * (0.5 * inv_s * inv_s)) + trunc);   /* :122-125 */
   total += hyper;
   PHF_UNROLL
@@ -180,6 +184,11 @@ PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const doub
     total += phf_fma(pr->shape_m1[k], lg[4 + k], -xl * pr->inv_scale[k]);
   }
   return bad ? -PHF_INF : total;
+}
+
+PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const double* lc, const double* y,
+                                  const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
+  return phf_hier_log_target_n(n_expts, 0, expt_start, lc, y, th, ts, pr, k_exp, k_log);
 }
 
 /* Draws of hierarchical MH iteration t: dim standard normals into z[i*zs] (Box-Muller, two pairs per Philox block,

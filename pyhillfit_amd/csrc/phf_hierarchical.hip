@@ -53,22 +53,15 @@ __device__ __forceinline__ void stage(const phf_hier_points& pts, int pair, doub
   __syncthreads();
 }
 
-template <int NE>
-__global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) {
+// The whole launch of one wavefront.  FIXED_N > 0: every experiment of the pair has exactly FIXED_N points, known at compile
+// time (the point loops unroll: straight-line iteration); 0: run-time experiment boundaries.
+template <int NE, int FIXED_N>
+__device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_mem, const double* s_lc, const double* s_y,
+                                                  const int* s_es, int q, int c) {
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
-  extern __shared__ double s_mem[];
   double* sL = s_mem + threadIdx.x;                       // element e of this lane's factor: sL[e * 64]
-  double* s_lc = s_mem + (size_t)TRI * kBlock;
-  double* s_y = s_lc + a.pts.stride;
-  int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
-  const int q = blockIdx.x / a.blocks_per_problem;
-  const int chunk = blockIdx.x - q * a.blocks_per_problem;
   const int C = a.prob.chains_per_problem;
-  const int c = chunk * kBlock + threadIdx.x;
-  const int pair = a.prob.pair_index[q];
-  stage<NE>(a.pts, pair, s_lc, s_y, s_es);
-  if (c >= C) return;
   const uint32_t pid = a.prob.problem_id[q];
   const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
   const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
@@ -107,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) 
       star[i] = phf_fma(sc, v, th[i]);
     }
     // ---- target, accept (:486-492) ----
-    const double lt_star = phf_hier_log_target(NE, s_es, s_lc, s_y, star, 1, &a.prior, k_exp, k_log);
+    const double lt_star = phf_hier_log_target_n(NE, FIXED_N, s_es, s_lc, s_y, star, 1, &a.prior, k_exp, k_log);
     const bool acc = log_u < lt_star - lt;
     if (acc) {
 #pragma unroll
@@ -172,6 +165,28 @@ __global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) 
   for (int e = 0; e < TRI; ++e) sp[(size_t)(2 * D + 1 + e) * nchains] = sL[e * kBlock];
   sp[(size_t)(2 * D + 1 + TRI) * nchains] = loga;
   sp[(size_t)(2 * D + 2 + TRI) * nchains] = nacc;
+}
+
+template <int NE>
+__global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) {
+  constexpr int D = 5 + 2 * NE;
+  constexpr int TRI = D * (D + 1) / 2;
+  extern __shared__ double s_mem[];
+  double* s_lc = s_mem + (size_t)TRI * kBlock;
+  double* s_y = s_lc + a.pts.stride;
+  int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
+  const int q = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - q * a.blocks_per_problem;
+  const int c = chunk * kBlock + threadIdx.x;
+  const int pair = a.prob.pair_index[q];
+  stage<NE>(a.pts, pair, s_lc, s_y, s_es);
+  if (c >= a.prob.chains_per_problem) return;
+  // 4 points in every experiment (147 of the 210 Crumb pairs: 3 experiments x 4 doses)?  scalar loads: a uniform branch
+  bool four_each = true;
+#pragma unroll
+  for (int i = 1; i <= NE; ++i) four_each = four_each && (a.pts.expt_start[(size_t)pair * (NE + 1) + i] == 4 * i);
+  if (four_each) hier_advance_body<NE, 4>(a, s_mem, s_lc, s_y, s_es, q, c);
+  else hier_advance_body<NE, 0>(a, s_mem, s_lc, s_y, s_es, q, c);
 }
 
 template <int NE>

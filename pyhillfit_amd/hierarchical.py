@@ -247,7 +247,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     writers = chainio.WriterPool(getattr(args, "write_workers", 0))    # one pool for the start-point fits and the file formatting
     # one sampler and one HIP stream per Ne group: the groups are independent, their launches overlap on the GPU
     runs = []
-    for ne, members in sorted(groups.items()):
+    for ne, members in sorted(groups.items(), reverse=True):
         packed = PackedHierPoints([m[2] for m in members])
         theta0 = np.array(writers.map(bestfit.hierarchical_first_iteration, [(m[2], locs) for m in members]))
         Q, C, d = len(members), args.num_chains, 5 + 2 * ne
