@@ -141,10 +141,16 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   double* out = a.rows + ((size_t)q * (D + 1)) * C + c;
   const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
 
+  // The iteration is ONE basic block up to the sample store: the adaptation is applied unconditionally with gamma = 0 before
+  // it starts (cov, mean, loga are then reproduced exactly: (1-0) x + 0 y), and the random numbers of iteration t+1 — a
+  // function of (chain, t+1) only — are drawn next to the factorisation of iteration t, so that the two long dependency
+  // chains of an iteration (Philox -> log -> sqrt, and sqrt -> divide -> sqrt -> divide -> sqrt) overlap each other and
+  // the likelihood instead of being exposed one after the other on a wavefront that has its SIMD to itself.
+  double z[4];
+  double log_u = phf_mh_draws(D, cid, pid, (uint32_t)(a.t_begin + 1), seed_lo, seed_hi, k_log, k_sc, z);
+  const bool reset_mean = a.cfg.reset_mean_at_adapt_start != 0;
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
     // ---- proposal: theta* = theta + e^(loga/2) L z  (PyHillFit.py:831) ----
-    double z[4];
-    const double log_u = phf_mh_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, k_sc, z);
     double star[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -165,14 +171,14 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
       ll1 = ll1_star;
     }
     nacc += acc ? 1.0 : 0.0;
-    // ---- adaptation (PyHillFit.py:840-846; PyHillTemp.py:114-122) ----
-    if (a.cfg.reset_mean_at_adapt_start && t == a.cfg.adapt_start) {
-#pragma unroll
-      for (int i = 0; i < D; ++i) mean[i] = th[i];
-    }
-    if (t > a.cfg.adapt_start) {
-      const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
-      const double omg = 1.0 - gs;
+    // ---- adaptation (PyHillFit.py:840-846; PyHillTemp.py:114-122), wave-uniform selects instead of branches ----
+    const bool adapting = t > a.cfg.adapt_start;
+    const bool reset_now = reset_mean && t == a.cfg.adapt_start;                       // PyHillTemp.py:114-115: mean <- theta
+    const double gs_tab = a.cfg.gamma[adapting ? t - a.cfg.adapt_start : 0];
+    const double gs = adapting ? gs_tab : 0.0;
+    const double omg = 1.0 - gs;
+    const double gm = reset_now ? 1.0 : gs, omm = reset_now ? 0.0 : omg;               // mean: 1 theta + 0 mean on the reset step
+    {
       double v[D];
 #pragma unroll
       for (int i = 0; i < D; ++i) v[i] = th[i] - mean[i];
@@ -182,11 +188,17 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
         for (int j = 0; j <= i; ++j)
           cov[i * (i + 1) / 2 + j] = phf_fma(gs, v[i] * v[j], omg * cov[i * (i + 1) / 2 + j]);
 #pragma unroll
-      for (int i = 0; i < D; ++i) mean[i] = phf_fma(gs, th[i], omg * mean[i]);
+      for (int i = 0; i < D; ++i) mean[i] = phf_fma(gm, th[i], omm * mean[i]);
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
-      chol_packed<D>(cov, L);
-      sc = phf_exp_fast_k(0.5 * loga, k_exp);
     }
+    // ---- draws of the next iteration, factor and scale of the next proposal ----
+    double z_next[4];
+    const double log_u_next = phf_mh_draws(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, k_sc, z_next);
+    chol_packed<D>(cov, L);
+    sc = phf_exp_fast_k(0.5 * loga, k_exp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = z_next[i];
+    log_u = log_u_next;
     // ---- thinning + sample store (PyHillFit.py:847-848) ----
     if (--until_save == 0) {
       until_save = thin;
