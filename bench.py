@@ -10,6 +10,7 @@ rank runs its own 65 536-chain shard of the chain batch (weak scaling, no collec
 Philox chain ids continue across ranks), timing is barrier + synchronize on both sides, MAX over ranks.
 Rank 0 prints ONE JSON line."""
 import argparse
+import gc
 import json
 import os
 import sys
@@ -74,8 +75,8 @@ def cpu_baseline(iterations=300000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps before the timed ones (the first ~6 launches of a process run ~10 % slow while the clocks settle)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--iters-per-step", type=int, default=2000)
     ap.add_argument("--chains", type=int, default=None, help="chains per problem (default: 65536 c2, 4096 c3, 1024 c4/c5)")
@@ -193,6 +194,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    gc.collect(); gc.disable()                      # no collector pause between launches of the timed region
     t0 = time.perf_counter()
     for k in range(a.steps):
         ev[k][0].record()
@@ -203,6 +205,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
