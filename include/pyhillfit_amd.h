@@ -79,7 +79,8 @@ typedef struct phf_mh_config {
   int32_t reset_mean_at_adapt_start; /* PyHillTemp.py:114-115 */
   int32_t reserved;
   uint64_t seed;                 /* Philox key (the reference seeds numpy with 25: PyHillFit.py:824-825) */
-  const double* gamma;           /* device [>= t_end-adapt_start+1]  gamma[s] = 1/(s+1)**0.6 (PyHillFit.py:841-842), gamma[0] unused */
+  const double* gamma;           /* device [>= max(1, t_end-adapt_start+1)]  gamma[s] = 1/(s+1)**0.6 (PyHillFit.py:841-842);
+                                    never NULL: gamma[0] (any finite value) is read before the adaptation starts */
 } phf_mh_config;
 
 int phf_version(void);

@@ -438,7 +438,8 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
   if (!state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null state");
   if (cfg->thinning <= 0) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "thinning must be positive");
   if (t_begin < 0 || t_end < t_begin || t_end > 0xffffffffLL) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad iteration range");
-  if (t_end > cfg->adapt_start && !cfg->gamma) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "gamma table required once adapting");
+  // gamma[0] is read (and multiplied by zero) on every iteration before the adaptation starts: the table is always needed
+  if (!cfg->gamma) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "gamma table required (gamma[0] is read even before adaptation starts)");
   if (t_end == t_begin) return PHF_OK;
   AdvanceArgs a{*pts, *prob, *cfg, t_begin, t_end, state, rows, moments, moments_after, 0};
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;

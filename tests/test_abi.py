@@ -56,6 +56,8 @@ def test_argument_validation_without_gpu(lib):
     cfg.thinning = 5
     assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 4000, 1, None, None, 0, None) == -1
     assert b"gamma" in lib.phf_last_error()
+    assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
+    assert b"gamma" in lib.phf_last_error()               # the table is read (times zero) before the adaptation starts too
     pts.stride = 20000                                    # 480 KB of entries cannot be staged in a CU's LDS
     assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -3
     with pytest.raises(_lib.PhfError):
