@@ -141,3 +141,46 @@ def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):
         assert np.array_equal(chain[:, 0, :, c], rows)
         assert np.array_equal(state[:, 0, c], st)
     assert np.isfinite(chain).all() and (np.diff(chain[:, 0, 0, :], axis=0) != 0).any()
+
+
+def test_all_pairs_alpha_mu_against_the_reference_stored_samples(gpu):
+    """every Crumb pair at the reference's run length (500 000 iterations, first quarter dropped), 128 chains each: pooled
+    posterior means of (alpha, mu) against the reference's own stored hierarchical samples (chaste/samples: 500 draws of ONE
+    unseeded chain per pair, so each reference mean carries a Monte-Carlo error of a few sd/sqrt(500)).  Observed: all 210
+    pairs within 3.3 such errors.  (Shorter runs do NOT agree for the weakly informative pairs: their chains need well over
+    60 000 iterations to leave the start point — which is why the reference runs 500 000.)"""
+    from pyhillfit_amd import bestfit
+    from pyhillfit_amd import doseresponse as dr
+    from pyhillfit_amd import hierarchical as H
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    with open(os.path.join(GOLDEN, "chaste_alpha_mu_stats.json")) as f:
+        ref = json.load(f)
+    shapes, scales, locs = H.prior_params()
+    groups = {}
+    for d in dr.drugs:
+        for c in dr.channels:
+            ne, _, ex = dr.load_crumb_data(d, c)
+            groups.setdefault(len(ex), []).append((d, c, ex))
+    T, C = 500000, 128
+    z, names, sd_ratio = [], [], []
+    for ne, members in sorted(groups.items(), reverse=True):
+        packed = H.PackedHierPoints([m[2] for m in members])
+        theta0 = np.array([bestfit.hierarchical_first_iteration(m[2], locs) for m in members])
+        s = H.HierarchicalSampler(packed, list(range(len(members))), C, thinning=5, seed=7, device=gpu)
+        s.init(theta0, cov_scale=0.01)
+        s.enable_moments(after_iteration=T // 4)
+        s.advance(T, save=False)
+        mean, var, n = s.posterior_moments()
+        pooled = mean.mean(dim=2).cpu().numpy()                      # [dim+1][Q]
+        pooled_sd = torch.sqrt(var.mean(dim=2) + mean.var(dim=2)).cpu().numpy()
+        for q, (d, c, _) in enumerate(members):
+            w = ref["%s_%s" % (d.replace("/", "_"), c.replace("/", "_"))]
+            se_a, se_m = 3 * w["alpha_sd"] / np.sqrt(w["n"]), 3 * w["mu_sd"] / np.sqrt(w["n"])    # x3: autocorrelated draws
+            z.append(max(abs(pooled[0, q] - w["alpha_mean"]) / (se_a + 0.005 * w["alpha_mean"]),
+                         abs(pooled[2, q] - w["mu_mean"]) / (se_m + 0.005 * abs(w["mu_mean"]))))
+            sd_ratio.append((pooled_sd[0, q] / w["alpha_sd"], pooled_sd[2, q] / w["mu_sd"]))
+            names.append((d, c))
+    z, sd_ratio = np.array(z), np.array(sd_ratio)
+    assert len(names) == 210
+    assert z.max() < 6 and np.mean(z < 4) >= 0.98, (names[int(z.argmax())], z.max(), np.mean(z < 4))
+    assert np.all(sd_ratio > 0.6) and np.all(sd_ratio < 1.6), (sd_ratio.min(), sd_ratio.max())   # posterior widths too
