@@ -4,13 +4,11 @@ PyTorch is used for device memory and streams only; every number is produced by 
 include/pyhillfit_amd.h.  Mirrors the state machine of the reference loops
 (python/PyHillFit.py:748-856, python/PyHillTemp.py:57-125) for Q problems x C chains at once."""
 import ctypes as C
-import math
 
 import numpy as np
 import torch
 
 from . import _lib
-from .doseresponse import PackedPoints
 
 _GAMMA_CACHE = {}
 
