@@ -292,25 +292,26 @@ def test_posteriors_of_other_pair_shapes_match_reference(gpu, dr):
             np.testing.assert_allclose(pooled_sd[:s.d, q], w["sd"][:s.d], rtol=0.15)
 
 
-def test_every_crumb_pair_posterior_within_one_percent_of_reference(gpu, dr):
+@pytest.mark.parametrize("model", [2, 1])
+def test_every_crumb_pair_posterior_within_one_percent_of_reference(model, gpu, dr):
     """BASELINE's correctness target on the full data set (config 3): G5c = the reference's own sampler (PyHillTemp.do_mcmc,
-    model 2, 200 000 iterations, tests/golden/make_golden_posteriors_all.py) run on every one of the 210 pairs; here 256
-    chains per pair, same length and start, pooled on the device.  Tolerance per (pair, column): 1 % of the reference mean
-    + 4 batch-means standard errors of the reference's single chain."""
+    200 000 iterations, tests/golden/make_golden_posteriors_all.py) run on every one of the 210 pairs, for both models; here
+    256 chains per pair, same length and start, pooled on the device.  Tolerance per (pair, column): 1 % of the reference
+    mean + 4 batch-means standard errors of the reference's single chain."""
     from pyhillfit_amd.sampler import SingleLevelSampler
-    path = os.path.join(GOLDEN, "g5c_posteriors_all_pairs_model_2.json")
+    path = os.path.join(GOLDEN, "g5c_posteriors_all_pairs_model_%d.json" % model)
     with open(path) as f:
         g5c = json.load(f)
     assert len(g5c) == 210
     names = [(w["drug"], w["channel"]) for w in g5c]
     packed = dr.pack_single_level(names)
-    s = SingleLevelSampler(packed, 2, list(range(len(names))), [1.0] * len(names), 256, thinning=5, seed=5,
+    s = SingleLevelSampler(packed, model, list(range(len(names))), [1.0] * len(names), 256, thinning=5, seed=5,
                            reset_mean_at_adapt_start=True, device=gpu)
-    s.init(np.ones(3), cov_identity=True, cov_scale=1.0)            # PyHillTemp.py:63,80
+    s.init(np.ones(s.d), cov_identity=True, cov_scale=1.0)          # PyHillTemp.py:63,80
     s.enable_moments(after_iteration=50000)
     s.advance(200000, save=False)
     mean, var, n = s.posterior_moments()
-    pooled = mean.mean(dim=2).cpu().numpy()                          # [4][210]
+    pooled = mean.mean(dim=2).cpu().numpy()                          # [d+1][210]
     pooled_sd = torch.sqrt(var.mean(dim=2) + mean.var(dim=2)).cpu().numpy()
     want = np.array([w["mean"] for w in g5c]).T
     se = np.array([w["batch_means_se"] for w in g5c]).T
@@ -320,7 +321,7 @@ def test_every_crumb_pair_posterior_within_one_percent_of_reference(gpu, dr):
     assert np.mean(ratio < 1) >= 0.99 and ratio.max() < 2.0, (np.mean(ratio < 1), ratio.max(), names[worst[1]], worst[0])
     # posterior widths: the reference's single 200k chain estimates an sd poorly where the posterior has a long thin tail
     # (Hill of weakly informative pairs), so the bulk is checked tightly and the extremes loosely
-    sd_ratio = pooled_sd[:3] / np.array([w["sd"][:3] for w in g5c]).T
+    sd_ratio = pooled_sd[:s.d] / np.array([w["sd"][:s.d] for w in g5c]).T
     lo, hi = np.unravel_index(np.argmin(sd_ratio), sd_ratio.shape), np.unravel_index(np.argmax(sd_ratio), sd_ratio.shape)
     info = (sd_ratio.min(), names[lo[1]], lo[0], sd_ratio.max(), names[hi[1]], hi[0], np.mean((sd_ratio > 0.8) & (sd_ratio < 1.25)))
     assert np.mean((sd_ratio > 0.8) & (sd_ratio < 1.25)) >= 0.97, info
