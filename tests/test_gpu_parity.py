@@ -300,6 +300,8 @@ def test_every_crumb_pair_posterior_within_one_percent_of_reference(model, gpu, 
     mean + 4 batch-means standard errors of the reference's single chain."""
     from pyhillfit_amd.sampler import SingleLevelSampler
     path = os.path.join(GOLDEN, "g5c_posteriors_all_pairs_model_%d.json" % model)
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated (tests/golden/make_golden_posteriors_all.py --model %d)" % model)
     with open(path) as f:
         g5c = json.load(f)
     assert len(g5c) == 210
