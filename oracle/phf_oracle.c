@@ -183,7 +183,7 @@ typedef struct {
 } phfo_hier_problem;
 
 double phfo_hier_log_target(const phfo_hier_problem* pb, const double* th) {
-  return phf_hier_log_target(pb->n_expts, pb->expt_start, pb->ln_conc, pb->response, th, 1, &pb->prior, phf_k_exp, phf_k_log);
+  return phf_hier_log_target_any(pb->n_expts, pb->expt_start, pb->ln_conc, pb->response, th, 1, &pb->prior, phf_k_exp, phf_k_log);
 }
 
 /* state: th[d], lt, mean[d], L[d(d+1)/2] (factor of the adapted covariance), loga, n_accepted */

@@ -191,6 +191,125 @@ PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const doub
   return phf_hier_log_target_n(n_expts, 0, expt_start, lc, y, th, ts, pr, k_exp, k_log);
 }
 
+/* ---- the same target, experiment by experiment --------------------------------------------------------------------
+ * For pairs with many experiments (more than the kernels compiled per Ne cover: the reference's synthetic set has one
+ * with 50) a wavefront works on ONE chain and its lanes take one experiment each.  An experiment's terms are then computed
+ * on their own — no reciprocal shared across experiments — and the per-experiment sums are added in experiment order.
+ * Same mathematics as phf_hier_log_target_n, a different (equally fixed) order of roundings; the scalar twin uses this
+ * form for the same pairs, so the two still agree bit for bit.                                                      */
+typedef struct {
+  double inv_s, inv_sc;                 /* 1/sigma, 1/s */
+  double log_sigma, ln_alpha, ln_beta, ln_s, beta, mu;
+  double prior;                         /* the five shifted-Gamma log-priors (:187) */
+  int bad;                              /* hyper-parameter outside its support (:176,182) */
+} phf_hier_common;
+
+/* the part that depends on (alpha, beta, mu, s, sigma) only: 9 logarithms and 2 reciprocals behind one division */
+PHF_HD phf_hier_common phf_hier_common_terms(double alpha, double beta, double mu, double s, double sigma,
+                                             const phf_hier_prior* pr, phf_ktab k_log) {
+  phf_hier_common c;
+  c.bad = (alpha <= pr->loc[0]) | (beta <= pr->loc[1]) | (mu <= pr->loc[2]) | (s <= pr->loc[3]) | (sigma <= pr->loc[4]);
+  const double hv[5] = {alpha, beta, mu, s, sigma};
+  double lx[9];
+  lx[0] = sigma; lx[1] = alpha; lx[2] = beta; lx[3] = s;
+  PHF_UNROLL
+  for (int k = 0; k < 5; ++k) lx[4 + k] = hv[k] - pr->loc[k];
+  phf_logred lr[9];
+  double rc[11];
+  rc[0] = sigma; rc[1] = s;
+  PHF_UNROLL
+  for (int k = 0; k < 9; ++k) { lr[k] = phf_log_reduce(lx[k]); rc[2 + k] = 2.0 + lr[k].f; }
+  phf_batch_recip(rc, 11);
+  c.inv_s = rc[0]; c.inv_sc = rc[1];
+  double lg[9];
+  PHF_UNROLL
+  for (int k = 0; k < 9; ++k) lg[k] = phf_log_from_recip(lx[k], lr[k], rc[2 + k], k_log);
+  c.log_sigma = lg[0]; c.ln_alpha = lg[1]; c.ln_beta = lg[2]; c.ln_s = lg[3]; c.beta = beta; c.mu = mu;
+  double prior = 0.0;
+  PHF_UNROLL
+  for (int k = 0; k < 5; ++k) prior += phf_fma(pr->shape_m1[k], lg[4 + k], -lx[4 + k] * pr->inv_scale[k]);
+  c.prior = prior;
+  return c;
+}
+
+/* one experiment: its n points lc[0..n-1], y[0..n-1] and its (pIC50_i, Hill_i); returns through sse, trunc, hyper, bad */
+PHF_HD void phf_hier_experiment_terms(const phf_hier_common* c, double pic50, double hill, const double* lc, const double* y,
+                                      int n, phf_ktab k_exp, phf_ktab k_log, double* out_sse, double* out_trunc,
+                                      double* out_hyper, int* out_bad) {
+  *out_bad = (hill < 0.0) | (pic50 < PHF_HIER_PIC50_LOWER);
+  const double ln_ic50 = PHF_LN10 * (6.0 - pic50);
+  double sse = 0.0, trunc = 0.0;
+  int j = 0;
+  for (; j + 2 <= n; j += 2) {                                               /* :117-125, two points at a time */
+    const phf_ktab ke = k_exp;
+    const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
+    const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke, 0);
+    const double inv = 1.0 / (d0 * d1);
+    const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
+    const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
+    sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
+    trunc += phf_trunc_terms_x2(pred0, pred1, c->inv_s, k_exp, k_log);
+  }
+  for (; j < n; ++j) {
+    const double w = 1.0 / (1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
+    const double pred = phf_fma(-100.0, w, 100.0);
+    const double r = y[j] - pred;
+    sse = phf_fma(r, r, sse);
+    trunc += phf_trunc_term(pred, c->inv_s, k_exp, k_log);
+  }
+  /* log-logistic density of Hill_i (:134-142), logistic density of pIC50_i (:144-154): three logarithms, one division */
+  const double z = (pic50 - c->mu) * c->inv_sc;
+  const phf_logred lh = phf_log_reduce(hill);
+  const double la1 = 1.0 + phf_exp_fast_k(-z, k_exp);
+  const phf_logred l1 = phf_log_reduce(la1);
+  double d[2] = {2.0 + lh.f, 2.0 + l1.f};
+  phf_batch_recip(d, 2);
+  const double ln_h = phf_log_from_recip(hill, lh, d[0], k_log);
+  const double v1 = phf_log_finish_k(l1, l1.f * d[1], k_log);
+  const double la0 = 1.0 + phf_exp_fast_k(c->beta * (ln_h - c->ln_alpha), k_exp);
+  const phf_logred l0 = phf_log_reduce(la0);
+  const double v0 = phf_log_finish_k(l0, l0.f / (2.0 + l0.f), k_log);
+  double hyper = (c->ln_beta - c->beta * c->ln_alpha) + (c->beta - 1.0) * ln_h;
+  hyper += (-z - c->ln_s);
+  hyper -= 2.0 * ((la0 > 0x1p1000) ? PHF_INF : v0);                          /* overflowed power: log(inf) = inf */
+  hyper -= 2.0 * ((la1 > 0x1p1000) ? PHF_INF : v1);
+  *out_sse = sse; *out_trunc = trunc; *out_hyper = hyper;
+}
+
+PHF_HD double phf_hier_combine(const phf_hier_common* c, int n_pts, double sse, double trunc, double hyper, int bad) {
+  double total = -(phf_fma((double)n_pts, c->log_sigma, sse * (0.5 * c->inv_s * c->inv_s)) + trunc);   /* :122-125 */
+  total += hyper;
+  total += c->prior;
+  return (bad | c->bad) ? -PHF_INF : total;
+}
+
+/* sequential form: what one lane, or the scalar twin, computes for a whole parameter vector */
+PHF_HD double phf_hier_log_target_by_experiment(int n_expts, const int* expt_start, const double* lc, const double* y,
+                                                const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp,
+                                                phf_ktab k_log) {
+  const int dim = 5 + 2 * n_expts;
+  const phf_hier_common c = phf_hier_common_terms(th[0], th[1 * ts], th[2 * ts], th[3 * ts], th[(dim - 1) * ts], pr, k_log);
+  double sse = 0.0, trunc = 0.0, hyper = 0.0;
+  int bad = 0;
+  for (int i = 0; i < n_expts; ++i) {
+    double a, b, h;
+    int bi;
+    phf_hier_experiment_terms(&c, th[(4 + 2 * i) * ts], th[(5 + 2 * i) * ts], lc + expt_start[i], y + expt_start[i],
+                              expt_start[i + 1] - expt_start[i], k_exp, k_log, &a, &b, &h, &bi);
+    sse += a; trunc += b; hyper += h; bad |= bi;
+  }
+  return phf_hier_combine(&c, expt_start[n_expts], sse, trunc, hyper, bad);
+}
+
+/* which form a pair uses: the kernels compiled per Ne (and their twin) the batched one, larger Ne the per-experiment one */
+#define PHF_HIER_BATCHED_MAX_EXPTS 8
+PHF_HD double phf_hier_log_target_any(int n_expts, const int* expt_start, const double* lc, const double* y,
+                                      const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
+  if (n_expts > PHF_HIER_BATCHED_MAX_EXPTS)
+    return phf_hier_log_target_by_experiment(n_expts, expt_start, lc, y, th, ts, pr, k_exp, k_log);
+  return phf_hier_log_target_n(n_expts, 0, expt_start, lc, y, th, ts, pr, k_exp, k_log);
+}
+
 /* Draws of hierarchical MH iteration t: dim standard normals into z[i*zs] (Box-Muller, two pairs per Philox block,
  * blocks 0..ceil(dim/4)-1) and log(u) of the accept uniform (block ceil(dim/4)).                                 */
 PHF_HD void phf_box_muller_k(uint32_t w1, uint32_t w2, double* z0, double* z1, phf_ktab k_log, phf_ktab k_sc) {

@@ -255,8 +255,8 @@ __global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_
 constexpr int kGenBlock = 16;
 
 __device__ __forceinline__ double gen_target(const HierArgs& a, int ne, int pair, const double* th, int ts, phf_ktab k_exp, phf_ktab k_log) {
-  return phf_hier_log_target(ne, a.pts.expt_start + (size_t)pair * (ne + 1), a.pts.ln_conc + (size_t)pair * a.pts.stride,
-                             a.pts.response + (size_t)pair * a.pts.stride, th, ts, &a.prior, k_exp, k_log);
+  return phf_hier_log_target_any(ne, a.pts.expt_start + (size_t)pair * (ne + 1), a.pts.ln_conc + (size_t)pair * a.pts.stride,
+                                 a.pts.response + (size_t)pair * a.pts.stride, th, ts, &a.prior, k_exp, k_log);
 }
 
 __global__ __launch_bounds__(kGenBlock) void hier_generic_advance_kernel(const HierArgs a) {
@@ -350,6 +350,176 @@ __global__ __launch_bounds__(kGenBlock) void hier_generic_advance_kernel(const H
   *plt = lt; *ploga = loga; *pnacc = nacc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One WAVEFRONT per chain, for pairs with many experiments (dim = 5 + 2 Ne up to 133): the chain's factor (dim(dim+1)/2
+// doubles: 44.5 KB at dim 105), theta, mean, proposal and normals live in LDS; the 64 lanes take one experiment each in
+// the target (phf_hier_experiment_terms) and the rows lane, lane+64, ... of the factor in the proposal and in the Givens
+// sweep.  Every element is computed by the same operations in the same order as in hier_generic_advance_kernel and the
+// twin (the per-experiment sums are added in experiment order by every lane), so results are bit-identical; what changes
+// is the cost: the state no longer streams through HBM once per iteration (1.2 ms per iteration at dim 105 -> tens of us).
+struct WaveLds {
+  int D, tri, stride, ne;
+  __host__ __device__ size_t doubles() const { return (size_t)tri + 4 * (size_t)D + 3 * 64 + 2 * (size_t)stride; }
+  __host__ __device__ size_t bytes() const { return doubles() * 8 + (size_t)(ne + 1) * 4 + 8; }
+};
+
+__global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArgs a) {
+  extern __shared__ double s_mem[];
+  const int ne = a.pts.n_expts;
+  const int D = 5 + 2 * ne;
+  const int TRI = D * (D + 1) / 2;
+  const int lane = threadIdx.x;
+  double* sLm = s_mem;                           // packed lower triangle, row-major
+  double* s_th = sLm + TRI;
+  double* s_mean = s_th + D;
+  double* s_star = s_mean + D;
+  double* s_z = s_star + D;                      // normals; reused as the update vector w
+  double* s_part = s_z + D;                      // [3][64]: per-experiment sse, trunc, hyper
+  double* s_lc = s_part + 3 * 64;
+  double* s_y = s_lc + a.pts.stride;
+  int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
+  const int C = a.prob.chains_per_problem;
+  const int q = blockIdx.x / C;
+  const int c = blockIdx.x - q * C;
+  const int pair = a.prob.pair_index[q];
+  const uint32_t pid = a.prob.problem_id[q];
+  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
+  const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
+  const size_t nch = (size_t)a.prob.num_problems * C;
+  const size_t g = (size_t)q * C + c;
+  double* sp = a.state + g;                      // element e of this chain's state: sp[e * nch]
+  // ---- stage the pair's points and the chain's state ----
+  const int n_pts = a.pts.expt_start[(size_t)pair * (ne + 1) + ne];
+  for (int j = lane; j < n_pts; j += kBlock) {
+    s_lc[j] = a.pts.ln_conc[(size_t)pair * a.pts.stride + j];
+    s_y[j] = a.pts.response[(size_t)pair * a.pts.stride + j];
+  }
+  for (int i = lane; i <= ne; i += kBlock) s_es[i] = a.pts.expt_start[(size_t)pair * (ne + 1) + i];
+  for (int i = lane; i < D; i += kBlock) { s_th[i] = sp[(size_t)i * nch]; s_mean[i] = sp[(size_t)(D + 1 + i) * nch]; }
+  for (int e = lane; e < TRI; e += kBlock) sLm[e] = sp[(size_t)(2 * D + 1 + e) * nch];
+  __syncthreads();
+  double lt = sp[(size_t)D * nch], loga = sp[(size_t)(2 * D + 1 + TRI) * nch], nacc = sp[(size_t)(2 * D + 2 + TRI) * nch];
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
+  double sc = phf_exp_fast_k(0.5 * loga, k_exp);
+  const int thin = a.cfg.thinning;
+  int until_save = thin - (int)(a.t_begin % thin);
+  double* out = a.rows ? a.rows + ((size_t)q * (D + 1)) * C + c : nullptr;
+  const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
+  const int nb = (D + 3) / 4;
+
+  for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
+    // ---- draws: Philox block b -> normals 4b..4b+3 (as phf_hier_draws), lane b; the accept uniform in every lane ----
+    for (int b = lane; b < nb; b += kBlock) {
+      const phf_u32x4 w = phf_philox4x32_10(cid, pid, (uint32_t)t, (uint32_t)b, seed_lo, seed_hi);
+      double z0, z1, z2, z3;
+      phf_box_muller_k(w.w[0], w.w[1], &z0, &z1, k_log, k_sc);
+      phf_box_muller_k(w.w[2], w.w[3], &z2, &z3, k_log, k_sc);
+      const int i = 4 * b;
+      s_z[i] = z0;
+      if (i + 1 < D) s_z[i + 1] = z1;
+      if (i + 2 < D) s_z[i + 2] = z2;
+      if (i + 3 < D) s_z[i + 3] = z3;
+    }
+    const phf_u32x4 wu = phf_philox4x32_10(cid, pid, (uint32_t)t, (uint32_t)nb, seed_lo, seed_hi);
+    const double u = phf_uniform53(wu.w[0], wu.w[1]);
+    const phf_logred lu = phf_log_reduce(u);
+    const double log_u = phf_log_from_recip(u, lu, 1.0 / (2.0 + lu.f), k_log);
+    __syncthreads();
+    // ---- proposal theta* = theta + e^(loga/2) L z: rows lane, lane+64, ... ----
+    for (int i = lane; i < D; i += kBlock) {
+      const double* row = sLm + i * (i + 1) / 2;
+      double v = row[i] * s_z[i];
+      for (int k = i - 1; k >= 0; --k) v = phf_fma(row[k], s_z[k], v);
+      s_star[i] = phf_fma(sc, v, s_th[i]);
+    }
+    __syncthreads();
+    // ---- target: one experiment per lane, sums in experiment order ----
+    const phf_hier_common cm = phf_hier_common_terms(s_star[0], s_star[1], s_star[2], s_star[3], s_star[D - 1], &a.prior, k_log);
+    int bad_mine = 0;
+    for (int i = lane; i < ne; i += kBlock) {                     // PHF_HIER_MAX_EXPTS = 64: at most one per lane
+      double e_sse, e_trunc, e_hyper;
+      phf_hier_experiment_terms(&cm, s_star[4 + 2 * i], s_star[5 + 2 * i], s_lc + s_es[i], s_y + s_es[i], s_es[i + 1] - s_es[i],
+                                k_exp, k_log, &e_sse, &e_trunc, &e_hyper, &bad_mine);
+      s_part[i] = e_sse; s_part[64 + i] = e_trunc; s_part[128 + i] = e_hyper;
+    }
+    const int bad = __any(bad_mine) ? 1 : 0;
+    __syncthreads();
+    double sse = 0.0, trunc = 0.0, hyper = 0.0;
+    for (int i = 0; i < ne; ++i) { sse += s_part[i]; trunc += s_part[64 + i]; hyper += s_part[128 + i]; }
+    const double lt_star = phf_hier_combine(&cm, n_pts, sse, trunc, hyper, bad);
+    // ---- accept (the same decision in every lane) ----
+    const bool acc = log_u < lt_star - lt;
+    if (acc) {
+      for (int i = lane; i < D; i += kBlock) s_th[i] = s_star[i];
+      lt = lt_star;
+    }
+    nacc += acc ? 1.0 : 0.0;
+    __syncthreads();
+    // ---- adaptation: rank-one update of the factor, column by column; rows of a column in parallel ----
+    if (t > a.cfg.adapt_start) {
+      const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
+      const double omg = 1.0 - gs;
+      const double sqa = phf_sqrt(omg), sqg = phf_sqrt(gs);
+      double* s_w = s_z;
+      for (int i = lane; i < D; i += kBlock) {
+        const double thi = s_th[i], mi = s_mean[i];
+        s_w[i] = sqg * (thi - mi);
+        s_mean[i] = phf_fma(gs, thi, omg * mi);
+      }
+      loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
+      __syncthreads();
+      for (int k = 0; k < D; ++k) {
+        const double wk = s_w[k];
+        const double tkk = sqa * sLm[k * (k + 1) / 2 + k];
+        const double r = phf_sqrt(phf_fma(tkk, tkk, wk * wk));
+        const double inv = (r > 0.0) ? 1.0 / r : 0.0;
+        const double cs = (r > 0.0) ? tkk * inv : 1.0;
+        const double sn = wk * inv;
+        __syncthreads();                                          // everybody has read L_kk and w_k
+        if (lane == 0) sLm[k * (k + 1) / 2 + k] = r;
+        for (int i = k + 1 + lane; i < D; i += kBlock) {
+          const double tik = sqa * sLm[i * (i + 1) / 2 + k];
+          const double wi = s_w[i];
+          sLm[i * (i + 1) / 2 + k] = phf_fma(cs, tik, sn * wi);
+          s_w[i] = phf_fma(cs, wi, -(sn * tik));
+        }
+        __syncthreads();                                          // w_{k+1} is final before the next column reads it
+      }
+      sc = phf_exp_fast_k(0.5 * loga, k_exp);
+    }
+    // ---- thinning + sample store ----
+    if (--until_save == 0) {
+      until_save = thin;
+      if (out) {
+        for (int i = lane; i < D; i += kBlock) out[(size_t)i * C] = s_th[i];
+        if (lane == 0) out[(size_t)D * C] = lt;
+        out += row_stride;
+      }
+      if (a.moments && t > a.moments_after) {
+        for (int i = lane; i < D; i += kBlock) {
+          const double x = s_th[i];
+          a.moments[(size_t)i * nch + g] += x;
+          a.moments[(size_t)(D + 1 + i) * nch + g] = phf_fma(x, x, a.moments[(size_t)(D + 1 + i) * nch + g]);
+        }
+        if (lane == 0) {
+          a.moments[(size_t)D * nch + g] += lt;
+          a.moments[(size_t)(2 * D + 1) * nch + g] = phf_fma(lt, lt, a.moments[(size_t)(2 * D + 1) * nch + g]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < D; i += kBlock) { sp[(size_t)i * nch] = s_th[i]; sp[(size_t)(D + 1 + i) * nch] = s_mean[i]; }
+  for (int e = lane; e < TRI; e += kBlock) sp[(size_t)(2 * D + 1 + e) * nch] = sLm[e];
+  if (lane == 0) {
+    sp[(size_t)D * nch] = lt;
+    sp[(size_t)(2 * D + 1 + TRI) * nch] = loga;
+    sp[(size_t)(2 * D + 2 + TRI) * nch] = nacc;
+  }
+}
+
 __global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a) {
   const int ne = a.pts.n_expts;
   const int D = 5 + 2 * ne;
@@ -390,7 +560,7 @@ __global__ __launch_bounds__(64) void hier_generic_log_target_kernel(const phf_h
   const int pair = pair_index[i];
   PHF_KFETCH_V(k_exp, phf_k_exp, 10);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
-  out[i] = phf_hier_log_target(ne, pts.expt_start + (size_t)pair * (ne + 1), pts.ln_conc + (size_t)pair * pts.stride,
+  out[i] = phf_hier_log_target_any(ne, pts.expt_start + (size_t)pair * (ne + 1), pts.ln_conc + (size_t)pair * pts.stride,
                                pts.response + (size_t)pair * pts.stride, theta + i, (int)m, &prior, k_exp, k_log);
 }
 
@@ -456,7 +626,31 @@ int launch_init(const HierArgs& a, hipStream_t stream) {
     default: return FN<8>(__VA_ARGS__);                             \
   }
 
+int launch_wave_advance(const HierArgs& a, hipStream_t stream, bool* launched) {
+  WaveLds w;
+  w.ne = a.pts.n_expts; w.D = 5 + 2 * w.ne; w.tri = w.D * (w.D + 1) / 2; w.stride = a.pts.stride;
+  *launched = false;
+  if (w.bytes() > 160 * 1024) return PHF_OK;                     // dimension too large for LDS: the HBM-state kernel below
+  const int64_t blocks = (int64_t)a.prob.num_problems * a.prob.chains_per_problem;
+  if (blocks > 0x7fffffffLL) return PHF_OK;
+  static bool configured[kMaxDevices] = {};
+  const int dev = current_device();
+  if (!configured[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_wave_advance_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    configured[dev] = true;
+  }
+  hipLaunchKernelGGL(hier_wave_advance_kernel, dim3((unsigned)blocks), dim3(kBlock), w.bytes(), stream, a);
+  *launched = true;
+  return phf_check_launch("phf_hierarchical_advance (wave per chain)");
+}
+
 int launch_generic_advance(HierArgs a, hipStream_t stream) {
+  bool launched = false;
+  const int rc = launch_wave_advance(a, stream, &launched);
+  if (rc != PHF_OK || launched) return rc;
   const int D = 5 + 2 * a.pts.n_expts;
   const size_t lds = (size_t)3 * D * kGenBlock * 8;
   if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "dimension too large for the generic hierarchical kernel");
