@@ -69,6 +69,80 @@ class WriterPool(object):
         return False
 
 
+class StreamWriters(object):
+    """Chain files written WHILE the GPU samples: every file belongs to one of `workers` single-process executors (spawned,
+    torch-free like WriterPool's), which executes its jobs in submission order — create the file with its header lines, then
+    append the rows of each segment as the sampler delivers them.  The text is what one np.savetxt call would have
+    produced.  workers <= 0, or processes that cannot start, fall back to writing in the caller."""
+
+    def __init__(self, workers):
+        ctx = mp.get_context("spawn")
+        self.lanes = [ProcessPoolExecutor(1, mp_context=ctx) for _ in range(max(workers, 0))]
+        self.pending = []
+
+    def _submit(self, key, fn, *args):
+        if self.lanes:
+            try:
+                self.pending.append((self.lanes[hash(key) % len(self.lanes)].submit(fn, *args), fn, args))
+                return
+            except BrokenProcessPool:
+                self._broken()
+        fn(*args)
+
+    def _broken(self):
+        print("chainio.StreamWriters: worker processes unavailable, continuing in the main process")
+        done = []
+        for f, fn, args in self.pending:                      # replay, in order, whatever did not complete
+            try:
+                if f.done() and f.exception() is None:
+                    continue
+            except Exception:
+                pass
+            done.append((fn, args))
+        for lane in self.lanes:
+            lane.shutdown(wait=False)
+        self.lanes, self.pending = [], []
+        for fn, args in done:
+            fn(*args)
+
+    def create(self, path, header_lines, first_rows=None):
+        self._submit(path, _create_file, path, header_lines, first_rows)
+
+    def append(self, path, rows):
+        self._submit(path, _append_rows, path, rows)
+
+    def close(self):
+        try:
+            for f, fn, args in list(self.pending):
+                try:
+                    f.result()
+                except BrokenProcessPool:
+                    self._broken()
+                    break
+        finally:
+            self.pending = []
+            for lane in self.lanes:
+                lane.shutdown()
+            self.lanes = []
+
+
+def _create_file(path, header_lines, first_rows):
+    with open(path, 'w') as outfile:
+        for line in header_lines:
+            outfile.write(line)
+        if first_rows is not None:
+            np.savetxt(outfile, first_rows)
+
+
+def _append_rows(path, rows):
+    with open(path, 'a') as outfile:
+        np.savetxt(outfile, rows)
+
+
+HIERARCHICAL_HEADER = ("# Hill ~ log-logistic(alpha,beta), pIC50 ~ logistic(mu,s)\n",
+                       "# alpha, beta, mu, s, pic50_1, hill_1, pic50_2, hill_2, ..., pic50_Ne, hill_Ne, sigma, log-target\n")
+
+
 def default_write_workers(world=1):
     """host cores of this rank's share, minus the one driving the GPU; at most 16"""
     return max(0, min(16, (os.cpu_count() or 1) // max(world, 1) - 1))
@@ -94,10 +168,12 @@ def drop_burn_in(chain, burn_in_fraction):
 def save_single_level_chain(chain_file, chain, drug, channel, model):
     """PyHillFit.py:865-867.  Columns: model 2 -> pIC50, Hill, sigma, log-target; model 1 -> pIC50, sigma, log-target
     (the reference's header text says "(Hill,pIC50,sigma,log-target)"; its code writes the order used here)."""
+    _create_file(chain_file, (single_level_header(drug, channel, model),), chain)
+
+
+def single_level_header(drug, channel, model):
     cols = "(pIC50,Hill,sigma,log-target)" if model == 2 else "(pIC50,sigma,log-target)"
-    with open(chain_file, 'w') as outfile:
-        outfile.write('# Nonhierarchical MCMC output for {} + {}: {}\n'.format(drug, channel, cols))
-        np.savetxt(outfile, chain)
+    return '# Nonhierarchical MCMC output for {} + {}: {}\n'.format(drug, channel, cols)
 
 
 def save_tempered_chain(chain_file, chain):
@@ -108,10 +184,7 @@ def save_tempered_chain(chain_file, chain):
 def save_hierarchical_chain(chain_file, chain):
     """PyHillFit.py:423-426,514-515 — two header lines, then the FULL chain (burn-in included).
     Parameter order as the code stores it: alpha, beta, mu, s, pIC50_1, Hill_1, ..., sigma, log-target."""
-    with open(chain_file, 'w') as outfile:
-        outfile.write("# Hill ~ log-logistic(alpha,beta), pIC50 ~ logistic(mu,s)\n")
-        outfile.write("# alpha, beta, mu, s, pic50_1, hill_1, pic50_2, hill_2, ..., pic50_Ne, hill_Ne, sigma, log-target\n")
-        np.savetxt(outfile, chain)
+    _create_file(chain_file, HIERARCHICAL_HEADER, chain)
 
 
 def pick_alpha_mu_rows(chain, num_samples, burn, rng):

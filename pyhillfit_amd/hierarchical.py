@@ -245,11 +245,15 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     rng = np.random.RandomState(args.seed)
     rng_pred = np.random.RandomState(1)                                # construct_hierarchical_cdfs.py:12-13
     writers = chainio.WriterPool(getattr(args, "write_workers", 0))    # one pool for the start-point fits and the file formatting
+    chain_streams = chainio.StreamWriters(getattr(args, "write_workers", 0))   # the chain files, written segment by segment
     # one sampler and one HIP stream per Ne group: the groups are independent, their launches overlap on the GPU
     runs = []
-    for ne, members in sorted(groups.items(), reverse=True):
+    ordered = sorted(groups.items(), reverse=True)
+    # all start points first, in one sweep over the worker pool (the file-writer processes start after it)
+    fits = writers.map(bestfit.hierarchical_first_iteration, [(m[2], locs) for _, members in ordered for m in members])
+    for ne, members in ordered:
         packed = PackedHierPoints([m[2] for m in members])
-        theta0 = np.array(writers.map(bestfit.hierarchical_first_iteration, [(m[2], locs) for m in members]))
+        theta0 = np.array(fits[:len(members)]); fits = fits[len(members):]
         Q, C, d = len(members), args.num_chains, 5 + 2 * ne
         s = HierarchicalSampler(packed, list(range(Q)), C, thinning=thinning, seed=args.seed, prior=prior,
                                 problem_ids=[m[3] for m in members], device=device)
@@ -258,6 +262,11 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         s.reserve(total_iterations)
         kept = torch.empty((saved_iterations, Q, d + 1), dtype=torch.float64)
         kept[0] = s.row0[:, :, 0].cpu()
+        files = []
+        for q, m in enumerate(members):                               # chain files grow while the GPU samples (:423-426,514-515)
+            paths = dr.hierarchical_output_dirs_and_chain_file(m[0], m[1], ne)
+            files.append(paths)
+            chain_streams.create(paths[5], chainio.HIERARCHICAL_HEADER, kept[0:1, q].numpy())
         seg = max(thinning, args.segment - args.segment % thinning)
         buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
         curves = None
@@ -266,11 +275,12 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
             curves = PredictiveCurves(Q, device)
             if burn == 0:
                 curves.accumulate(s.row0.unsqueeze(0).contiguous(), cdf_chains(args, C))
-        runs.append(dict(ne=ne, members=members, theta0=theta0, s=s, kept=kept, buf=buf, seg=seg, r=1, curves=curves,
+        runs.append(dict(ne=ne, members=members, theta0=theta0, s=s, kept=kept, buf=buf, seg=seg, r=1, curves=curves, files=files,
                          stream=torch.cuda.Stream(device=device)))
     torch.cuda.synchronize(device)
     start = time.time()
     done = 0
+    to_append = []
     while done < total_iterations:
         k = min(runs[0]["seg"], total_iterations - done) if runs else total_iterations
         pending = []
@@ -283,13 +293,20 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
                 if run["curves"] is not None and first < nr:
                     run["curves"].accumulate(rows[first:], cdf_chains(args, args.num_chains))
                 pending.append((run, nr, rows))
+        for path, block in to_append:          # ... while the GPU works, hand the PREVIOUS segment's rows to the file writers ...
+            chain_streams.append(path, block)
+        to_append = []
         for run, nr, rows in pending:          # ... then collect chain 0 of each pair
             with torch.cuda.stream(run["stream"]):
                 run["kept"][run["r"]:run["r"] + nr] = rows[:, :, :, 0].cpu()
+            for q, paths in enumerate(run["files"]):
+                to_append.append((paths[5], run["kept"][run["r"]:run["r"] + nr, q].numpy()))
             run["r"] += nr
         done += k
     torch.cuda.synchronize(device)
     elapsed = time.time() - start
+    for path, block in to_append:
+        chain_streams.append(path, block)
     total_chains = sum(len(r_["members"]) for r_ in runs) * args.num_chains
     for run in runs:
         ne, members, theta0, s, kept = run["ne"], run["members"], run["theta0"], run["s"], run["kept"]
@@ -298,9 +315,8 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         mean, var = mean.cpu().numpy(), var.cpu().numpy()
         acc = s.acceptance().cpu().numpy()
         for q, (drug, channel, experiments, _, fitted_all) in enumerate(members):
-            d_clean, c_clean, output_dir, chain_dir, figs_dir, chain_file = dr.hierarchical_output_dirs_and_chain_file(drug, channel, ne)
+            d_clean, c_clean, output_dir, chain_dir, figs_dir, chain_file = run["files"][q]
             chain0 = kept[:, q].numpy()
-            writers.submit(chainio.save_hierarchical_chain, chain_file, chain0)                     # :423-426,514-515
             writers.submit(chainio.save_alpha_mu_samples, dr.alpha_mu_downsampling(d_clean, c_clean),
                            chainio.pick_alpha_mu_rows(chain0, args.num_APs, burn, rng), d_clean, c_clean)   # :519-525
             if run["curves"] is not None:
@@ -315,6 +331,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
                 json.dump(summ, f, indent=1)
             summaries.append(summ)
     writers.close()
+    chain_streams.close()
     print("timing [rank {}]: data + start points {:.1f} s, sampling {:.1f} s ({} chains x {} iterations), chain files {:.1f} s".format(
         rank, start - t_begin, elapsed, total_chains, total_iterations, time.time() - start - elapsed))
     return summaries

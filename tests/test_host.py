@@ -191,3 +191,25 @@ def test_writer_pool_reports_a_failed_write(tmp_path):
     w.submit(chainio.save_tempered_chain, str(tmp_path / "no_such_dir" / "x.txt"), np.zeros((2, 2)))
     with pytest.raises(OSError):
         w.close()
+
+
+def test_stream_writers_produce_the_file_of_one_savetxt(tmp_path):
+    """chain files appended segment by segment (by ordered single-process lanes, or in the caller) are byte-identical to
+    writing the whole chain at once"""
+    from pyhillfit_amd import chainio
+    rng = np.random.RandomState(11)
+    chains = {str(tmp_path / ("h%d.txt" % i)): rng.standard_normal((130 + i, 9)) for i in range(7)}
+    for path, chain in chains.items():
+        chainio.save_hierarchical_chain(path + ".whole", chain)
+    for workers in (0, 3):
+        sw = chainio.StreamWriters(workers)
+        for path, chain in chains.items():
+            sw.create(path, chainio.HIERARCHICAL_HEADER, chain[0:1])
+        for lo in range(1, 140, 17):
+            for path, chain in chains.items():
+                if lo < len(chain):
+                    sw.append(path, chain[lo:lo + 17])
+        sw.close()
+        for path in chains:
+            assert open(path, "rb").read() == open(path + ".whole", "rb").read(), (workers, path)
+            os.remove(path)
