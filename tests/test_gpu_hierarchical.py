@@ -114,8 +114,9 @@ def test_hierarchical_cli_and_statistics(gpu, tmp_path):
 
 
 def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):
-    """pairs with more than 8 experiments (the reference's synthetic set: Ne = 50, dim 105, 200 points) run the generic
-    kernel (theta / mean / factor in the HBM state buffer): same bits as the twin, across a launch cut"""
+    """pairs with more than 8 experiments (the reference's synthetic set: Ne = 50, dim 105, 200 points) run one wavefront per
+    chain (state in LDS, lanes = experiments / factor rows): same bits as the twin across a launch cut, and the moments it
+    accumulates on the device are the sums of the rows it saved; two problems of the same pair in one launch"""
     from oracle import c_oracle as co
     from pyhillfit_amd import hierarchical as H
     from pyhillfit_amd.sampler import gamma_table
@@ -127,11 +128,17 @@ def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):
     d = 5 + 2 * ne
     theta0 = np.concatenate([[1., 5., 4., .3], np.tile([4.0, 1.0], ne), [6.0]])
     C, T, thin, adapt = 20, 90, 3, 30
-    s = H.HierarchicalSampler(packed, [0], C, thinning=thin, seed=42, adapt_start=adapt, problem_ids=[3], chain_id_base=100, device=gpu)
-    s.init(theta0, cov_scale=0.01)
+    s = H.HierarchicalSampler(packed, [0, 0], C, thinning=thin, seed=42, adapt_start=adapt, problem_ids=[3, 9], chain_id_base=100, device=gpu)
+    s.init(np.stack([theta0, theta0]), cov_scale=0.01)
+    s.enable_moments(after_iteration=0)
     row0 = s.row0.cpu().numpy()
     chain = np.concatenate([s.advance(k).cpu().numpy() for k in (adapt + 5, T - adapt - 5)])
-    state = s.state.cpu().numpy().reshape(s.S, 1, C)
+    state = s.state.cpu().numpy().reshape(s.S, 2, C)
+    mean, var, n = s.posterior_moments()
+    assert n == T // thin
+    np.testing.assert_allclose(mean.cpu().numpy(), chain.mean(axis=0).transpose(1, 0, 2), rtol=1e-12, atol=1e-12)   # [d+1][Q][C]
+    np.testing.assert_allclose(var.cpu().numpy(), chain.var(axis=0, ddof=1).transpose(1, 0, 2), rtol=1e-7, atol=1e-12)
+    assert not np.array_equal(chain[:, 0], chain[:, 1])                     # different problem ids: different streams
     pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
     gam = gamma_table(T)
     for c in (0, 7, C - 1):
