@@ -119,6 +119,12 @@ def run_single_level(pairs, args, device, rank=0, world=1):
     s.enable_moments(after_iteration=max(burn * thinning - 1, 0))      # moments over exactly the rows that are written
     s.reserve(total_iterations)
     keep_all = args.save_all_chains
+    if keep_all:                                                       # every saved row of every chain stays in HBM until it is written
+        need = saved_iterations * Q * (s.d + 1) * C * 8
+        free = torch.cuda.mem_get_info(device)[0]
+        if need > 0.8 * free:
+            raise SystemExit("--save-all-chains needs {:.1f} GB of device memory for {} pairs x {} chains x {} saved rows, {:.1f} GB are free: "
+                             "select fewer pairs (--drugs/--channels), fewer chains or a larger thinning".format(need / 1e9, Q, C, saved_iterations, free / 1e9))
     d = s.d
     kept = torch.empty((saved_iterations, Q, d + 1, C if keep_all else 1), dtype=torch.float64,
                        device=device if keep_all else "cpu")
