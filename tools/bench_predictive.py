@@ -1,5 +1,5 @@
 """Measurement for SURVEY 8f-4 (posterior-predictive curves): the GPU accumulation on the BASELINE-C4 shape next to the
-reference arithmetic restated with scipy (oracle) on the host.  One JSON line.
+reference's arithmetic (scipy.stats, one sample at a time, restated below) on the host.  One JSON line.
 
     python tools/bench_predictive.py [--pairs 210] [--rows 75001] [--chains 1] [--steps 5]
 """
@@ -13,6 +13,21 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+
+
+def reference_arithmetic(alphas, betas, mus, ss, grid_points=501):
+    """what construct_hierarchical_cdfs.py:32-58 does per saved sample: four scipy.stats calls on the two grids, summed
+    (kept inside this tool: oracle/ is for tests, smoke() and bench.py's cpu_baseline only)"""
+    import scipy.stats as st
+    hill_x, pic50_x = np.linspace(0., 4., grid_points), np.linspace(-2., 12., grid_points)
+    sums = np.zeros((4, grid_points))
+    for a_, b_, m_, s_ in zip(alphas, betas, mus, ss):
+        sums[0] += st.fisk.cdf(hill_x, c=b_, scale=a_, loc=0)
+        sums[2] += st.fisk.pdf(hill_x, c=b_, scale=a_, loc=0)
+        sums[1] += st.logistic.cdf(pic50_x, m_, s_)
+        sums[3] += st.logistic.pdf(pic50_x, m_, s_)
+    sums /= len(alphas)
+    return hill_x, sums[0], pic50_x, sums[1], sums[2], sums[3]
 
 
 def main():
@@ -32,9 +47,8 @@ def main():
     rows[:, :, 1] = 2.1 + torch.rand((a.rows, a.pairs, a.chains), generator=g, device=dev, dtype=torch.float64) * 8
     rows[:, :, 2] = 3.0 + torch.rand((a.rows, a.pairs, a.chains), generator=g, device=dev, dtype=torch.float64) * 6
     rows[:, :, 3] = 0.02 + torch.rand((a.rows, a.pairs, a.chains), generator=g, device=dev, dtype=torch.float64) * 0.5
-    from oracle import pyhillfit_oracle as orc
     s = rows[:max(a.cpu_samples, 2000), 0, :, 0].cpu().numpy()
-    check = orc.predictive_cdfs(s[:2000, 0], s[:2000, 1], s[:2000, 2], s[:2000, 3])
+    check = reference_arithmetic(s[:2000, 0], s[:2000, 1], s[:2000, 2], s[:2000, 3])
     pc2 = PredictiveCurves(1, dev)
     pc2.accumulate(rows[:2000, :1, :, :1].contiguous())
     got = pc2.result(0)
@@ -52,7 +66,7 @@ def main():
     # host: the reference's arithmetic (scipy.stats fisk/logistic cdf+pdf per sample) on a bounded sample, 1 core
     n = a.cpu_samples
     t0 = time.perf_counter()
-    orc.predictive_cdfs(s[:n, 0], s[:n, 1], s[:n, 2], s[:n, 3], block=1)      # block=1: one scipy call per sample, as the reference loops
+    reference_arithmetic(s[:n, 0], s[:n, 1], s[:n, 2], s[:n, 3])
     cpu = time.perf_counter() - t0
     print(json.dumps({"what": "posterior-predictive curves (construct_hierarchical_cdfs.py:32-58)", "pairs": a.pairs,
                       "samples_per_pair": a.rows * a.chains, "grid_points": pc.G, "ms_per_pass": ms,
