@@ -213,3 +213,22 @@ def test_stream_writers_produce_the_file_of_one_savetxt(tmp_path):
         for path in chains:
             assert open(path, "rb").read() == open(path + ".whole", "rb").read(), (workers, path)
             os.remove(path)
+
+
+def test_product_code_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke()/build() and bench.py's cpu_baseline may touch it"""
+    import ast
+    import glob
+    offenders = []
+    for path in glob.glob(os.path.join(REPO, "pyhillfit_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(REPO, "python", "*.py")) \
+            + glob.glob(os.path.join(REPO, "tools", "*.py")):
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            mods = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ""] if isinstance(node, ast.ImportFrom) else []
+            if any(m.split(".")[0] == "oracle" for m in mods):
+                offenders.append(os.path.relpath(path, REPO))
+    assert not offenders, offenders
+    bench = ast.parse(open(os.path.join(REPO, "bench.py")).read())
+    for fn in [n for n in bench.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+        assert uses == (fn.name == "cpu_baseline"), fn.name
