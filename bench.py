@@ -191,6 +191,8 @@ def main():
     for _ in range(a.warmup):
         s.advance(I, out=rows)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    for b_, e_ in ev:                                # events are created lazily at their first record: not inside the timed region
+        b_.record(); e_.record()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
