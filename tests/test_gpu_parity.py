@@ -344,3 +344,42 @@ def test_prior_only_rung_known_answer(gpu, dr):
     sd = torch.sqrt(var.mean(dim=2) + mean.var(dim=2)).cpu().numpy()[:3, 0]
     np.testing.assert_allclose(m, [2.0, 5.0, 7.49975], rtol=0.03)
     np.testing.assert_allclose(sd, [5.0, 10 / np.sqrt(12), np.sqrt(5) * 1.49975], rtol=0.04)
+
+
+def test_thermodynamic_integration_against_the_reference_pipeline(gpu, dr):
+    """G6 = the reference's own pipeline for two pairs and both models: PyHillTemp.do_mcmc on each of the 41 rungs, then
+    compute_bayes_factors.py's per-rung mean of log L(theta; t=1), its trapezium rule and B12 (tests/golden/make_golden_ti.py).
+    Here: one launch for all rungs of a model, 256 chains per rung, the per-rung mean accumulated inside the sampler kernel."""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    path = os.path.join(GOLDEN, "g6_thermodynamic_integration.json")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated (tests/golden/make_golden_ti.py)")
+    with open(path) as f:
+        g6 = json.load(f)
+    for entry in g6:
+        temps = np.array(entry["temperatures"])
+        assert np.array_equal(temps, dr.temperature_ladder()) and len(temps) == 41
+        T, thin = entry["iterations"], 5
+        burn = (T // thin + 1) // 4                                       # PyHillTemp.py:70-71
+        packed = dr.pack_single_level([(entry["drug"], entry["channel"])])
+        E = {}
+        for model in (1, 2):
+            ref = entry["models"][str(model)]
+            s = SingleLevelSampler(packed, model, [0] * len(temps), temps.tolist(), 256, thinning=thin, seed=1,
+                                   reset_mean_at_adapt_start=True, device=gpu)
+            s.init(np.ones(s.d), cov_identity=True, cov_scale=1.0)
+            s.enable_moments(after_iteration=max(burn * thin - 1, 0))
+            s.advance(T, save=False)
+            log_py = s.mean_log_likelihood_t1().mean(dim=1).cpu().numpy()                    # pooled over the chains of a rung
+            want, se = np.array(ref["log_py"]), np.array(ref["batch_means_se"])
+            ratio = np.abs(log_py - want) / (0.01 * np.abs(want) + 4 * se)
+            assert ratio.max() < 1.5 and np.mean(ratio < 1) >= 0.9, (entry["drug"], model, ratio.max(), int(ratio.argmax()))
+            E[model] = float(dr.trapezium_rule(temps, log_py))
+            w = np.zeros(len(temps)); w[1:] += 0.5 * np.diff(temps); w[:-1] += 0.5 * np.diff(temps)   # trapezium weights
+            se_E = float(np.sqrt(np.sum((w * se) ** 2)))
+            assert abs(E[model] - ref["expectation"]) <= 0.01 * abs(ref["expectation"]) + 4 * se_E, (entry["drug"], model, E[model], ref["expectation"], se_E)
+        # the Bayes factor itself (compute_bayes_factors.py:96): same order of magnitude and side of 1 as the reference's
+        log_b12, ref_log_b12 = E[1] - E[2], entry["models"]["1"]["expectation"] - entry["models"]["2"]["expectation"]
+        print("G6 %s-%s: E1 %.3f (ref %.3f)  E2 %.3f (ref %.3f)  log B12 %.3f (ref %.3f)" % (
+            entry["drug"], entry["channel"], E[1], entry["models"]["1"]["expectation"], E[2], entry["models"]["2"]["expectation"], log_b12, ref_log_b12))
+        assert abs(log_b12 - ref_log_b12) < 0.5, (entry["drug"], log_b12, ref_log_b12)
