@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: MH samples/sec of the HIP sampler (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3] [--iters-per-step I]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--iters-per-step I]
 
-A "step" is ONE launch of the sampler kernel advancing every chain of the batch by I Metropolis-Hastings
-iterations (thinned samples of all chains written to HBM).  N=1 workload = BASELINE.json configs[1]:
-Amiodarone-hERG, model 2, 65 536 chains.  With N>1 (launched by torch.distributed.run, one rank per GPU) every
-rank runs its own 65 536-chain shard of the chain batch (weak scaling, no collective in the data path; the
-Philox chain ids continue across ranks), timing is barrier + synchronize on both sides, MAX over ranks.
+A "step" is ONE pass of the sampler over the whole batch: every chain advanced by I Metropolis-Hastings iterations
+(thinned samples of all chains written to HBM).  The N=1 workload is the one BASELINE.json's metric is quoted on,
+configs[2]: ALL 210 Crumb drug x channel pairs, non-hierarchical model 2, 4 096 chains each (c3); c2 / c4 / c5 are the
+other configurations.
+
+--gpus N > 1: this process starts `python -m torch.distributed.run --nproc-per-node N` as a child BEFORE it makes any
+GPU call (one rank per GPU over RCCL; never a re-exec) and passes the child's output and exit code through; under
+torchrun (the driver's way of starting it) RANK / LOCAL_RANK / WORLD_SIZE are read from the environment.  The path
+shards without a data-path collective (python/PyHillFit.py:978-1003 maps pairs over a process pool):
+  weak scaling (default): every rank runs the full workload on its own range of Philox chain ids
+                          (rank r owns chains [r C, (r+1) C) of every pair), value = all ranks' iterations / time;
+  --scaling strong:       the pairs of ONE workload are partitioned over the ranks by cost (distributed.shard_problems).
+RCCL is used outside the timed region only: rank 0 reads and packs the data and broadcasts it, the per-problem
+acceptance summaries are gathered to rank 0.  Timing: barrier + synchronize on both sides, MAX over ranks.
 Rank 0 prints ONE JSON line."""
 import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +36,9 @@ import pyhillfit_amd  # noqa: E402,F401  (sets the ROCm runtime defaults — har
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 64 fp64 FMA lanes x 2 x 2.4 GHz (vector, non-MFMA)
 FP64_VALU_MEASURED_TFLOPS = 58.3  # tools/microbench.hip: v_fma_f64 saturates at 2.25 ns per wave-instruction per SIMD
+
+DEFAULT_CHAINS = {"c2": 65536, "c3": 4096, "c4": 1024, "c5": 1024}
+DEFAULT_ITERS = {"c2": 2000, "c3": 2000, "c4": 500, "c5": 500}
 
 
 def profile_facts(workload, chains, iters, thinning):
@@ -45,51 +59,159 @@ def profile_facts(workload, chains, iters, thinning):
     return out
 
 
-def cpu_baseline(iterations=300000):
-    """rank 0 only, N=1 only: the oracle timed on the host (about 10 s + 5 s of CPU work).
-    'port' = the numpy/scipy restatement of the reference
-    loop (python/PyHillTemp.py:57-125 with numpy's legacy RNG, like the reference), one core, same pair/model.
-    The scalar C twin's rate is reported next to it."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=12.0):
+    """rank 0 only, N=1 only: the oracle timed on the host, one core (the reference loop is single-threaded per pair).
+
+    value = the reference's COST PROFILE: the restated loop (python/PyHillTemp.py:57-125 / PyHillFit.py:830-848) calling
+    scipy.stats.norm.logcdf/logsf per iteration exactly as python/doseresponse.py:244-245 does and
+    RandomState.multivariate_normal / rand as PyHillFit.py:831,834 do.  Next to it: the lean numpy port (scipy.special
+    directly) and the scalar C twin of the kernels."""
     from oracle import pyhillfit_oracle as orc
     from oracle import c_oracle as co
     from pyhillfit_amd import doseresponse as dr
     ne, _, ex = dr.load_crumb_data("Amiodarone", "hERG")
     concs, y = dr.concatenate_experiments(ne, ex)
     pair = orc.PairData(concs, y)
+    th0 = [6.0, 0.8, 8.0]
+    # a short probe sizes the sample to ~budget_s of CPU work
     t0 = time.perf_counter()
-    orc.single_level_chain(2, pair, [6.0, 0.8, 8.0], iterations, 5, orc.LegacyNumpyDraws(25))
+    orc.single_level_chain(2, pair, th0, 2000, 5, orc.LegacyNumpyDraws(25), as_reference=True)
+    rate = 2000 / (time.perf_counter() - t0)
+    iterations = int(max(5000, min(400000, rate * budget_s)) // 5 * 5)
+    t0 = time.perf_counter()
+    orc.single_level_chain(2, pair, th0, iterations, 5, orc.LegacyNumpyDraws(25), as_reference=True)
     dt = time.perf_counter() - t0
+    n_lean = int(max(5000, min(400000, 5 * iterations)) // 5 * 5)
+    t0 = time.perf_counter()
+    orc.single_level_chain(2, pair, th0, n_lean, 5, orc.LegacyNumpyDraws(25))
+    dt_lean = time.perf_counter() - t0
     pk = co.PackedPair(concs, y, 2, 1.0)
-    st = pk.init_state([6.0, 0.8, 8.0], False, 0.05)
+    st = pk.init_state(th0, False, 0.05)
     n_c = 20000000
     gam = co.gamma_table(n_c)
     t0 = time.perf_counter()
     pk.advance(st, 0, n_c, 5, 3000, False, gam, seed=25)
     dtc = time.perf_counter() - t0
     return {"value": iterations / dt, "unit": "MH samples/s", "cores": 1, "kind": "port",
-            "sample": "%d iterations of 1 chain, Amiodarone-hERG model 2, numpy/scipy restatement of the reference loop "
-                      "(oracle/pyhillfit_oracle.py), %.1f s" % (iterations, dt),
+            "sample": "%d iterations of 1 chain, Amiodarone-hERG model 2: restatement of the reference loop with the reference's "
+                      "own library calls (scipy.stats.norm.logcdf/logsf per iteration, RandomState.multivariate_normal/rand; "
+                      "oracle/pyhillfit_oracle.py as_reference=True), %.1f s" % (iterations, dt),
+            "lean_port_value": n_lean / dt_lean,
+            "lean_port_sample": "%d iterations, same loop calling scipy.special.log_ndtr directly, %.1f s" % (n_lean, dt_lean),
             "c_twin_value": n_c / dtc, "c_twin_sample": "%d iterations, scalar C twin (oracle/phf_oracle.c), 1 core, %.1f s" % (n_c, dtc),
-            "host_cpus": os.cpu_count()}
+            "cpu_model": _cpu_model(), "host_cpus": os.cpu_count()}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10, help="untimed steps before the timed ones (the first ~6 launches of a process run ~10 % slow while the clocks settle)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
-    ap.add_argument("--iters-per-step", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps before the timed ones (the first launches of a process run ~10 %% slow while the clocks settle)")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--iters-per-step", type=int, default=None, help="MH iterations per step (default: 2000 c2/c3, 500 c4/c5)")
     ap.add_argument("--chains", type=int, default=None, help="chains per problem (default: 65536 c2, 4096 c3, 1024 c4/c5)")
     ap.add_argument("--thinning", type=int, default=5)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(a):
+    """--gpus N without a torchrun environment: start the N ranks as a fresh child (no GPU call has been made by this
+    process; it is a child process, not an exec) and hand back its exit code."""
+    import torch
+    backend = os.environ.get("PHF_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if backend == "nccl" and have < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for but %d GPU(s) visible (RCCL needs one GPU per rank; "
+                         "PHF_BENCH_BACKEND=gloo rehearses several ranks on one GPU)\n" % (a.gpus, have))
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+class HierarchicalBatch(object):
+    """c4: one sampler per group of pairs with equal numbers of experiments, one HIP stream each, inside a 'step'."""
+
+    def __init__(self, dr, names, C, thinning, chain_id_base, dev, torch):
+        from pyhillfit_amd import hierarchical as H
+        self.torch, self.dev, self.C = torch, dev, C
+        groups = {}
+        for d_, c_ in names:
+            ne, _, ex = dr.load_crumb_data(d_, c_)
+            groups.setdefault(len(ex), []).append(ex)
+        shapes, scales, locs = H.prior_params()
+        self.samplers = []
+        for ne, exs in sorted(groups.items(), reverse=True):
+            hs = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(len(exs))), C, thinning=thinning, seed=25,
+                                       chain_id_base=chain_id_base, device=dev)
+            hs.init(np.array([H.first_iteration(e, locs) for e in exs]), cov_scale=0.01)
+            self.samplers.append(hs)
+        self.adapt_start = max(h.adapt_start for h in self.samplers)
+        self.bytes_per_iter = sum(h.Q * C * 8.0 * (h.d + 1) for h in self.samplers) / thinning
+        self.chains = sum(h.Q * C for h in self.samplers)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.samplers]
+
+    def reserve(self, n):
+        [h.reserve(n) for h in self.samplers]
+
+    def make_rows(self, I):
+        return [self.torch.empty((h.rows_between(0, I), h.Q, h.d + 1, self.C), dtype=self.torch.float64, device=self.dev)
+                for h in self.samplers]
+
+    def advance(self, I, out):
+        # one HIP stream per Ne group: the small groups (Ne = 5, 6: tens of wavefronts) are latency-bound
+        # and hide under the big Ne = 3 launch instead of queueing behind it
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.dev)
+        for h, o, st in zip(self.samplers, out, self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                h.advance(I, out=o)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def acceptance_summary(self):
+        return self.torch.cat([h.acceptance().mean(dim=1) for h in self.samplers])
+
+
+def main():
+    a = parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the sampler has no CPU path)")
     # one rank per GPU over RCCL.  Rehearsal on a single-GPU box: PHF_BENCH_BACKEND=gloo lets several ranks share
@@ -104,69 +226,47 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from pyhillfit_amd import distributed as D
     from pyhillfit_amd import doseresponse as dr
     from pyhillfit_amd.sampler import SingleLevelSampler
-    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    # ONE reader: rank 0 parses the data file, the table reaches the other ranks by broadcast (outside the timed region)
+    D.setup_data_file(os.path.join(REPO, "data", "crumb_dataset.json"))
     dr.define_model(2)
     all_names = [(d, c) for d in dr.drugs for c in dr.channels]
+    C = a.chains or DEFAULT_CHAINS[a.workload]
+    I = a.iters_per_step or DEFAULT_ITERS[a.workload]
     kernel_name = "mh_advance_kernel<2>"
+    per = "per GPU" if a.scaling == "weak" else "in all"
     if a.workload == "c2":
         names = [("Amiodarone", "hERG")]
-        C = a.chains or 65536
-        label = "Amiodarone-hERG, non-hierarchical model 2 (pIC50, Hill, sigma), %d chains per GPU (BASELINE configs[1])" % C
+        label = "Amiodarone-hERG, non-hierarchical model 2 (pIC50, Hill, sigma), %d chains %s (BASELINE configs[1])" % (C, per)
     elif a.workload == "c3":
-        names, C = all_names, a.chains or 4096
-        label = "all %d Crumb drug x channel pairs, non-hierarchical model 2, %d chains each per GPU (BASELINE configs[2])" % (len(names), C)
+        names = all_names
+        label = "all %d Crumb drug x channel pairs, non-hierarchical model 2, %d chains each %s (BASELINE configs[2])" % (len(names), C, per)
     elif a.workload == "c5":
-        names, C = all_names, a.chains or 1024
-        label = "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains per GPU, model 2 (BASELINE configs[4])" % (len(names), C)
+        names = all_names
+        label = "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains %s, model 2 (BASELINE configs[4])" % (len(names), C, per)
     else:
-        names, C = all_names, a.chains or 1024
-        label = "hierarchical model, all Crumb pairs, %d chains each per GPU (BASELINE configs[3])" % C
+        names = all_names
+        label = "hierarchical model, all %d Crumb pairs, %d chains each %s (BASELINE configs[3])" % (len(names), C, per)
+
+    # the partition: weak = this rank's own chain-id range of every problem; strong = this rank's share of the pairs
+    chain_id_base = rank * C if a.scaling == "weak" else 0
+    if a.scaling == "strong" and world > 1:
+        if len(names) >= world:
+            costs = [len(dr.concatenate_experiments(*dr.load_crumb_data(d_, c_)[::2])[0]) for d_, c_ in names]
+            mine = D.shard_problems(costs, world)[rank]
+            names = [names[i] for i in mine]
+        else:                                                         # fewer pairs than GPUs (c2): split the chains
+            chain_id_base, C = D.shard_chains(C, rank, world)
+
     if a.workload == "c4":
-        # hierarchical: one sampler per Ne group, stepped back to back inside a "step"
-        from pyhillfit_amd import hierarchical as H
-        groups = {}
-        for d_, c_ in names:
-            ne, _, ex = dr.load_crumb_data(d_, c_)
-            groups.setdefault(len(ex), []).append(ex)
-        shapes, scales, locs = H.prior_params()
-        samplers = []
-        for ne, exs in sorted(groups.items(), reverse=True):
-            hs = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(len(exs))), C, thinning=a.thinning, seed=25,
-                                       chain_id_base=rank * C, device=dev)
-            hs.init(np.array([H.first_iteration(e, locs) for e in exs]), cov_scale=0.01)
-            samplers.append(hs)
+        s = HierarchicalBatch(dr, names, C, a.thinning, chain_id_base, dev, torch)
         kernel_name = "hier_advance_kernel<Ne=3..6>"
-
-        class Multi(object):
-            d = None
-            adapt_start = max(h.adapt_start for h in samplers)
-            bytes_per_iter = sum(h.Q * C * 8.0 * (h.d + 1) for h in samplers) / a.thinning
-            chains = sum(h.Q * C for h in samplers)
-
-            def reserve(self, n):
-                [h.reserve(n) for h in samplers]
-
-            def make_rows(self, I):
-                return [torch.empty((h.rows_between(0, I), h.Q, h.d + 1, C), dtype=torch.float64, device=dev) for h in samplers]
-
-            streams = [torch.cuda.Stream(device=dev) for _ in samplers]
-
-            def advance(self, I, out):
-                # one HIP stream per Ne group: the small groups (Ne = 5, 6: tens of wavefronts) are latency-bound
-                # and hide under the big Ne = 3 launch instead of queueing behind it
-                cur = torch.cuda.current_stream(dev)
-                for h, o, st in zip(samplers, out, self.streams):
-                    st.wait_stream(cur)
-                    with torch.cuda.stream(st):
-                        h.advance(I, out=o)
-                for st in self.streams:
-                    cur.wait_stream(st)
-        s = Multi()
-        Q = len(names)
     else:
-        packed = dr.pack_single_level(names)
+        packed = dr.pack_single_level(names) if rank == 0 or a.scaling == "strong" else None
+        if a.scaling == "weak":
+            packed = D.broadcast_packed_points(packed, dev)           # RCCL: "scatter the dataset", a few tens of KB
         if a.workload == "c5":
             ladder = dr.temperature_ladder(31)                           # 32 rungs (BASELINE configs[4]); reference ladder has 41
             pair_index = [p for p in range(len(names)) for _ in ladder]
@@ -174,8 +274,7 @@ def main():
         else:
             pair_index, temps = list(range(len(names))), [1.0] * len(names)
         Q = len(pair_index)
-        # weak scaling: rank r owns chains [r*C, (r+1)*C) of every problem
-        s = SingleLevelSampler(packed, 2, pair_index, temps, C, thinning=a.thinning, seed=25, chain_id_base=rank * C,
+        s = SingleLevelSampler(packed, 2, pair_index, temps, C, thinning=a.thinning, seed=25, chain_id_base=chain_id_base,
                                reset_mean_at_adapt_start=(a.workload == "c5"), device=dev)
         if a.workload == "c5":
             s.init(np.ones(3), cov_identity=True, cov_scale=1.0)          # PyHillTemp.py:63,80 start
@@ -184,7 +283,7 @@ def main():
         s.bytes_per_iter = float(Q) * C * 8 * (s.d + 1) / a.thinning      # 8(d+1)/thin B per iteration
         s.chains = Q * C
         s.make_rows = lambda I: torch.empty((s.rows_between(0, I), Q, s.d + 1, C), dtype=torch.float64, device=dev)
-    I = a.iters_per_step
+        s.acceptance_summary = lambda: s.acceptance().mean(dim=1)
     s.reserve((a.warmup + a.steps) * I)
     rows = s.make_rows(I)
 
@@ -209,17 +308,24 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     gc.enable()
+    chains_total = float(s.chains)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        ct = torch.tensor([chains_total], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+        chains_total = float(ct.item())
     kernel_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))   # HIP events on the launch stream
     for r_ in (rows if isinstance(rows, list) else [rows]):
         assert torch.isfinite(r_).all()
+    # "gather samples/summaries" (RCCL, outside the timed region): per-problem mean acceptance of every rank to rank 0
+    acc = s.acceptance_summary().reshape(-1, 1)
+    gathered = D.gather_rows(acc if backend == "nccl" or world == 1 else acc.cpu())
 
     if rank == 0:
-        samples_per_step = float(s.chains) * I * world
-        value = samples_per_step * a.steps / dt
+        acc_all = np.concatenate(gathered)
+        value = chains_total * I * a.steps / dt
         alg_bytes = s.bytes_per_iter * I
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         prof = profile_facts(a.workload, s.chains, I, a.thinning)
@@ -228,9 +334,11 @@ def main():
         out = {
             "metric": "MCMC samples/sec (whole node)", "value": value, "unit": "MH samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "real Crumb dose-response rows (data/crumb_dataset.json), synthetic chain batch",
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "real Crumb dose-response rows (data/crumb_dataset.json), synthetic chain batch",
             "config": {"workload": label, "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": s.chains,
-                       "adaptation": "on (steps start after iteration %d > adapt_start %d)" % (a.warmup * I, s.adapt_start)},
+                       "chains_all_gpus": chains_total,
+                       "adaptation": "on (steps start after iteration %d > adapt_start %d)" % (a.warmup * I, s.adapt_start),
+                       "mean_acceptance": float(acc_all.mean()), "problems_reporting": int(acc_all.shape[0])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": prof.get("traffic_bytes_per_launch"), "kernel": kernel_name, "kernel_ms": kernel_ms,
                          "traffic_source": prof.get("source"),

@@ -145,10 +145,34 @@ def log_likelihood(model, pair, params, t):
     return t * (lo + hi - pair.pi_bit - n_log_sigma - sse)
 
 
-def log_target(model, pair, params, t):
+def log_likelihood_as_reference(model, pair, params, t):
+    """The same likelihood through the reference's own library calls — scipy.stats.norm.logcdf(0, pred, sigma) and
+    .logsf(100, pred, sigma) on the masked predictions, doseresponse.py:218-219 / :244-245 — so that a loop built on it has the
+    reference's COST profile (the generic-distribution argument checking of scipy.stats is ~60 % of a reference
+    log_target call).  Values equal log_likelihood() to rounding (tests/test_oracle_golden.py)."""
+    import scipy.stats as st
+    if t == 0:
+        return 0
+    if model == 1:
+        pic50, sigma = params
+        hill = 1
+    else:
+        pic50, hill, sigma = params
+    if sigma <= SIGMA_FLOOR:
+        return -np.inf
+    pred = hill_curve(pair.concs, hill, ic50_of(pic50))
+    lo = np.sum(st.norm.logcdf(0, pred[pair.is0], sigma))
+    hi = np.sum(st.norm.logsf(100, pred[pair.is100], sigma))
+    n_log_sigma = len(pair.responses[pair.other]) * np.log(sigma)
+    sse = np.sum((pair.responses[pair.other] - pred[pair.other]) ** 2 / (2. * sigma ** 2))
+    return t * (lo + hi - pair.pi_bit - n_log_sigma - sse)
+
+
+def log_target(model, pair, params, t, as_reference=False):
     """doseresponse.py:187-189 — likelihood is always evaluated; only it is tempered."""
     with np.errstate(all="ignore"):
-        return log_likelihood(model, pair, params, t) + log_prior(model, params)
+        lik = log_likelihood_as_reference if as_reference else log_likelihood
+        return lik(model, pair, params, t) + log_prior(model, params)
 
 
 def temperature_ladder(n=LADDER_N, c=LADDER_C):
@@ -272,11 +296,12 @@ def adaptive_mh(target, theta0, cov0, iterations, thinning, adapt_start, draws,
     return chain, {"loga": loga, "acceptance": acceptance, "mean": mean, "cov": cov}
 
 
-def single_level_chain(model, pair, theta0, iterations, thinning, draws, temperature=1):
-    """PyHillFit.py:748-751,787,796-856: cov0 = 0.05*diag|theta0|, adapt after 1000*d."""
+def single_level_chain(model, pair, theta0, iterations, thinning, draws, temperature=1, as_reference=False):
+    """PyHillFit.py:748-751,787,796-856: cov0 = 0.05*diag|theta0|, adapt after 1000*d.
+    as_reference: evaluate the likelihood through scipy.stats like the reference (bench.py's cpu_baseline)."""
     theta0 = np.asarray(theta0, float)
     cov0 = 0.05 * np.diag(np.abs(theta0))
-    return adaptive_mh(lambda th: log_target(model, pair, th, temperature), theta0, cov0, iterations, thinning,
+    return adaptive_mh(lambda th: log_target(model, pair, th, temperature, as_reference), theta0, cov0, iterations, thinning,
                        1000 * len(theta0), draws)
 
 

@@ -318,8 +318,7 @@ def _clean(name):
 
 def _mk(*dirs):
     for d in dirs:
-        if not os.path.exists(d):
-            os.makedirs(d)
+        os.makedirs(d, exist_ok=True)       # ranks of one run share leaf directories: no exists()-then-create race
 
 
 def hierarchical_output_dirs_and_chain_file(drug, channel, Ne=0):

@@ -1,6 +1,7 @@
 """Host-side logic (no GPU): data loading/packing mirror of python/doseresponse.py against the reference's
 own loader output (tests/golden/g4_pairs.json), path helpers, gamma table."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -158,6 +159,33 @@ def test_bench_profile_facts_only_apply_to_the_measured_launch_shape():
     assert 500 < f["flop_per_iteration"] < 2000 and f["traffic_bytes_per_launch"] > 8e8
     assert "traffic_bytes_per_launch" not in bench.profile_facts("c2", 65536, 1000, 5)
     assert bench.profile_facts("zz", 1, 1, 1) == {}
+
+
+def test_bench_gpus_n_starts_n_ranks_as_a_child(monkeypatch):
+    """`bench.py --gpus N` outside torchrun hands over to `torch.distributed.run --nproc-per-node N` as a CHILD process
+    (before any GPU call, never an exec) and passes its exit code through; with fewer GPUs than ranks it refuses."""
+    import bench
+    import torch
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--workload", "c3"])
+    a = bench.parse_args(sys.argv[1:])
+    assert a.workload == "c3" and bench.parse_args([]).workload == "c3"      # the metric's own config is the default
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    assert bench.spawn_ranks(a) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == sys.argv[1:]
+    assert os.path.basename(cmd[-7]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    seen.clear()
+    assert bench.spawn_ranks(a) == 2 and not seen                            # one GPU, four RCCL ranks: refused, nothing started
+    monkeypatch.setenv("PHF_BENCH_BACKEND", "gloo")                          # rehearsal: ranks share the one GPU
+    assert bench.spawn_ranks(a) == 7 and seen
 
 
 def test_writer_pool_files_equal_the_synchronous_ones(tmp_path):

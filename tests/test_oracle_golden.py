@@ -57,6 +57,19 @@ def test_log_target_single_level(golden_meta, oracle_pair):
     assert orc.log_target(2, amio, np.array([6., 1., 5.]), 0) == pytest.approx(1.9037293660251158, rel=1e-14)
 
 
+def test_reference_cost_profile_likelihood_is_the_same_function(golden_meta, oracle_pair):
+    """bench.py's cpu_baseline times the loop through scipy.stats.norm.logcdf/logsf, the calls of doseresponse.py:244-245;
+    it must be the same function as the oracle's lean form (every 7th G1 row, both models, all temperatures, edges)."""
+    g = np.load(os.path.join(GOLDEN, "g1_log_target.npz"))
+    pairs = [oracle_pair(m["drug"], m["channel"]) for m in golden_meta["g1_pairs"]]
+    idx = np.arange(0, len(g["target"]), 7)
+    got = np.empty(len(idx))
+    for j, k in enumerate(idx):
+        model, t, th = int(g["model"][k]), float(g["t"][k]), g["theta"][k]
+        got[j] = orc.log_target(model, pairs[int(g["pair"][k])], th if model == 2 else th[[0, 2]], t, as_reference=True)
+    _same(got, g["target"][idx], rtol=1e-12)
+
+
 def test_hierarchical_prior_params():
     g = np.load(os.path.join(GOLDEN, "g2_hier_target.npz"))
     shapes, scales, locs = orc.hierarchical_prior_params()
