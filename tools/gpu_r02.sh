@@ -8,8 +8,8 @@ R=$GRAFT_REPO_ROOT
 STEPS="${PHF_STEPS:-smoke pytest bench c2 c4 c5 two_ranks rocprof pmc}"
 want() { [[ " $STEPS " == *" $1 "* ]]; }
 step() { local name=$1 to=$2; shift 2
-  echo "== $name"; timeout -k 10 "$to" "$@" > "gpurun_out/$name.log" 2>&1; local rc=$?
-  echo "$name rc=$rc"; tail -n 4 "gpurun_out/$name.log" | cut -c1-1200
+  echo "== $name"; timeout -k 10 "$to" "$@" > "$R/gpurun_out/$name.log" 2>&1; local rc=$?
+  echo "$name rc=$rc"; tail -n 4 "$R/gpurun_out/$name.log" | cut -c1-1200
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out - stopping"; exit 1; fi; return $rc; }
 if want smoke; then step smoke 300 python -c 'import __graft_entry__ as g; g.build(); g.smoke()' || exit 1; fi
 if want pytest; then step pytest_gpu 1100 python -m pytest tests -m gpu -q --timeout 900 ${PHF_PYTEST_ARGS:-}; fi
