@@ -6,4 +6,17 @@ char* phf_error_buffer() {
   return buf;
 }
 
+long long phf_simd_count() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 1024; }
+  if (dev < 0 || dev >= 64) return 1024;
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+    cached[dev] = 4 * cus;
+  }
+  return cached[dev];
+}
+
 extern "C" const char* phf_last_error(void) { return phf_error_buffer(); }

@@ -9,6 +9,9 @@
 // traffic at all.  HBM sees the state once per launch and the thinned samples.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
+#define PHF_FMA_K_AS_BUILTIN 1   // one wavefront per SIMD: every s_nop is a lost issue slot (phf_math.h)
 #include "../../include/pyhillfit_amd.h"
 #include "phf_common.h"
 #include "phf_hier_model.h"
@@ -34,12 +37,21 @@ struct HierArgs {
   double* row0;
 };
 
-// LDS layout: [tri][64] factor, then ln_conc[stride], response[stride], expt_start[NE+1]
-template <int NE>
+// LDS layout: [tri - NREG][64] factor elements, then ln_conc[stride], response[stride], expt_start[NE+1].
+// WPS = wavefronts per SIMD the kernel is built for.  1: the whole factor in LDS (34..78 KB per wavefront: at most 4 wavefronts
+// per CU) and all 512 registers for the iteration.  2: eight wavefronts must share a CU's 160 KB, so only kLdsElems2 = 39
+// elements of the factor (19.5 KB) stay in LDS and the first NREG = tri - 39 live in registers, inside a 256-register budget:
+// two wavefronts per SIMD hide each other's fp64 latency (measured on a lone wavefront: one instruction per ~3.8 ns against
+// 2.1-2.25 ns when the SIMD is shared).  Same arithmetic, same order: both builds are bit-identical to each other and the twin.
+constexpr int kLdsElems2 = 39;
+constexpr int kLdsPointBytes2 = 160 * 1024 / 8 - kLdsElems2 * kBlock * 8;        // 512 B left for the pair's points
+template <int NE, int WPS>
 struct Lds {
   static constexpr int dim = 5 + 2 * NE;
   static constexpr int tri = dim * (dim + 1) / 2;
-  static size_t bytes(int stride) { return (size_t)tri * kBlock * 8 + (size_t)stride * 16 + (NE + 1) * 4 + 8; }
+  static constexpr int nreg = (WPS == 2) ? (tri > kLdsElems2 ? tri - kLdsElems2 : 0) : 0;
+  static size_t point_bytes(int stride) { return (size_t)stride * 16 + (NE + 1) * 4 + 8; }
+  static size_t bytes(int stride) { return (size_t)(tri - nreg) * kBlock * 8 + point_bytes(stride); }
 };
 
 template <int NE>
@@ -55,12 +67,15 @@ __device__ __forceinline__ void stage(const phf_hier_points& pts, int pair, doub
 
 // The whole launch of one wavefront.  FIXED_N > 0: every experiment of the pair has exactly FIXED_N points, known at compile
 // time (the point loops unroll: straight-line iteration); 0: run-time experiment boundaries.
-template <int NE, int FIXED_N>
+template <int NE, int FIXED_N, int NREG>
 __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_mem, const double* s_lc, const double* s_y,
                                                   const int* s_es, int q, int c) {
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
-  double* sL = s_mem + threadIdx.x;                       // element e of this lane's factor: sL[e * 64]
+  double* sL = s_mem + threadIdx.x;                       // element e >= NREG of this lane's factor: sL[(e - NREG) * 64]
+  double Lr[NREG > 0 ? NREG : 1];                         // elements e < NREG: registers (every index below is a constant)
+#define PHF_LGET(e) (((e) < NREG) ? Lr[((e) < NREG) ? (e) : 0] : sL[(((e) < NREG) ? 0 : (e) - NREG) * kBlock])
+#define PHF_LSET(e, v) do { if ((e) < NREG) Lr[((e) < NREG) ? (e) : 0] = (v); else sL[(((e) < NREG) ? 0 : (e) - NREG) * kBlock] = (v); } while (0)
   const int C = a.prob.chains_per_problem;
   const uint32_t pid = a.prob.problem_id[q];
   const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
@@ -75,7 +90,8 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   double lt = sp[(size_t)D * nchains];
 #pragma unroll
   for (int i = 0; i < D; ++i) mean[i] = sp[(size_t)(D + 1 + i) * nchains];
-  for (int e = 0; e < TRI; ++e) sL[e * kBlock] = sp[(size_t)(2 * D + 1 + e) * nchains];
+#pragma unroll
+  for (int e = 0; e < TRI; ++e) PHF_LSET(e, sp[(size_t)(2 * D + 1 + e) * nchains]);
   double loga = sp[(size_t)(2 * D + 1 + TRI) * nchains];
   double nacc = sp[(size_t)(2 * D + 2 + TRI) * nchains];
   PHF_KFETCH_V(k_exp, phf_k_exp, 10);
@@ -94,9 +110,9 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
     const double log_u = phf_hier_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, z, 1);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      double v = sL[(i * (i + 1) / 2 + i) * kBlock] * z[i];
+      double v = PHF_LGET(i * (i + 1) / 2 + i) * z[i];
 #pragma unroll
-      for (int k = i - 1; k >= 0; --k) v = phf_fma(sL[(i * (i + 1) / 2 + k) * kBlock], z[k], v);
+      for (int k = i - 1; k >= 0; --k) v = phf_fma(PHF_LGET(i * (i + 1) / 2 + k), z[k], v);
       star[i] = phf_fma(sc, v, th[i]);
     }
     // ---- target, accept (:486-492) ----
@@ -121,16 +137,16 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
 #pragma unroll
       for (int k = 0; k < D; ++k) {                        // Givens sweep down column k
-        const double tkk = sqa * sL[(k * (k + 1) / 2 + k) * kBlock];
+        const double tkk = sqa * PHF_LGET(k * (k + 1) / 2 + k);
         const double r = phf_sqrt(phf_fma(tkk, tkk, w[k] * w[k]));
         const double inv = (r > 0.0) ? 1.0 / r : 0.0;
         const double cs = (r > 0.0) ? tkk * inv : 1.0;
         const double sn = w[k] * inv;
-        sL[(k * (k + 1) / 2 + k) * kBlock] = r;
+        PHF_LSET(k * (k + 1) / 2 + k, r);
 #pragma unroll
         for (int i = k + 1; i < D; ++i) {
-          const double tik = sqa * sL[(i * (i + 1) / 2 + k) * kBlock];
-          sL[(i * (i + 1) / 2 + k) * kBlock] = phf_fma(cs, tik, sn * w[i]);
+          const double tik = sqa * PHF_LGET(i * (i + 1) / 2 + k);
+          PHF_LSET(i * (i + 1) / 2 + k, phf_fma(cs, tik, sn * w[i]));
           w[i] = phf_fma(cs, w[i], -(sn * tik));
         }
       }
@@ -162,17 +178,21 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   sp[(size_t)D * nchains] = lt;
 #pragma unroll
   for (int i = 0; i < D; ++i) sp[(size_t)(D + 1 + i) * nchains] = mean[i];
-  for (int e = 0; e < TRI; ++e) sp[(size_t)(2 * D + 1 + e) * nchains] = sL[e * kBlock];
+#pragma unroll
+  for (int e = 0; e < TRI; ++e) sp[(size_t)(2 * D + 1 + e) * nchains] = PHF_LGET(e);
   sp[(size_t)(2 * D + 1 + TRI) * nchains] = loga;
   sp[(size_t)(2 * D + 2 + TRI) * nchains] = nacc;
+#undef PHF_LGET
+#undef PHF_LSET
 }
 
-template <int NE>
-__global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) {
+template <int NE, int WPS>
+__global__ __launch_bounds__(kBlock, WPS) void hier_advance_kernel(const HierArgs a) {
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
+  constexpr int NREG = Lds<NE, WPS>::nreg;
   extern __shared__ double s_mem[];
-  double* s_lc = s_mem + (size_t)TRI * kBlock;
+  double* s_lc = s_mem + (size_t)(TRI - NREG) * kBlock;
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
   const int q = blockIdx.x / a.blocks_per_problem;
@@ -185,8 +205,8 @@ __global__ __launch_bounds__(kBlock) void hier_advance_kernel(const HierArgs a) 
   bool four_each = true;
 #pragma unroll
   for (int i = 1; i <= NE; ++i) four_each = four_each && (a.pts.expt_start[(size_t)pair * (NE + 1) + i] == 4 * i);
-  if (four_each) hier_advance_body<NE, 4>(a, s_mem, s_lc, s_y, s_es, q, c);
-  else hier_advance_body<NE, 0>(a, s_mem, s_lc, s_y, s_es, q, c);
+  if (four_each) hier_advance_body<NE, 4, NREG>(a, s_mem, s_lc, s_y, s_es, q, c);
+  else hier_advance_body<NE, 0, NREG>(a, s_mem, s_lc, s_y, s_es, q, c);
 }
 
 template <int NE>
@@ -589,22 +609,45 @@ int current_device() {
   return (dev >= 0 && dev < kMaxDevices) ? dev : 0;
 }
 
-template <int NE>
-int launch_advance(const HierArgs& a, hipStream_t stream) {
-  const size_t lds = Lds<NE>::bytes(a.pts.stride);
+// Which build runs: the one-wavefront-per-SIMD build, always, unless PHF_HIER_WPS=2 in the environment asks for the
+// two-wavefronts-per-SIMD one (Ne <= kMaxNe2, points fitting beside 39 factor elements in a 20 KB LDS slice).  Measured on
+// C4 (round 2, profiles/r02/c4_wps_ab.txt): the 256-register build spills ~2 KB per lane (the target alone wants ~260
+// registers) and its scratch traffic makes it SLOWER (38.3 ms per 500 iterations against 29.6), so it is kept for the
+// bit-identity test and for A/B timing only.
+constexpr int kMaxNe2 = 4;
+
+int hier_wps_override() {                                         // read at every launch: tests switch it between launches
+  const char* e = getenv("PHF_HIER_WPS");
+  return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
+}
+
+template <int NE, int WPS>
+int launch_advance_wps(const HierArgs& a, hipStream_t stream) {
+  const size_t lds = Lds<NE, WPS>::bytes(a.pts.stride);
   if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
   static bool configured[kMaxDevices] = {};                      // the attribute is per function AND per device
   const int dev = current_device();
   if (!configured[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_advance_kernel<NE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_advance_kernel<NE, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
       (void)hipGetLastError();
     }
     configured[dev] = true;
   }
   const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
-  hipLaunchKernelGGL(hier_advance_kernel<NE>, grid, block, lds, stream, a);
+  hipLaunchKernelGGL((hier_advance_kernel<NE, WPS>), grid, block, lds, stream, a);
   return phf_check_launch("phf_hierarchical_advance");
+}
+
+template <int NE>
+int launch_advance(const HierArgs& a, hipStream_t stream) {
+  if constexpr (NE <= kMaxNe2) {
+    const bool fits = Lds<NE, 2>::point_bytes(a.pts.stride) <= (size_t)kLdsPointBytes2;
+    const int force = hier_wps_override();
+    const bool two = fits && force == 2;
+    if (two) return launch_advance_wps<NE, 2>(a, stream);
+  }
+  return launch_advance_wps<NE, 1>(a, stream);
 }
 
 template <int NE>

@@ -85,8 +85,21 @@ typedef const double __attribute__((address_space(4))) * phf_ktab4;
     for (int phf_i_ = 0; phf_i_ < (n); ++phf_i_) name##_buf[phf_i_] = phf_p_[phf_i_];       \
   }                                                                                         \
   const phf_ktab name = (have) ? (resident) : name##_buf
+/* SGPR-resident coefficient.  Inline asm pins the 3-operand form with the SGPR pair as the addend (left to itself hipcc copies
+ * some coefficients to VGPRs and uses v_fmac: more VALU instructions, which is what a SIMD shared by two wavefronts pays for),
+ * at the price of an `s_nop` between dependent steps (see PHF_FMA_KV).  A translation unit whose wavefronts run one per SIMD,
+ * where an s_nop costs as much as an fma, defines PHF_FMA_K_AS_BUILTIN before including this header (phf_hierarchical.hip:
+ * 486 -> 248 scalar instructions per iteration of the Ne = 3 kernel, VALU count unchanged). */
+#if defined(PHF_FMA_K_AS_BUILTIN)
+#define PHF_FMA_K(p, t, c) __builtin_fma((p), (t), (c))
+#else
 #define PHF_FMA_K(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "s"(c)); phf_r_; })
-#define PHF_FMA_KV(p, t, c) __extension__({ double phf_r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(phf_r_) : "v"(p), "v"(t), "v"(c)); phf_r_; })
+#endif
+/* VGPR-resident coefficient: the compiler itself emits the 3-operand v_fma_f64 here (the coefficient register stays live, so
+ * v_fmac cannot overwrite it), and — unlike around an inline-asm statement, whose instruction class the hazard recogniser cannot
+ * see — it inserts no `s_nop` between two dependent steps: 540 s_nop per iteration of the Ne = 3 hierarchical kernel, ~70 of the
+ * single-level one, each a full issue slot of a wavefront that has its SIMD to itself. */
+#define PHF_FMA_KV(p, t, c) __builtin_fma((p), (t), (c))
 #else
 #define PHF_KFETCH_UNLESS(name, have, resident, table, n) const phf_ktab name = (have) ? (resident) : (table)
 #define PHF_KFETCH(name, table, n) const phf_ktab name = (table)

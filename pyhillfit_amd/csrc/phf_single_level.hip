@@ -378,20 +378,6 @@ __global__ void debug_philox_kernel(int64_t n, const uint32_t* ck, uint32_t* out
   for (int k = 0; k < 4; ++k) out[4 * i + k] = r.w[k];
 }
 
-// SIMDs of the current device (4 per compute unit on CDNA: 1 024 on MI355X), looked up once per device
-int64_t simd_count() {
-  static int cached[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 1024; }
-  if (dev < 0 || dev >= 64) return 1024;
-  if (cached[dev] == 0) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
-    cached[dev] = 4 * cus;
-  }
-  return cached[dev];
-}
-
 int check_common(const phf_points* pts, const phf_problems* prob, int model) {
   if (!pts || !prob) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null points/problems");
   if (model != 1 && model != 2) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "model must be 1 or 2");
@@ -445,7 +431,7 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
   const dim3 grid((unsigned)(a.blocks_per_problem * prob->num_problems)), block(kBlock);
   const size_t lds = (size_t)pts->stride * 24;
-  const bool lone = (int64_t)grid.x <= simd_count();      // one wavefront per SIMD at most: let it have the whole register file
+  const bool lone = (int64_t)grid.x <= phf_simd_count();      // one wavefront per SIMD at most: let it have the whole register file
   hipStream_t s = (hipStream_t)stream;
   if (cfg->model == 1) {
     if (moments) hipLaunchKernelGGL((mh_advance_kernel<1, true, 2>), grid, block, lds, s, a);

@@ -83,6 +83,47 @@ def test_hier_chains_bit_identical_to_cpu_twin(names, gpu, oracle_pair):
     assert 0.01 < float(s.acceptance().mean()) < 0.95
 
 
+@pytest.mark.parametrize("names", [[("Amiodarone", "hERG"), ("Verapamil", "hERG")],            # Ne = 3: 4+4+4 points (straight-line body) and 5+5+4
+                                   [("Amiodarone", "Nav1.5-peak"), ("Amiodarone", "Kv4.3")]])  # Ne = 4: 4+4+4+1 and 4+4+4+3
+def test_two_waves_per_simd_build_is_bit_identical(names, gpu, oracle_pair, monkeypatch):
+    """hier_advance_kernel<Ne, 2> (256 registers, part of the factor in registers, 8 wavefronts per CU) against
+    hier_advance_kernel<Ne, 1> (512 registers, whole factor in LDS) and the twin: same chain, same final state, bit for bit;
+    PHF_HIER_WPS forces the build whatever the launch size (big launches choose <Ne, 2> by themselves)"""
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import gamma_table
+    shapes, scales, locs = H.prior_params()
+    pairs = [oracle_pair(d, c) for d, c in names]
+    packed = H.PackedHierPoints([p.experiments for p in pairs])
+    ne = packed.n_expts
+    d = 5 + 2 * ne
+    theta0 = np.array([np.concatenate([[1., 5., 6., .3], np.tile([6.0, 0.8], ne), [8.0]]),
+                       np.concatenate([[1.2, 4., 5., .4], np.tile([4.5, 1.1], ne), [5.0]])])
+    C, T, thin, adapt = 200, 600, 5, 140
+    got = {}
+    for wps in ("1", "2"):
+        monkeypatch.setenv("PHF_HIER_WPS", wps)
+        s = H.HierarchicalSampler(packed, [0, 1], C, thinning=thin, seed=31337, adapt_start=adapt, problem_ids=[4, 5], chain_id_base=64, device=gpu)
+        s.init(theta0, cov_scale=0.01)
+        s.enable_moments(after_iteration=adapt)
+        chain = np.concatenate([s.advance(k).cpu().numpy() for k in (adapt + 7, T - adapt - 7)])
+        mean, var, n = s.posterior_moments()
+        got[wps] = (chain, s.state.cpu().numpy().reshape(s.S, 2, C), mean.cpu().numpy())
+    monkeypatch.delenv("PHF_HIER_WPS")
+    assert np.array_equal(got["1"][0], got["2"][0]) and np.array_equal(got["1"][1], got["2"][1]) and np.array_equal(got["1"][2], got["2"][2])
+    chain, state, mean = got["2"]
+    keep = chain[(adapt // thin):]                                            # rows saved at t > adapt
+    np.testing.assert_allclose(mean, keep.mean(axis=0).transpose(1, 0, 2), rtol=1e-12, atol=1e-12)
+    gam = gamma_table(T)
+    for q in range(2):
+        pk = co.PackedHierPair(pairs[q].experiments, shapes, scales, locs)
+        for c in (0, 63, 64, C - 1):
+            st = pk.init_state(theta0[q], 0.01)
+            rows = pk.advance(st, 0, T, thin, adapt, gam, seed=31337, chain_id=64 + c, problem_id=4 + q)
+            assert np.array_equal(chain[:, q, :, c], rows), (q, c)
+            assert np.array_equal(state[:, q, c], st), (q, c)
+
+
 def test_hierarchical_cli_and_statistics(gpu, tmp_path):
     """python PyHillFit.py --hierarchical: files where the reference puts them, (alpha, mu) consistent with the
     reference's stored samples (chaste/samples, coarse: 500 draws of an unseeded run)"""
