@@ -47,7 +47,7 @@ PHF_HD void phf_batch_recip(double* v, int n) {
   pre[0] = v[0];
   PHF_UNROLL
   for (int i = 1; i < n; ++i) pre[i] = pre[i - 1] * v[i];
-  double inv = 1.0 / pre[n - 1];
+  double inv = phf_rcp(pre[n - 1]);
   PHF_UNROLL
   for (int i = n - 1; i > 0; --i) {
     const double vi = v[i];
@@ -93,7 +93,7 @@ PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl
   const double ga = phf_exp_capped_k(-0.5 * a * a, kx, 1), gb = phf_exp_capped_k(-0.5 * b * b, kx, 1);
   const double m = 1.0 - 0.5 * phf_fma(ea, ga, eb * gb);
   const phf_logred lr = phf_log_reduce(m);
-  return phf_log_from_recip(m, lr, 1.0 / (2.0 + lr.f), kl);
+  return phf_log_from_recip(m, lr, phf_rcp(2.0 + lr.f), kl);
 }
 
 /* n_expts must be a compile-time constant at the call site (PHF_HIER_MAX_EXPTS at most) when theta lives in registers. */
@@ -140,14 +140,14 @@ PHF_HD double phf_hier_log_target_n(int n_expts, int fixed_n, const int* expt_st
       const phf_ktab ke = k_exp;
       const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
       const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke, 0);
-      const double inv = 1.0 / (d0 * d1);
+      const double inv = phf_rcp(d0 * d1);
       const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
       const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
       trunc += phf_trunc_terms_x2(pred0, pred1, inv_s, k_exp, k_log);
     }
     for (; j < jend; ++j) {
-      const double w = 1.0 / (1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
+      const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
       const double pred = phf_fma(-100.0, w, 100.0);
       const double r = y[j] - pred;
       sse = phf_fma(r, r, sse);
@@ -244,14 +244,14 @@ PHF_HD void phf_hier_experiment_terms(const phf_hier_common* c, double pic50, do
     const phf_ktab ke = k_exp;
     const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
     const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke, 0);
-    const double inv = 1.0 / (d0 * d1);
+    const double inv = phf_rcp(d0 * d1);
     const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
     const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
     sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
     trunc += phf_trunc_terms_x2(pred0, pred1, c->inv_s, k_exp, k_log);
   }
   for (; j < n; ++j) {
-    const double w = 1.0 / (1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
+    const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
     const double pred = phf_fma(-100.0, w, 100.0);
     const double r = y[j] - pred;
     sse = phf_fma(r, r, sse);
@@ -268,7 +268,7 @@ PHF_HD void phf_hier_experiment_terms(const phf_hier_common* c, double pic50, do
   const double v1 = phf_log_finish_k(l1, l1.f * d[1], k_log);
   const double la0 = 1.0 + phf_exp_fast_k(c->beta * (ln_h - c->ln_alpha), k_exp);
   const phf_logred l0 = phf_log_reduce(la0);
-  const double v0 = phf_log_finish_k(l0, l0.f / (2.0 + l0.f), k_log);
+  const double v0 = phf_log_finish_k(l0, phf_div(l0.f, 2.0 + l0.f), k_log);
   double hyper = (c->ln_beta - c->beta * c->ln_alpha) + (c->beta - 1.0) * ln_h;
   hyper += (-z - c->ln_s);
   hyper -= 2.0 * ((la0 > 0x1p1000) ? PHF_INF : v0);                          /* overflowed power: log(inf) = inf */
@@ -315,7 +315,7 @@ PHF_HD double phf_hier_log_target_any(int n_expts, const int* expt_start, const 
 PHF_HD void phf_box_muller_k(uint32_t w1, uint32_t w2, double* z0, double* z1, phf_ktab k_log, phf_ktab k_sc) {
   const double ua = phf_unit_open32(w1);
   const phf_logred lr = phf_log_reduce(ua);
-  const double rad = phf_sqrt(-2.0 * phf_log_finish_k(lr, lr.f / (2.0 + lr.f), k_log));
+  const double rad = phf_sqrt_pos(-2.0 * phf_log_finish_k(lr, phf_div(lr.f, 2.0 + lr.f), k_log));
   double sn, cs;
   phf_sincos_2pi_u32_k(w2, &sn, &cs, k_sc);
   *z0 = rad * cs;
@@ -341,7 +341,7 @@ PHF_HD double phf_hier_draws(int dim, uint32_t chain_id, uint32_t problem_id, ui
   const phf_u32x4 wu = phf_philox4x32_10(chain_id, problem_id, t, (uint32_t)nb, seed_lo, seed_hi);
   const double u = phf_uniform53(wu.w[0], wu.w[1]);
   const phf_logred lu = phf_log_reduce(u);
-  return phf_log_from_recip(u, lu, 1.0 / (2.0 + lu.f), k_log);
+  return phf_log_from_recip(u, lu, phf_rcp(2.0 + lu.f), k_log);
 }
 
 #endif /* PHF_HIER_MODEL_H */

@@ -128,7 +128,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
     if (t > a.cfg.adapt_start) {
       const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
       const double omg = 1.0 - gs;
-      const double sqa = phf_sqrt(omg), sqg = phf_sqrt(gs);
+      const double sqa = phf_sqrt_pos(omg), sqg = phf_sqrt_pos(gs);
       double w[D];
 #pragma unroll
       for (int i = 0; i < D; ++i) w[i] = sqg * (th[i] - mean[i]);
@@ -138,8 +138,8 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #pragma unroll
       for (int k = 0; k < D; ++k) {                        // Givens sweep down column k
         const double tkk = sqa * PHF_LGET(k * (k + 1) / 2 + k);
-        const double r = phf_sqrt(phf_fma(tkk, tkk, w[k] * w[k]));
-        const double inv = (r > 0.0) ? 1.0 / r : 0.0;
+        const double r = phf_sqrt_nonneg(phf_fma(tkk, tkk, w[k] * w[k]));
+        const double inv = (r > 0.0) ? phf_rcp(r) : 0.0;
         const double cs = (r > 0.0) ? tkk * inv : 1.0;
         const double sn = w[k] * inv;
         PHF_LSET(k * (k + 1) / 2 + k, r);
@@ -328,15 +328,15 @@ __global__ __launch_bounds__(kGenBlock) void hier_generic_advance_kernel(const H
     if (t > a.cfg.adapt_start) {
       const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
       const double omg = 1.0 - gs;
-      const double sqa = phf_sqrt(omg), sqg = phf_sqrt(gs);
+      const double sqa = phf_sqrt_pos(omg), sqg = phf_sqrt_pos(gs);
       for (int i = 0; i < D; ++i) s_w[i * kGenBlock] = sqg * (th[(size_t)i * nch] - mean[(size_t)i * nch]);
       for (int i = 0; i < D; ++i) mean[(size_t)i * nch] = phf_fma(gs, th[(size_t)i * nch], omg * mean[(size_t)i * nch]);
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
       for (int k = 0; k < D; ++k) {
         const double wk = s_w[k * kGenBlock];
         const double tkk = sqa * L[(size_t)(k * (k + 1) / 2 + k) * nch];
-        const double r = phf_sqrt(phf_fma(tkk, tkk, wk * wk));
-        const double inv = (r > 0.0) ? 1.0 / r : 0.0;
+        const double r = phf_sqrt_nonneg(phf_fma(tkk, tkk, wk * wk));
+        const double inv = (r > 0.0) ? phf_rcp(r) : 0.0;
         const double cs = (r > 0.0) ? tkk * inv : 1.0;
         const double sn = wk * inv;
         L[(size_t)(k * (k + 1) / 2 + k) * nch] = r;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
     const phf_u32x4 wu = phf_philox4x32_10(cid, pid, (uint32_t)t, (uint32_t)nb, seed_lo, seed_hi);
     const double u = phf_uniform53(wu.w[0], wu.w[1]);
     const phf_logred lu = phf_log_reduce(u);
-    const double log_u = phf_log_from_recip(u, lu, 1.0 / (2.0 + lu.f), k_log);
+    const double log_u = phf_log_from_recip(u, lu, phf_rcp(2.0 + lu.f), k_log);
     __syncthreads();
     // ---- proposal theta* = theta + e^(loga/2) L z: rows lane, lane+64, ... ----
     for (int i = lane; i < D; i += kBlock) {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
     if (t > a.cfg.adapt_start) {
       const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
       const double omg = 1.0 - gs;
-      const double sqa = phf_sqrt(omg), sqg = phf_sqrt(gs);
+      const double sqa = phf_sqrt_pos(omg), sqg = phf_sqrt_pos(gs);
       double* s_w = s_z;
       for (int i = lane; i < D; i += kBlock) {
         const double thi = s_th[i], mi = s_mean[i];
@@ -493,8 +493,8 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
       for (int k = 0; k < D; ++k) {
         const double wk = s_w[k];
         const double tkk = sqa * sLm[k * (k + 1) / 2 + k];
-        const double r = phf_sqrt(phf_fma(tkk, tkk, wk * wk));
-        const double inv = (r > 0.0) ? 1.0 / r : 0.0;
+        const double r = phf_sqrt_nonneg(phf_fma(tkk, tkk, wk * wk));
+        const double inv = (r > 0.0) ? phf_rcp(r) : 0.0;
         const double cs = (r > 0.0) ? tkk * inv : 1.0;
         const double sn = wk * inv;
         __syncthreads();                                          // everybody has read L_kk and w_k

@@ -124,6 +124,55 @@ PHF_HD uint64_t phf_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); re
 PHF_HD double phf_from_bits(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 PHF_HD double phf_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 PHF_HD double phf_sqrt(double x) { return __builtin_sqrt(x); } /* correctly rounded on both sides (checked in tests) */
+
+/* Division and square root of the MH loops.  hipcc expands an fp64 division into v_div_scale x2, v_rcp_f64, two Newton steps,
+ * q = n y, r = n - d q, v_div_fmas, v_div_fixup (11 instructions) and sqrt into a scaled v_rsq_f64 iteration (18): the scaling
+ * and fix-up only serve operands within 2^+-~250 of the ends of the exponent range, zeros, infinities and NaNs.  The loops divide
+ * by products of O(1)..1e70 numbers and take roots of O(1e-30)..O(1e30) numbers, so the device versions below are the SAME
+ * iterations without the range handling — 7 / 8 / 10 instructions — and return the same correctly rounded result (which is what
+ * the host computes with / and sqrt): bit-identity with the twin is kept and checked (tests/test_gpu_parity.py, 400 k arguments
+ * per function across 2^-600..2^600).  Outside that range (never reached by a live chain: such operands only arise where the
+ * target is -inf anyway and a select discards them) device and host may differ in NaN-versus-infinity.                        */
+#if defined(__HIP_DEVICE_COMPILE__)
+PHF_HD double phf_rcp_refined_(double d) {                  /* 1/d to ~0.5 ulp: hardware estimate + two Newton steps */
+  double y = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-d, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+PHF_HD double phf_rcp(double d) {                           /* 1.0 / d */
+  const double y = phf_rcp_refined_(d);
+  const double r = __builtin_fma(-d, y, 1.0);               /* q = 1.0 * y = y exactly */
+  return __builtin_fma(r, y, y);
+}
+PHF_HD double phf_div(double n, double d) {                 /* n / d */
+  const double y = phf_rcp_refined_(d);
+  const double q = n * y;
+  const double r = __builtin_fma(-d, q, n);
+  return __builtin_fma(r, y, q);
+}
+PHF_HD double phf_sqrt_pos(double x) {                      /* sqrt(x), x > 0 */
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+#else
+PHF_HD double phf_rcp(double d) { return 1.0 / d; }
+PHF_HD double phf_div(double n, double d) { return n / d; }
+PHF_HD double phf_sqrt_pos(double x) { return __builtin_sqrt(x); }
+#endif
+/* sqrt(x) for x >= 0 with sqrt(0) = 0 (pivots of a degenerate factor); anything else non-positive also gives 0 */
+PHF_HD double phf_sqrt_nonneg(double x) {
+  const double r = phf_sqrt_pos(x);
+  return (x > 0.0) ? r : 0.0;
+}
 PHF_HD double phf_pow2i(int k) { return phf_from_bits((uint64_t)(k + 1023) << 52); } /* -1022 <= k <= 1023 */
 
 /* ------------------------------------------------------------------------------------------------ exp
@@ -233,7 +282,7 @@ PHF_HD double phf_log_finish(phf_logred lr, double s) { PHF_KFETCH_V(k, phf_k_lo
 /* positive normal finite x only (no checks) */
 PHF_HD double phf_log_core(double x) {
   const phf_logred lr = phf_log_reduce(x);
-  return phf_log_finish(lr, lr.f / (2.0 + lr.f));
+  return phf_log_finish(lr, phf_div(lr.f, 2.0 + lr.f));
 }
 
 /* kernels: x >= 2^-1022 exact; anything below (0, negatives, subnormals) gives -inf; branch-free.
@@ -312,7 +361,7 @@ PHF_HD void phf_erfcx_finish_x2_kx(double y0, double r0, double y1, double r1, p
 PHF_HD double phf_erfcx_finish(double y, double r) { PHF_KFETCH(k, phf_k_erfcx, 24); return phf_erfcx_finish_k(y, r, k); }
 
 /* 0 <= y < ~1e150 (no checks) */
-PHF_HD double phf_erfcx_core(double y) { return phf_erfcx_finish(y, 1.0 / phf_erfcx_den(y)); }
+PHF_HD double phf_erfcx_core(double y) { return phf_erfcx_finish(y, phf_rcp(phf_erfcx_den(y))); }
 
 /* any y >= 0 */
 PHF_HD double phf_erfcx_nonneg(double y) {
@@ -340,12 +389,12 @@ PHF_HD double phf_log_ndtr_nonpos(double x) {
 PHF_HD void phf_log_ndtr_nonpos_x2_kx(double x0, double x1, double* r0, double* r1, phf_ktab ke, int ke_in_vgpr, phf_ktab kl) {
   const double y0 = -x0 * PHF_INV_SQRT2, y1 = -x1 * PHF_INV_SQRT2;
   const double q0 = phf_erfcx_den(y0), q1 = phf_erfcx_den(y1);
-  const double iq = 1.0 / (q0 * q1);
+  const double iq = phf_rcp(q0 * q1);
   double e0, e1;
   phf_erfcx_finish_x2_kx(y0, iq * q1, y1, iq * q0, ke, ke_in_vgpr, &e0, &e1);
   const phf_logred l0 = phf_log_reduce(0.5 * e0), l1 = phf_log_reduce(0.5 * e1);
   const double d0 = 2.0 + l0.f, d1 = 2.0 + l1.f;
-  const double id = 1.0 / (d0 * d1);
+  const double id = phf_rcp(d0 * d1);
   *r0 = phf_fma(-0.5 * x0, x0, phf_log_finish_k(l0, l0.f * (id * d1), kl));
   *r1 = phf_fma(-0.5 * x1, x1, phf_log_finish_k(l1, l1.f * (id * d0), kl));
 }
@@ -363,9 +412,9 @@ PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1)
 /* one, with the log table from the caller */
 PHF_HD double phf_log_ndtr_nonpos_kx(double x, phf_ktab ke, int ke_in_vgpr, phf_ktab kl) {
   const double yv = -x * PHF_INV_SQRT2;
-  const double e = phf_erfcx_finish_kx(yv, 1.0 / phf_erfcx_den(yv), ke, ke_in_vgpr);
+  const double e = phf_erfcx_finish_kx(yv, phf_rcp(phf_erfcx_den(yv)), ke, ke_in_vgpr);
   const phf_logred lr = phf_log_reduce(0.5 * e);
-  return phf_fma(-0.5 * x, x, phf_log_finish_k(lr, lr.f / (2.0 + lr.f), kl));
+  return phf_fma(-0.5 * x, x, phf_log_finish_k(lr, phf_div(lr.f, 2.0 + lr.f), kl));
 }
 
 PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab ke, phf_ktab kl) { return phf_log_ndtr_nonpos_kx(x, ke, 0, kl); }
@@ -443,7 +492,7 @@ PHF_HD double phf_unit_open24(uint32_t v24) { return ((double)v24 + 0.5) * 0x1p-
 
 /* Box-Muller pair from two 32-bit words (own division; the samplers use phf_mh_draws in phf_model.h) */
 PHF_HD void phf_box_muller(uint32_t w1, uint32_t w2, double* z0, double* z1) {
-  const double rad = phf_sqrt(-2.0 * phf_log_core(phf_unit_open32(w1)));
+  const double rad = phf_sqrt_pos(-2.0 * phf_log_core(phf_unit_open32(w1)));
   double sn, cs;
   phf_sincos_2pi_u32(w2, &sn, &cs);
   *z0 = rad * cs;

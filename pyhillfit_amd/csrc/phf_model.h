@@ -69,7 +69,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
   const phf_logred lr_s = phf_log_reduce(sigma), lr_l = phf_log_reduce(sl);
   const double ds = 2.0 + lr_s.f, dl = 2.0 + lr_l.f;
   const double p1 = sigma * ds;
-  const double inv3 = 1.0 / (p1 * dl);
+  const double inv3 = phf_rcp(p1 * dl);
   const double i1 = inv3 * dl;                    /* 1/(sigma ds) */
   const double inv_s = i1 * ds;
   const double log_sigma = phf_log_finish_k(lr_s, lr_s.f * (i1 * sigma), k_log);
@@ -82,7 +82,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke, 0), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50, ke, 0);
     const double p01 = d0 * d1, p23 = d2 * d3;
-    const double inv = 1.0 / (p01 * p23);
+    const double inv = phf_rcp(p01 * p23);
     const double i01 = inv * p23, i23 = inv * p01;
     const double r0 = y[j] - phf_hill_percent(i01 * d1), r1 = y[j + 1] - phf_hill_percent(i01 * d0);
     const double r2 = y[j + 2] - phf_hill_percent(i23 * d3), r3 = y[j + 3] - phf_hill_percent(i23 * d2);
@@ -95,7 +95,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke, 0);
     const double p01 = d0 * d1;
-    const double inv = 1.0 / (p01 * d2);
+    const double inv = phf_rcp(p01 * d2);
     const double i01 = inv * d2;
     const double r0 = y[j] - phf_hill_percent(i01 * d1), r1 = y[j + 1] - phf_hill_percent(i01 * d0);
     const double r2 = y[j + 2] - phf_hill_percent(inv * p01);
@@ -103,11 +103,11 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
   } else if (rem == 2) {
     const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
-    const double inv = 1.0 / (d0 * d1);
+    const double inv = phf_rcp(d0 * d1);
     const double r0 = y[j] - phf_hill_percent(inv * d1), r1 = y[j + 1] - phf_hill_percent(inv * d0);
     sse = phf_fma(w[j] * r0, r0, sse); sse = phf_fma(w[j + 1] * r1, r1, sse);
   } else if (rem == 1) {
-    const double r = y[j] - phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1));
+    const double r = y[j] - phf_hill_percent(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1)));
     sse = phf_fma(w[j] * r, r, sse);
   }
   j = n_other;
@@ -116,7 +116,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
     PHF_KFETCH_UNLESS(k_erfcx, erfcx_resident, k_erfcx_resident, phf_k_erfcx, 24);   /* issued now, needed after the two exponentials */
     const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
-    const double inv = 1.0 / (d0 * d1);
+    const double inv = phf_rcp(d0 * d1);
     const double z0 = phf_censored_z(phf_hill_percent(inv * d1), y[j], inv_s);
     const double z1 = phf_censored_z(phf_hill_percent(inv * d0), y[j + 1], inv_s);
     double l0, l1;
@@ -125,7 +125,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
   }
   for (; j < n; ++j) {
     PHF_KFETCH_UNLESS(k_erfcx, erfcx_resident, k_erfcx_resident, phf_k_erfcx, 24);
-    const double pred = phf_hill_percent(1.0 / phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1));
+    const double pred = phf_hill_percent(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1)));
     cens = phf_fma(w[j], phf_log_ndtr_nonpos_kx(phf_censored_z(pred, y[j], inv_s), k_erfcx, erfcx_resident, k_log), cens);
   }
   double a = cens - pi_bit;
@@ -169,19 +169,19 @@ PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32
   const phf_logred la = phf_log_reduce(ua), lb = phf_log_reduce(ub), lu = phf_log_reduce(u);
   const double da = 2.0 + la.f, db = 2.0 + lb.f, du = 2.0 + lu.f;
   const double pab = da * db;
-  const double inv = 1.0 / (pab * du);
+  const double inv = phf_rcp(pab * du);
   const double iab = inv * du;
   const double log_ua = phf_log_finish_k(la, la.f * (iab * db), k_log);
   double sn, cs;
   phf_sincos_2pi_u32_k(ang_a, &sn, &cs, k_sc);
-  const double ra = phf_sqrt(-2.0 * log_ua);
+  const double ra = phf_sqrt_pos(-2.0 * log_ua);
   z[0] = ra * cs; z[1] = ra * sn;
   if (d == 2) {
     z[2] = 0.0; z[3] = 0.0;
   } else {
     const double log_ub = phf_log_finish_k(lb, lb.f * (iab * da), k_log);
     phf_sincos_2pi_u32_k(ang_b, &sn, &cs, k_sc);
-    const double rb = phf_sqrt(-2.0 * log_ub);
+    const double rb = phf_sqrt_pos(-2.0 * log_ub);
     z[2] = rb * cs; z[3] = rb * sn;
   }
   const double log_u = phf_log_finish_k(lu, lu.f * (inv * pab), k_log);

@@ -34,11 +34,10 @@ __device__ __forceinline__ void chol_packed(const double* c, double* l) {
 #pragma unroll
       for (int k = 0; k < j; ++k) s = phf_fma(-l[i * (i + 1) / 2 + k], l[j * (j + 1) / 2 + k], s);
       if (i == j) {   // sqrt and reciprocal are computed unconditionally (no divergent branch); a non-positive pivot selects 0
-        const double sp = __builtin_fmax(s, 0.0);
-        const double r = phf_sqrt(sp);
-        const double ir = 1.0 / r;
+        const double r = phf_sqrt_nonneg(s);
+        const double ir = phf_rcp(r);
         l[i * (i + 1) / 2 + i] = r;
-        inv[i] = (sp > 0.0) ? ir : 0.0;
+        inv[i] = (r > 0.0) ? ir : 0.0;
       } else {
         l[i * (i + 1) / 2 + j] = s * inv[j];
       }
@@ -365,6 +364,11 @@ __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* o
     case 9: r = phf_exp_fast(x); break;
     case 10: r = phf_log_fast(x); break;
     case 11: r = phf_log_ndtr_nonpos(x); break;
+    case 12: r = phf_rcp(x); break;
+    case 13: r = phf_sqrt_pos(x); break;
+    case 14: r = phf_div(PHF_LN10, x); break;
+    case 15: r = phf_sqrt_nonneg(x); break;
+    case 16: r = phf_div(x, PHF_LN10); break;
     default: phf_sincos_2pi_u32((uint32_t)x, &s, &c); r = c; break;
   }
   out[i] = r;
@@ -458,7 +462,7 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
 }
 
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream) {
-  if (fn < 0 || fn > 11 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
+  if (fn < 0 || fn > 16 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
   if (n == 0) return PHF_OK;
   hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, n, in, out);
   return phf_check_launch("phf_debug_math");

@@ -58,6 +58,19 @@ def test_device_math_bit_identical_to_host_build(gpu):
         assert np.array_equal(got, want, equal_nan=True), "%s: %d mismatches" % (name, int((got != want).sum()))
     x = np.concatenate([np.exp(rng.uniform(-700, 700, n)), -np.exp(rng.uniform(-5, 5, n))])
     assert np.array_equal(debug_math(6, x, gpu), 1.0 / x)                      # IEEE division
+    # the MH loops' own division / square root: hipcc's iterations without the exponent-range handling (phf_math.h) must still
+    # be the correctly rounded results — that is what the twin computes with / and sqrt — over 2^-600 .. 2^600, both signs
+    x = np.concatenate([np.exp(rng.uniform(-415, 415, n)), -np.exp(rng.uniform(-415, 415, n)), rng.uniform(1, 2, n), 1 + np.arange(1, 4097) * 2.0 ** -52,
+                        2 - np.arange(1, 4097) * 2.0 ** -52, [1.0, 2.0, 3.0, 4.0, 2.0 ** 52 + 1, 1.0 / 3, 1e70, 1e-70]])
+    assert np.array_equal(debug_math(12, x, gpu), 1.0 / x), "phf_rcp"
+    ln10 = float.fromhex("0x1.26bb1bbb55516p+1")
+    assert np.array_equal(debug_math(14, x, gpu), ln10 / x), "phf_div (denominator varies)"
+    assert np.array_equal(debug_math(16, x, gpu), x / ln10), "phf_div (numerator varies)"
+    xp = np.abs(x)
+    assert np.array_equal(debug_math(13, xp, gpu), np.sqrt(xp)), "phf_sqrt_pos"
+    xz = np.concatenate([xp[:1000], [0.0, -0.0, -1.0, -1e-300]])
+    want = np.where(xz > 0, np.sqrt(np.abs(xz)), 0.0)
+    assert np.array_equal(debug_math(15, xz, gpu), want), "phf_sqrt_nonneg"
     w = rng.integers(0, 2 ** 32, n, dtype=np.uint64)
     w[:6] = [0, 2 ** 28 - 1, 2 ** 28, 2 ** 31, 2 ** 32 - 1, 2 ** 32 - 2 ** 28]
     s, c = co.sincos(w.astype(np.uint32))
