@@ -1,0 +1,231 @@
+"""BASELINE.json's configurations at their FULL sizes on the GPU (-m gpu), and the sampler kernels' log-target column
+re-evaluated by the INDEPENDENT numpy oracle.
+
+  C3  all 210 Crumb pairs x 4 096 chains, single level   — shard invariance (the multi-GPU partition) and checkpoint identity
+  C4  all 210 pairs x 1 024 chains, hierarchical          — the same two properties
+  C5  32 rungs (i/31)^3 x 210 pairs x 1 024 chains        — prior-only rung against the analytic prior, t = 1 rung against the
+                                                            reference sampler's posteriors (golden G5c), per-rung <log L> monotone
+and, for every pair, rows sampled by mh_advance_kernel (both register builds) and hier_advance_kernel whose log-target column
+is recomputed with oracle/pyhillfit_oracle.py (numpy/scipy, shares no source with the kernels) to |diff| <= 1e-12 (|value| + 1): the
+twin that the bit-identity tests use includes the kernels' own target headers, so THIS is what pins the arithmetic of the
+specialised loop bodies to the reference (python/doseresponse.py:187-189,229-248; python/PyHillFit.py:173-193)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pyhillfit_amd import _lib
+    _lib.load()
+    return "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def dr(gpu):
+    from pyhillfit_amd import doseresponse as d
+    d.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    return d
+
+
+def _all_names(dr):
+    return [(d, c) for d in dr.drugs for c in dr.channels]
+
+
+# ------------------------------------------------------------------------------------- independent re-evaluation
+@pytest.mark.parametrize("model,chains,temps", [(2, 64, (1.0,)),          # 210 wavefronts: the one-wavefront-per-SIMD build (512 registers)
+                                                (2, 640, (1.0, 0.125)),   # 4 200 wavefronts: the two-per-SIMD build (256 registers)
+                                                (1, 640, (1.0,))])
+def test_sampled_rows_log_target_recomputed_by_the_numpy_oracle(model, chains, temps, gpu, dr, oracle_pair):
+    from oracle import pyhillfit_oracle as orc
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    names = _all_names(dr)
+    packed = dr.pack_single_level(names)
+    pair_index = [p for p in range(len(names)) for _ in temps]
+    tt = [t for _ in names for t in temps]
+    s = SingleLevelSampler(packed, model, pair_index, tt, chains, thinning=5, seed=77, adapt_start=300, device=gpu)
+    d = s.d
+    s.init([6.0, 0.8, 8.0] if model == 2 else [6.0, 8.0], cov_identity=False, cov_scale=0.05)
+    rows = s.advance(1500).cpu().numpy()                         # [300][Q][d+1][C], adaptation on from iteration 300
+    assert np.isfinite(rows).all()
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for q in range(len(pair_index)):
+        pair = oracle_pair(*names[pair_index[q]])
+        for r, c in zip(rng.integers(0, rows.shape[0], 6), rng.integers(0, chains, 6)):
+            th, got = rows[r, q, :d, c], rows[r, q, d, c]
+            want = orc.log_target(model, pair, th, tt[q])
+            worst = max(worst, abs(got - want) / (abs(want) + 1.0))
+    assert worst <= 1e-12, worst
+    # the chains moved: a column that never changed would make the check vacuous
+    assert (np.abs(np.diff(rows[:, :, 0, :], axis=0)) > 0).mean() > 0.1
+
+
+def test_hierarchical_sampled_rows_recomputed_by_the_numpy_oracle(gpu, dr, oracle_pair):
+    """every Crumb pair (Ne = 3..6: all four compiled kernels, straight-line and run-time-loop bodies)"""
+    from oracle import pyhillfit_oracle as orc
+    from pyhillfit_amd import bestfit
+    from pyhillfit_amd import hierarchical as H
+    shapes, scales, locs = H.prior_params()
+    groups = {}
+    for dname, c in _all_names(dr):
+        ne, _, ex = dr.load_crumb_data(dname, c)
+        groups.setdefault(len(ex), []).append((dname, c, ex))
+    assert sorted(groups) == [3, 4, 5, 6]
+    rng = np.random.default_rng(2)
+    worst, checked = 0.0, 0
+    for ne, members in sorted(groups.items()):
+        packed = H.PackedHierPoints([m[2] for m in members])
+        theta0 = np.array([bestfit.hierarchical_first_iteration(m[2], locs) for m in members])
+        s = H.HierarchicalSampler(packed, list(range(len(members))), 64, thinning=5, seed=9, adapt_start=200, device=gpu)
+        s.init(theta0, cov_scale=0.01)
+        rows = s.advance(600).cpu().numpy()                      # [120][Q][dim+1][64]
+        dim = 5 + 2 * ne
+        assert np.isfinite(rows).all()
+        for q, m in enumerate(members):
+            expts = oracle_pair(m[0], m[1]).experiments
+            for r, c in zip(rng.integers(0, rows.shape[0], 3), rng.integers(0, 64, 3)):
+                th = rows[r, q, :dim, c]
+                want = orc.hier_log_target(expts, th, shapes, scales, locs)
+                # conditioning: SSE/(2 sigma^2) turns a relative error e in a prediction into |y - pred| pred e / sigma^2; chains do visit
+                # sigma ~ 0.02 (Toremifene-Nav1.5-peak: predictions within 0.05 of the data), where 4 ulp on pred ~ 100 is 1e-11 of
+                # the target.  There the kernel's value is the closer of the two to a 50-digit evaluation.
+                cond = sum(np.sum(np.abs(e[:, 1] - orc.hill_curve(e[:, 0], th[5 + 2 * i], orc.ic50_of(th[4 + 2 * i]))) * 100.0) for i, e in enumerate(expts)) / th[-1] ** 2
+                worst = max(worst, abs(rows[r, q, dim, c] - want) / (1e-12 * (abs(want) + 1.0) + 4 * 2.0 ** -53 * cond))
+                checked += 1
+        assert (np.abs(np.diff(rows[:, :, 0, :], axis=0)) > 0).mean() > 0.02
+    assert checked == 630 and worst <= 1.0, (checked, worst)        # in units of the tolerance above
+
+
+# ------------------------------------------------------------------------------------- C3 / C4 at full width
+def test_c3_full_width_shard_invariance_and_checkpoint(gpu, dr):
+    """210 pairs x 4 096 chains (BASELINE configs[2]): one launch == the pairs split over 3 'ranks' by cost
+    (distributed.shard_problems, global problem ids) == the chains split in two (chain_id_base) == stop / checkpoint / resume."""
+    from pyhillfit_amd import distributed as D
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    names = _all_names(dr)
+    packed = dr.pack_single_level(names)
+    Q, C, T = len(names), 4096, 40
+    kw = dict(thinning=5, seed=25, adapt_start=15, device=gpu)
+    full = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, C, **kw)
+    full.init([6.0, 0.8, 8.0])
+    a = full.run(T)                                                # [9][210][4][4096]
+    assert torch.isfinite(a).all()
+    costs = packed.counts[:, 3]
+    parts = D.shard_problems(costs, 3)
+    assert sorted(np.concatenate(parts).tolist()) == list(range(Q))
+    for mine in parts:
+        sub = dr.pack_single_level([names[i] for i in mine])
+        s = SingleLevelSampler(sub, 2, list(range(len(mine))), [1.0] * len(mine), C, problem_ids=mine, **kw)
+        s.init([6.0, 0.8, 8.0])
+        assert torch.equal(s.run(T), a[:, torch.as_tensor(mine, device=a.device)])
+    for h in range(2):
+        s = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, C // 2, chain_id_base=h * (C // 2), **kw)
+        s.init([6.0, 0.8, 8.0])
+        assert torch.equal(s.run(T), a[..., h * (C // 2):(h + 1) * (C // 2)])
+    r = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, C, **kw)
+    r.init([6.0, 0.8, 8.0])
+    first = r.advance(25)
+    r2 = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, C, **kw)
+    r2.load_state_dict(r.state_dict())
+    assert torch.equal(torch.cat([first, r2.advance(15)]), a[1:])
+
+
+def test_c4_full_width_shard_invariance_and_checkpoint(gpu, dr):
+    """hierarchical, 210 pairs x 1 024 chains (BASELINE configs[3]), every Ne group: chain shards (8 'ranks' of 128 chains)
+    and a checkpointed run reproduce the one-launch run bit for bit"""
+    from pyhillfit_amd import bestfit
+    from pyhillfit_amd import hierarchical as H
+    shapes, scales, locs = H.prior_params()
+    groups = {}
+    for dname, c in _all_names(dr):
+        ne, _, ex = dr.load_crumb_data(dname, c)
+        groups.setdefault(len(ex), []).append(ex)
+    C, T = 1024, 40
+    total = 0
+    for ne, exs in sorted(groups.items()):
+        packed = H.PackedHierPoints(exs)
+        theta0 = np.array([bestfit.hierarchical_first_iteration(e, locs) for e in exs])
+        kw = dict(thinning=5, seed=25, adapt_start=15, device=gpu)
+        full = H.HierarchicalSampler(packed, list(range(len(exs))), C, **kw)
+        full.init(theta0, cov_scale=0.01)
+        a = torch.cat([full.advance(25), full.advance(15)])     # [8][Q][dim+1][1024]
+        assert torch.isfinite(a).all()
+        for r in (0, 3, 7):
+            s = H.HierarchicalSampler(packed, list(range(len(exs))), C // 8, chain_id_base=r * (C // 8), **kw)
+            s.init(theta0, cov_scale=0.01)
+            assert torch.equal(s.advance(T), a[..., r * (C // 8):(r + 1) * (C // 8)])
+        one = H.HierarchicalSampler(packed, list(range(len(exs))), C, **kw)
+        one.init(theta0, cov_scale=0.01)
+        assert torch.equal(one.advance(T), a) and torch.equal(one.state, full.state)
+        total += len(exs)
+    assert total == 210
+
+
+# ------------------------------------------------------------------------------------- C5 at full size
+def test_c5_full_ladder_all_pairs(gpu, dr):
+    """BASELINE configs[4]: 32 rungs t_i = (i/31)^3 (python/PyHillTemp.py:151 with n = 31) x 210 pairs x 1 024 chains =
+    6.9 M chains, PyHillTemp's start (ones, identity covariance, mean reset), 200 000 iterations like the reference's runs
+    behind golden G5c, moments on the device:
+      * rung t = 0 samples the prior alone (doseresponse.py:230-231): pooled over its 210 x 1 024 chains the means are the
+        analytic (2, 5, 7.49975) and the sds (5, 2.887, 3.354);
+      * rung t = 1 reproduces the reference sampler's posterior means of every pair (G5c: PyHillTemp.do_mcmc on all 210 pairs);
+      * per pair, <log L(theta; t=1)> under the tempered posteriors rises along the ladder (its t-derivative is a variance):
+        what python/compute_bayes_factors.py integrates."""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    with open(os.path.join(GOLDEN, "g5c_posteriors_all_pairs_model_2.json")) as f:
+        g5c = json.load(f)
+    names = [(w["drug"], w["channel"]) for w in g5c]
+    assert len(names) == 210
+    packed = dr.pack_single_level(names)
+    ladder = dr.temperature_ladder(31)
+    R, P, C = len(ladder), len(names), 1024
+    assert R == 32 and ladder[0] == 0.0 and ladder[-1] == 1.0
+    pair_index = [p for p in range(P) for _ in range(R)]
+    temps = [float(t) for _ in range(P) for t in ladder]
+    s = SingleLevelSampler(packed, 2, pair_index, temps, C, thinning=5, seed=25, reset_mean_at_adapt_start=True, device=gpu)
+    s.init(np.ones(3), cov_identity=True, cov_scale=1.0)
+    s.enable_moments(after_iteration=50000)
+    for _ in range(8):                                             # 8 launches of 25 000 iterations
+        s.advance(25000, save=False)
+    mean, var, n = s.posterior_moments()                           # [4][P*R][C]
+    assert n == 30000
+    mean = mean.view(4, P, R, C); var = var.view(4, P, R, C)
+    # t = 0: the prior
+    m0 = mean[:3, :, 0, :].reshape(3, -1)
+    prior_mean = m0.mean(dim=1).cpu().numpy()
+    prior_sd = torch.sqrt(var[:3, :, 0, :].reshape(3, -1).mean(dim=1) + m0.var(dim=1)).cpu().numpy()
+    print("C5 t=0 rung: pooled mean", prior_mean, "sd", prior_sd)
+    # the exponential pIC50 tail (mean 5 beyond -3) is explored slowly by a random walk started at 1: at this run length the
+    # REFERENCE's own t = 0 chain gives 1.89 for the analytic 2; Hill and sigma are at their analytic values
+    assert np.all(np.abs(prior_mean - [2.0, 5.0, 7.49975]) <= [0.12, 0.03, 0.05]), prior_mean
+    assert np.all(np.abs(prior_sd - [5.0, 10 / np.sqrt(12), np.sqrt(5) * 1.49975]) <= [0.35, 0.03, 0.06]), prior_sd
+    # t = 1: the reference sampler's posteriors, all pairs
+    pooled = mean[:, :, R - 1, :].mean(dim=2).cpu().numpy()        # [4][P]
+    want = np.array([w["mean"] for w in g5c]).T
+    se = np.array([w["batch_means_se"] for w in g5c]).T
+    ratio = np.abs(pooled - want) / (0.01 * np.abs(want) + 4 * se)
+    worst = np.unravel_index(np.argmax(ratio), ratio.shape)
+    print("C5 t=1 rung vs G5c: within tolerance %.4f, worst %.2f at %s column %d" % (np.mean(ratio < 1), ratio.max(), names[worst[1]], worst[0]))
+    assert np.mean(ratio < 1) >= 0.99 and ratio.max() < 2.0, (np.mean(ratio < 1), ratio.max(), names[worst[1]], worst[0])
+    # <log L> along the ladder
+    ll = s.mean_log_likelihood_t1().view(P, R, C)
+    e = ll.mean(dim=2).cpu().numpy()                               # [P][R]
+    e_se = (ll.std(dim=2) / np.sqrt(C)).cpu().numpy()
+    assert np.isfinite(e).all()
+    step = np.diff(e, axis=1)
+    slack = 4 * np.sqrt(e_se[:, 1:] ** 2 + e_se[:, :-1] ** 2) + 1e-9 * np.abs(e[:, 1:])
+    bad = step < -slack
+    print("C5 ladder: %d of %d steps fall by more than 4 standard errors; largest fall %.3g" % (bad.sum(), bad.size, (-step).max()))
+    assert bad.mean() <= 0.002, (bad.sum(), np.argwhere(bad)[:5])
+    acc = s.acceptance().view(P, R, C).mean(dim=2).cpu().numpy()
+    assert 0.1 < acc.min() and acc.max() < 0.6, (acc.min(), acc.max())
