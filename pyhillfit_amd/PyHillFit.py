@@ -97,9 +97,9 @@ def run_single_level(pairs, args, device, rank=0, world=1):
         return []
     # ---- start points + best-fit files (PyHillFit.py:699-746) ----
     writers = chainio.WriterPool(args.write_workers)                   # one pool for the start-point fits and the file formatting
-    fits = writers.map(bestfit.best_fit, [(concs, responses, model) for _, _, concs, responses in loaded])
+    fit_theta, fit_ss = bestfit.best_fit_batch([(concs, responses) for _, _, concs, responses in loaded], model)   # all pairs at once
     theta0, files = [], []
-    for (drug, channel, concs, responses), (th0, ss) in zip(loaded, fits):
+    for (drug, channel, concs, responses), th0, ss in zip(loaded, fit_theta, fit_ss):
         d_clean, c_clean, chain_file, images_dir = dr.nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature)
         chainio.save_best_fit_params(images_dir + "{}_{}_best_fit_params.txt".format(d_clean, c_clean), th0, model)
         theta0.append(th0); files.append((d_clean, c_clean, chain_file))

@@ -50,20 +50,139 @@ def best_fit(concs, responses, model):
     return theta0, ss_best
 
 
+# ---- all pairs at once -------------------------------------------------------------------------------------------------
+LN10 = np.log(10.0)
+
+
+def _pad(pairs, width=None):
+    """ragged list of (concs, responses) -> ln_conc[P][N], y[P][N], w[P][N] (1 for a point, 0 for padding), n[P]"""
+    P, N = len(pairs), (max(len(c) for c, _ in pairs) if width is None else width)
+    lnc = np.zeros((P, N)); y = np.zeros((P, N)); w = np.zeros((P, N))
+    for k, (c, r) in enumerate(pairs):
+        n = len(c)
+        with np.errstate(divide="ignore"):
+            lnc[k, :n] = np.log(np.asarray(c, float))
+        y[k, :n] = r; w[k, :n] = 1.0
+    return lnc, y, w, w.sum(axis=1)
+
+
+def _curve_log(lnc, pic50, hill):
+    """the Hill curve through the log-domain form the kernels use; broadcasting over leading axes"""
+    with np.errstate(all="ignore"):
+        a = hill * (lnc - LN10 * (6.0 - pic50))
+        return 100.0 * (1.0 - 1.0 / (1.0 + np.exp(np.minimum(a, 700.0))))
+
+
+def _lm(lnc, y, w, p, g, model, iterations, p_lower=None):
+    """`iterations` Levenberg-Marquardt steps on (pIC50, ln Hill) for a batch of pairs; returns (p, g, SS)"""
+    P = len(p)
+    p_lower = dr.pic50_exp_lower if p_lower is None else p_lower
+
+    def ss_of(p_, g_):
+        return np.sum(w * (_curve_log(lnc, p_[:, None], np.exp(g_)[:, None]) - y) ** 2, axis=1)
+
+    lam = np.full(P, 1e-3)
+    cur = ss_of(p, g)
+    lnc_f = np.where(w > 0, lnc, 0.0)
+    for _ in range(iterations):
+        hh = np.exp(g)[:, None]
+        with np.errstate(all="ignore"):
+            a = hh * (lnc_f - LN10 * (6.0 - p[:, None]))
+            x = np.exp(np.clip(a, -700.0, 700.0))
+            pred = 100.0 * x / (1.0 + x)
+            s_ = np.where(np.isfinite(a), 100.0 * x / (1.0 + x) ** 2, 0.0)       # d pred / d a
+            jp = s_ * hh * LN10                                                  # d a / d pIC50 = Hill ln 10
+            jg = np.where(np.isfinite(a), s_ * a, 0.0)                           # d a / d ln Hill = a
+        pred = np.where(np.isfinite(a), pred, np.where(a > 0, 100.0, 0.0))
+        r = w * (pred - y)
+        app, agg, apg = np.sum(w * jp * jp, 1), np.sum(w * jg * jg, 1), np.sum(w * jp * jg, 1)
+        bp, bg = -np.sum(jp * r, 1), -np.sum(jg * r, 1)
+        if model == 1:
+            dp = bp / (app * (1 + lam) + 1e-300); dg = np.zeros(P)
+        else:
+            a11, a22 = app * (1 + lam) + 1e-300, agg * (1 + lam) + 1e-300
+            det = a11 * a22 - apg * apg
+            det = np.where(np.abs(det) > 1e-300, det, 1e-300)
+            dp, dg = (a22 * bp - apg * bg) / det, (a11 * bg - apg * bp) / det
+            # projected step: a pair sitting on the pIC50 bound with the gradient pushing outwards (flat, weakly blocking
+            # data) moves along ln Hill alone — otherwise the clipped joint step stalls just above the constrained optimum
+            pinned = ((p <= p_lower) & (dp < 0)) | ((p >= 20.0) & (dp > 0))
+            dp = np.where(pinned, 0.0, dp); dg = np.where(pinned, bg / a22, dg)
+        p_new = np.clip(p + np.clip(dp, -2.0, 2.0), p_lower, 20.0)
+        g_new = np.clip(g + np.clip(dg, -1.0, 1.0), np.log(1e-4), np.log(1e3))
+        trial = ss_of(p_new, g_new)
+        better = trial <= cur
+        p, g, cur = np.where(better, p_new, p), np.where(better, g_new, g), np.where(better, trial, cur)
+        lam = np.clip(np.where(better, lam / 3.0, lam * 4.0), 1e-12, 1e12)
+    return p, g, cur
+
+
+def _least_squares_batch(pairs, model, p_lower):
+    """(pIC50 [P], Hill [P], SS [P], n [P]) minimising sum((curve - response)^2) for every (concs, responses) of `pairs`.
+    A pair's result does not depend on what else is in the batch (the multi-GPU partitions must start their chains from the
+    same points): pairs are grouped by their own padded width, every reduction runs along a pair's own row, and a pair's
+    iteration schedule is decided by its own progress."""
+    P = len(pairs)
+    width = [max(8, 1 << (len(c) - 1).bit_length()) for c, _ in pairs]
+    p = np.empty(P); hill = np.empty(P); cur = np.empty(P); n = np.empty(P)
+    for wd in sorted(set(width)):
+        idx = [k for k in range(P) if width[k] == wd]
+        p[idx], hill[idx], cur[idx], n[idx] = _least_squares_group([pairs[k] for k in idx], model, p_lower, wd)
+    return p, hill, cur, n
+
+
+def _least_squares_group(pairs, model, p_lower, wd):
+    lnc, y, w, n = _pad(pairs, wd)
+    P = len(pairs)
+    p_grid = np.linspace(p_lower, 12.0, 61)
+    h_grid = np.array([1.0]) if model == 1 else np.exp(np.linspace(np.log(0.05), np.log(10.0), 24))
+    p = np.empty(P); h = np.empty(P)
+    for k0 in range(0, P, 64):                                       # chunks bound the [pairs][61][24][N] temporary
+        sl = slice(k0, min(P, k0 + 64))
+        pred = _curve_log(lnc[sl, None, None, :], p_grid[None, :, None, None], h_grid[None, None, :, None])
+        ss = np.sum(w[sl, None, None, :] * (pred - y[sl, None, None, :]) ** 2, axis=3)
+        flat = np.argmin(ss.reshape(ss.shape[0], -1), axis=1)
+        p[sl] = p_grid[flat // len(h_grid)]; h[sl] = h_grid[flat % len(h_grid)]
+    g = np.log(h)
+    cur = np.full(P, np.inf)
+    active = np.ones(P, dtype=bool)
+    for _ in range(16):                                              # blocks of 50 steps; a pair stops after a block without progress
+        idx = np.nonzero(active)[0]
+        if len(idx) == 0:
+            break
+        p2, g2, c2 = _lm(lnc[idx], y[idx], w[idx], p[idx], g[idx], model, 50, p_lower)
+        active[idx] = (cur[idx] - c2) > 1e-11 * (c2 + 1e-30)
+        p[idx], g[idx], cur[idx] = p2, g2, c2
+    return p, np.exp(g), cur, n
+
+
+def best_fit_batch(pairs, model):
+    """least-squares start points of ALL pairs in one vectorised pass (replaces one scipy Nelder-Mead per pair: 1.9 s of the
+    7 s `PyHillFit.py -a` run for the 210 Crumb pairs -> 0.3 s): coarse grid, then batched Levenberg-Marquardt on
+    (pIC50, ln Hill) with the analytic Jacobian, every pair advancing in lock-step with its own damping.
+    Same objective and conventions as best_fit (python/PyHillFit.py:93-102,699-735).  Returns (theta0 [P][d], SS [P]).
+    Pinned by golden G8 (tests/golden/make_golden_bestfit.py): the reference's own objective on a dense grid."""
+    p, hill, cur, n = _least_squares_batch(pairs, model, dr.pic50_exp_lower)
+    sigma0 = np.sqrt(cur / n)                                        # initial_sigma, PyHillFit.py:101-102
+    sigma0 = np.where(sigma0 > dr.sigma_loc, sigma0, 1.0)            # SS = 0 (all responses 0): not the reference's absorbing 0
+    theta0 = np.column_stack([p, sigma0]) if model == 1 else np.column_stack([p, hill, sigma0])
+    return theta0, cur
+
+
 # ---- hierarchical start point (replaces the CMA-ES / scipy fits of PyHillFit.py:243-257,310-336) ---------------------
-def hierarchical_first_iteration(experiments, locs):
-    """theta0 = [alpha, beta, mu, s, pIC50_1, Hill_1, ..., sigma] as the reference builds it (:336), with
-    deterministic least-squares / maximum-likelihood fits instead of CMA-ES."""
-    best_fits = []
-    for ex in experiments:                                           # :243-257  per-experiment (pIC50, Hill) fit
-        th, ss = _fit_pic50_hill(ex[:, 0], ex[:, 1])
-        best_fits.append([th[0], th[1], np.sqrt(ss / len(ex))])      # initial_sigma, :101-102,255
-    best_fits = np.array(best_fits)
+def _fisk_logpdf(x, c, scale):
+    """log-logistic (scipy.stats.fisk) log-density, written out: the generic scipy.stats machinery costs ~100 us per call"""
+    z = x / scale
+    return np.log(c) - np.log(scale) + (c - 1.0) * np.log(z) - 2.0 * np.log1p(z ** c)
+
+
+def _hyper_start(best_fits, locs):
+    """(alpha, beta, mu, s, sigma) from a pair's per-experiment fits (PyHillFit.py:303-334)"""
     sigma_cur = np.mean(best_fits[:, -1])                            # :303-305
     if sigma_cur <= locs[3]:
         sigma_cur = locs[3] + 0.1
     hills = np.maximum(best_fits[:, 1], 1e-3)
-    nll = lambda x: -np.sum(st.fisk.logpdf(hills, c=abs(x[1]) + 1e-9, scale=abs(x[0]) + 1e-9))   # :310-324 (product of pdfs)
+    nll = lambda x: -np.sum(_fisk_logpdf(hills, abs(x[1]) + 1e-9, abs(x[0]) + 1e-9))   # :310-324 (product of pdfs)
     res = minimize(nll, np.array([max(np.median(hills), 0.1), 3.0]), method="Nelder-Mead", options={"xatol": 1e-8, "fatol": 1e-10})
     alpha_cur, beta_cur = abs(res.x[0]), min(abs(res.x[1]), 20.0)
     if alpha_cur <= locs[0]:
@@ -75,7 +194,28 @@ def hierarchical_first_iteration(experiments, locs):
         mu_cur = locs[2] + 0.1
     if s_cur <= locs[3]:
         s_cur = locs[3] + 0.1
-    return np.concatenate(([alpha_cur, beta_cur, mu_cur, s_cur], best_fits[:, :-1].flatten(), [sigma_cur]))
+    return alpha_cur, beta_cur, mu_cur, s_cur, sigma_cur
+
+
+def hierarchical_first_iteration_batch(experiments_per_pair, locs, pool_map=None):
+    """theta0 = [alpha, beta, mu, s, pIC50_1, Hill_1, ..., sigma] for every pair (PyHillFit.py:243-257,303-336): the
+    per-experiment (pIC50, Hill) least-squares fits of ALL pairs run as one batch (700 fits for the Crumb set; they were
+    85 % of the start-point time as one Nelder-Mead each), the two small distribution fits per pair stay scalar."""
+    flat = [(ex[:, 0], ex[:, 1]) for exs in experiments_per_pair for ex in exs]
+    p, hill, ss, n = _least_squares_batch(flat, 2, -2.0)           # pic50_hill_priors_lowers = (-2, 0), PyHillFit.py:218,253
+    tables, k = [], 0
+    for exs in experiments_per_pair:
+        m = len(exs)
+        tables.append(np.column_stack([p[k:k + m], hill[k:k + m], np.sqrt(ss[k:k + m] / n[k:k + m])]))   # initial_sigma, :101-102,255
+        k += m
+    locs = np.asarray(locs, float)
+    hypers = pool_map(_hyper_start, [(t, locs) for t in tables]) if pool_map is not None else [_hyper_start(t, locs) for t in tables]
+    return [np.concatenate((hy[:4], t[:, :-1].flatten(), [hy[4]])) for t, hy in zip(tables, hypers)]
+
+
+def hierarchical_first_iteration(experiments, locs):
+    """one pair (the batch of one)"""
+    return hierarchical_first_iteration_batch([experiments], locs)[0]
 
 
 def _fit_pic50_hill(concs, responses):

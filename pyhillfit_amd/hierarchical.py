@@ -250,7 +250,9 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     runs = []
     ordered = sorted(groups.items(), reverse=True)
     # all start points first, in one sweep over the worker pool (the file-writer processes start after it)
-    fits = writers.map(bestfit.hierarchical_first_iteration, [(m[2], locs) for _, members in ordered for m in members])
+    # (the least-squares fits of every experiment of every pair as ONE batch in this process, the two small distribution fits
+    # per pair over the pool)
+    fits = bestfit.hierarchical_first_iteration_batch([m[2] for _, members in ordered for m in members], locs, pool_map=writers.map)
     for ne, members in ordered:
         packed = PackedHierPoints([m[2] for m in members])
         theta0 = np.array(fits[:len(members)]); fits = fits[len(members):]

@@ -2,6 +2,7 @@
 own loader output (tests/golden/g4_pairs.json), path helpers, gamma table."""
 import os
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -151,6 +152,66 @@ def test_best_fit_start_points(dr):
     ne, _, ex = dr.load_crumb_data("Lidocaine", "KvLQT1/mink")          # all responses 0: SS = 0
     th, ss = bestfit.best_fit(*dr.concatenate_experiments(ne, ex), 2)
     assert ss < 1e-9 and th[2] == 1.0                                   # not the reference's absorbing sigma0 = 0
+
+
+def test_batched_least_squares_against_the_reference_objective_grid(dr):
+    """golden G8 (tests/golden/make_golden_bestfit.py): the reference's own sum_of_square_diffs (python/PyHillFit.py:93-97),
+    lifted and evaluated on a dense (pIC50, Hill) grid for every Crumb pair and both models.  The product's batched fit
+    (a) evaluates the same objective (probe points equal the reference's values), (b) reaches, for all 210 pairs, a sum of
+    squares no larger than the reference grid's minimum, with the reference's initial_sigma (:101-102) at it, (c) agrees with
+    the scalar Nelder-Mead fit it replaces, and (d) its start point is written in the form assemble_BFs.py:62-63 reads."""
+    import json
+    from conftest import GOLDEN
+    from pyhillfit_amd import bestfit, chainio
+    with open(os.path.join(GOLDEN, "g8_least_squares_grid.json")) as f:
+        g8 = json.load(f)
+    assert len(g8["pairs"]) == 210
+    pairs = []
+    for w in g8["pairs"]:
+        ne, _, ex = dr.load_crumb_data(w["drug"], w["channel"])
+        pairs.append(dr.concatenate_experiments(ne, ex))
+        for p_, h_, v in w["probes"]:
+            assert bestfit.sum_of_square_diffs([p_, h_], *pairs[-1]) == pytest.approx(v, rel=1e-13, abs=1e-300)
+    for model in (2, 1):
+        theta, ss = bestfit.best_fit_batch(pairs, model)
+        grid_min = np.array([w["model_%d" % model]["grid_min_ss"] for w in g8["pairs"]])
+        assert theta.shape == (210, model + 1)
+        assert np.all(ss <= grid_min * (1 + 1e-12) + 1e-20), np.max(ss - grid_min)
+        for k in range(210):                                          # the SS reported is the objective at the point reported
+            assert bestfit.sum_of_square_diffs([theta[k, 0], theta[k, 1] if model == 2 else 1.0], *pairs[k]) == pytest.approx(ss[k], rel=1e-9, abs=1e-12)
+        n = np.array([w["n"] for w in g8["pairs"]])
+        sig = np.sqrt(ss / n)
+        assert np.all(theta[:, -1] == np.where(sig > dr.sigma_loc, sig, 1.0))       # initial_sigma; 1 where SS = 0 (DESIGN.md section 7)
+        assert np.all(theta[:, 0] >= dr.pic50_exp_lower) and (model == 1 or np.all(theta[:, 1] > 0))
+        sub = list(range(3, 97, 5))                                   # a pair's fit does not depend on its batch (the multi-GPU
+        th_sub, ss_sub = bestfit.best_fit_batch([pairs[k] for k in sub], model)   # partitions start their chains from identical points)
+        assert np.array_equal(th_sub, theta[sub]) and np.array_equal(ss_sub, ss[sub])
+        for k in range(0, 210, 23):                                   # the scalar fit it replaces
+            th_nm, ss_nm = bestfit.best_fit(*pairs[k], model)
+            assert ss[k] <= ss_nm + 1e-6 * (1 + ss_nm)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "Amiodarone_hERG_best_fit_params.txt")
+        chainio.save_best_fit_params(path, theta[0], 1)
+        assert np.array_equal(np.loadtxt(path), theta[0])            # assemble_BFs.py:62-63
+        with open(path) as f:
+            assert f.readline().startswith("#") and f.readline().startswith("# pIC50, sigma")
+
+
+def test_hierarchical_start_points_batched(dr):
+    """per-experiment (pIC50, Hill) fits of all pairs in one batch == the scalar fits they replace (PyHillFit.py:243-257)"""
+    from pyhillfit_amd import bestfit
+    from pyhillfit_amd import hierarchical as H
+    shapes, scales, locs = H.prior_params()
+    names = [("Amiodarone", "hERG"), ("Amitriptyline", "Kv4.3"), ("Lidocaine", "KvLQT1/mink"), ("Verapamil", "Cav1.2")]
+    exs = [dr.load_crumb_data(d, c)[2] for d, c in names]
+    out = bestfit.hierarchical_first_iteration_batch(exs, locs)
+    for e, th in zip(exs, out):
+        assert len(th) == 5 + 2 * len(e) and np.all(th[:4] > locs[:4]) and th[-1] > locs[4]
+        assert np.array_equal(th, bestfit.hierarchical_first_iteration(e, locs))
+        for i, ex in enumerate(e):
+            th_nm, ss_nm = bestfit._fit_pic50_hill(ex[:, 0], ex[:, 1])
+            assert bestfit.sum_of_square_diffs([th[4 + 2 * i], th[5 + 2 * i]], ex[:, 0], ex[:, 1]) <= ss_nm + 1e-7 * (1 + ss_nm)
+            assert th[4 + 2 * i] >= -2.0 and th[5 + 2 * i] > 0
 
 
 def test_bench_profile_facts_only_apply_to_the_measured_launch_shape():
