@@ -199,22 +199,23 @@ def main(argv=None):
                 costs.append(0)
         mine = phfdist.shard_problems(costs, world)[rank]
         pairs = [pairs[i] for i in mine]
-    if args.hierarchical:
-        from .hierarchical import run_hierarchical
-        summaries = run_hierarchical(pairs, args, device, rank, world)
-    else:
-        summaries = run_single_level(pairs, args, device, rank, world)
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        # gather a compact numeric summary on rank 0 (pooled means of the first 3 columns + acceptance)
-        rows = torch.tensor([[s_["pooled_mean"][0], s_["pooled_mean"][-1], s_["acceptance"]] for s_ in summaries] or
-                            np.zeros((0, 3)), dtype=torch.float64, device=device).reshape(-1, 3)
-        allrows = phfdist.gather_rows(rows, dst=0)
-        if rank == 0:
-            print("gathered summaries from %d ranks: %d pairs" % (world, sum(len(a) for a in allrows)))
-        dist.barrier()
-    return summaries
+    try:
+        if args.hierarchical:
+            from .hierarchical import run_hierarchical
+            summaries = run_hierarchical(pairs, args, device, rank, world)
+        else:
+            summaries = run_single_level(pairs, args, device, rank, world)
+        if world > 1:
+            import torch
+            # gather a compact numeric summary on rank 0 (pooled means of the first 3 columns + acceptance)
+            rows = torch.tensor([[s_["pooled_mean"][0], s_["pooled_mean"][-1], s_["acceptance"]] for s_ in summaries] or
+                                np.zeros((0, 3)), dtype=torch.float64, device=device).reshape(-1, 3)
+            allrows = phfdist.gather_rows(rows, dst=0)
+            if rank == 0:
+                print("gathered summaries from %d ranks: %d pairs" % (world, sum(len(a) for a in allrows)))
+        return summaries
+    finally:
+        phfdist.finalize()       # also on an error or SystemExit of this rank: the others' next collective fails instead of hanging
 
 
 if __name__ == "__main__":

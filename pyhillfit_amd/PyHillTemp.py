@@ -52,74 +52,118 @@ def build_parser():
     return parser
 
 
-def run_tempered(pairs, temperatures, args, device):
-    """pairs: [(drug, channel)]; one problem per (pair, rung).  Returns summaries."""
+def partition_units(points_per_pair, num_rungs, world):
+    """The work units of a tempered run are (pair, rung): the reference maps the RUNGS of one pair over its process pool
+    (python/PyHillTemp.py:151-161), so `-d D -c C` on 8 GPUs must spread the 41 rungs, and --all-pairs spreads pairs x rungs.
+    Returns, per rank, a sorted array of unit numbers u = pair * num_rungs + rung (cost of a unit ~ the pair's points)."""
+    costs = np.repeat(np.asarray(points_per_pair, dtype=np.float64), num_rungs)
+    return phfdist.shard_problems(costs, world)
+
+
+def assemble_thermodynamic_integration(unit_rows, pairs, temperatures, model, run_facts):
+    """unit_rows: [n][4 + d + 1] = (pair, rung, log_py_pooled, log_py_chain0, pooled means...) from ALL ranks, any order.
+    Returns (per-rung records in (pair, rung) order, one thermodynamic-integration record per pair with all its rungs):
+    what python/compute_bayes_factors.py:67-83 recomputes from the chain files."""
+    unit_rows = np.asarray(unit_rows, dtype=np.float64)
+    R = len(temperatures)
+    order = np.lexsort((unit_rows[:, 1], unit_rows[:, 0]))
+    unit_rows = unit_rows[order]
+    keys = unit_rows[:, 0].astype(int) * R + unit_rows[:, 1].astype(int)
+    if not np.array_equal(keys, np.arange(len(pairs) * R)):
+        raise RuntimeError("tempered run: %d (pair, rung) units expected, %d distinct gathered" % (len(pairs) * R, len(np.unique(keys))))
+    rungs, tis = [], []
+    for ip, (drug, channel) in enumerate(pairs):
+        d_clean, c_clean = drug.replace('/', '_'), channel.replace('/', '_')
+        rows = unit_rows[ip * R:(ip + 1) * R]
+        for ir, temperature in enumerate(temperatures):
+            rungs.append({"drug": d_clean, "channel": c_clean, "temperature": float(temperature), "pooled_mean": rows[ir, 4:].tolist(),
+                          "chain_file": dr.nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature, make_dirs=False)[2],
+                          "log_py_pooled": float(rows[ir, 2]), "log_py_chain0": float(rows[ir, 3])})
+        ti = {"drug": d_clean, "channel": c_clean, "model": model, "temperatures": [float(t) for t in temperatures],
+              "log_py_pooled": rows[:, 2].tolist(), "log_py_chain0": rows[:, 3].tolist()}
+        ti.update(run_facts)
+        ti["expectation_pooled"] = float(dr.trapezium_rule(ti["temperatures"], ti["log_py_pooled"]))
+        ti["expectation_chain0"] = float(dr.trapezium_rule(ti["temperatures"], ti["log_py_chain0"]))
+        tis.append(ti)
+    return rungs, tis
+
+
+def run_tempered(pairs, temperatures, args, device, rank=0, world=1):
+    """pairs: [(drug, channel)] of the WHOLE run; one problem per (pair, rung), this rank's share of them sampled here.
+    Every rank writes the chain files of its own units; rank 0 gathers the per-unit expectations, writes one
+    thermodynamic_integration.json per pair and ONE run summary, and returns the per-rung records (other ranks: [])."""
     import torch
     from .sampler import SingleLevelSampler
     model = args.model
     d = dr.num_params
+    R = len(temperatures)
     loaded = []
     for drug, channel in pairs:
         num_expts, _, experiments = dr.load_crumb_data(drug, channel)
         loaded.append((drug, channel) + tuple(dr.concatenate_experiments(num_expts, experiments)))   # PyHillTemp.py:130-136
-    packed = dr.PackedPoints([(c, y) for _, _, c, y in loaded])
-    R = len(temperatures)
-    pair_index = [p for p in range(len(loaded)) for _ in range(R)]
-    temps = [float(t) for _ in loaded for t in temperatures]
-    all_pairs = [(a, b) for a in dr.drugs for b in dr.channels]
-    pids = [all_pairs.index((dg, ch)) * 1024 + r for dg, ch, _, _ in loaded for r in range(R)]
-    Q, C = len(pair_index), args.num_chains
+    mine = partition_units([len(c) for _, _, c, _ in loaded], R, world)[rank]
+    my_pairs = sorted(set(int(u) // R for u in mine))
+    local_of = {ip: k for k, ip in enumerate(my_pairs)}
+    C = args.num_chains
     total_iterations, thinning = args.iterations, args.thinning
     if total_iterations % thinning:
         raise SystemExit("iterations must be a multiple of thinning")
-    s = SingleLevelSampler(packed, model, pair_index, temps, C, thinning=thinning, seed=args.seed, adapt_start=1000 * d,
-                           reset_mean_at_adapt_start=True, problem_ids=pids, device=device)        # :83,114-115
-    s.init(np.ones(d), cov_identity=True, cov_scale=1.0)                                            # :63,80
     num_saved = total_iterations // thinning + 1                                                    # :70
     burn = num_saved // args.burn_in_fraction                                                       # :71
-    s.enable_moments(after_iteration=max(burn * thinning - 1, 0))
-    s.reserve(total_iterations)
-    kept = torch.empty((num_saved, Q, d + 1), dtype=torch.float64)
-    kept[0] = s.row0[:, :, 0].cpu()
-    writers = chainio.WriterPool(args.write_workers if args.write_workers is not None else chainio.default_write_workers())
-    seg = max(thinning, args.segment - args.segment % thinning)
-    buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
-    done, r = 0, 1
-    start = time.time()
-    while done < total_iterations:
-        k = min(seg, total_iterations - done)
-        nr = k // thinning
-        rows = s.advance(k, out=buf[:nr])
-        kept[r:r + nr] = rows[:, :, :, 0].cpu()
-        done += k; r += nr
-    torch.cuda.synchronize(device)
-    mcmc_time = time.time() - start
-    print("\nMCMC time: {} s\n".format(int(mcmc_time)))                                             # :162-163
-    mean, var, _ = s.posterior_moments()
-    mean = mean.cpu().numpy()
-    ll1 = s.mean_log_likelihood_t1().cpu().numpy()            # [Q][C]  E_rung[log L(theta; t=1)], fused into the sampler
-    out = []
-    for ip, (drug, channel, _, _) in enumerate(loaded):
-        for ir, temperature in enumerate(temperatures):
-            q = ip * R + ir
-            d_clean, c_clean, chain_file, _ = dr.nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature)
+    unit_rows = np.zeros((len(mine), 4 + d + 1))
+    mcmc_time = 0.0
+    if len(mine):
+        packed = dr.PackedPoints([(loaded[ip][2], loaded[ip][3]) for ip in my_pairs])
+        pair_index = [local_of[int(u) // R] for u in mine]
+        temps = [float(temperatures[int(u) % R]) for u in mine]
+        all_pairs = [(a, b) for a in dr.drugs for b in dr.channels]
+        # Philox problem ids are global — (pair's number in the data file, rung) — so a unit draws the same numbers on any rank
+        pids = [all_pairs.index((loaded[int(u) // R][0], loaded[int(u) // R][1])) * 1024 + int(u) % R for u in mine]
+        Q = len(mine)
+        s = SingleLevelSampler(packed, model, pair_index, temps, C, thinning=thinning, seed=args.seed, adapt_start=1000 * d,
+                               reset_mean_at_adapt_start=True, problem_ids=pids, device=device)        # :83,114-115
+        s.init(np.ones(d), cov_identity=True, cov_scale=1.0)                                            # :63,80
+        s.enable_moments(after_iteration=max(burn * thinning - 1, 0))
+        s.reserve(total_iterations)
+        kept = torch.empty((num_saved, Q, d + 1), dtype=torch.float64)
+        kept[0] = s.row0[:, :, 0].cpu()
+        writers = chainio.WriterPool(args.write_workers if args.write_workers is not None else chainio.default_write_workers(world))
+        seg = max(thinning, args.segment - args.segment % thinning)
+        buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
+        done, r = 0, 1
+        start = time.time()
+        while done < total_iterations:
+            k = min(seg, total_iterations - done)
+            nr = k // thinning
+            rows = s.advance(k, out=buf[:nr])
+            kept[r:r + nr] = rows[:, :, :, 0].cpu()
+            done += k; r += nr
+        torch.cuda.synchronize(device)
+        mcmc_time = time.time() - start
+        print("\nMCMC time: {} s\n".format(int(mcmc_time)))                                             # :162-163
+        mean, var, _ = s.posterior_moments()
+        mean = mean.cpu().numpy()
+        ll1 = s.mean_log_likelihood_t1().cpu().numpy()            # [Q][C]  E_rung[log L(theta; t=1)], fused into the sampler
+        for q, u in enumerate(mine):
+            ip, ir = int(u) // R, int(u) % R
+            drug, channel = loaded[ip][0], loaded[ip][1]
+            _, _, chain_file, _ = dr.nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperatures[ir])
             print("chain_file:", chain_file)
             writers.submit(chainio.save_tempered_chain, chain_file, kept[burn:, q].numpy())         # :125,169
-            out.append({"drug": d_clean, "channel": c_clean, "temperature": float(temperature),
-                        "pooled_mean": mean[:, q].mean(axis=1).tolist(), "chain_file": chain_file,
-                        "log_py_pooled": float(ll1[q].mean()), "log_py_chain0": float(ll1[q, 0])})
-        # thermodynamic integration (compute_bayes_factors.py:67-83): what that script recomputes from the chain files
-        rungs = out[ip * R:(ip + 1) * R]
-        ti = {"drug": d_clean, "channel": c_clean, "model": model, "temperatures": [float(t) for t in temperatures],
-              "log_py_pooled": [r_["log_py_pooled"] for r_ in rungs], "log_py_chain0": [r_["log_py_chain0"] for r_ in rungs],
-              "chains": C, "iterations": total_iterations, "thinning": thinning, "burn_in_fraction": args.burn_in_fraction}
-        ti["expectation_pooled"] = float(dr.trapezium_rule(ti["temperatures"], ti["log_py_pooled"]))
-        ti["expectation_chain0"] = float(dr.trapezium_rule(ti["temperatures"], ti["log_py_chain0"]))
+            unit_rows[q, :4] = ip, ir, ll1[q].mean(), ll1[q, 0]
+            unit_rows[q, 4:] = mean[:, q].mean(axis=1)
+        writers.close()
+    # ---- the one exchange step of the run: per-unit expectations to rank 0 (a few KB over RCCL / gloo) ----
+    gathered = phfdist.gather_rows(torch.as_tensor(unit_rows, device=phfdist.collective_device(device)), dst=0)
+    if rank != 0:
+        return []
+    facts = {"chains": C, "iterations": total_iterations, "thinning": thinning, "burn_in_fraction": args.burn_in_fraction, "ranks": world}
+    out, tis = assemble_thermodynamic_integration(np.concatenate(gathered), [(l[0], l[1]) for l in loaded], temperatures, model, facts)
+    for (drug, channel, _, _), ti in zip(loaded, tis):
         with open(thermodynamic_integration_file(model, drug, channel), "w") as f:
             json.dump(ti, f, indent=1)
-    writers.close()
     with open(dr.output_root + "/" + dr.dir_name + "/tempered_summary_model_%d.json" % model, "w") as f:
-        json.dump({"mcmc_seconds": mcmc_time, "chains": C, "rungs": out}, f, indent=1)
+        json.dump({"mcmc_seconds_rank0": mcmc_time, "chains": C, "ranks": world, "rungs": out}, f, indent=1)
     return out
 
 
@@ -147,11 +191,12 @@ def main(argv=None):
         pairs = [(a, b) for a in dr.drugs for b in dr.channels]
     else:
         pairs = [(dr.drugs[args.drug], dr.channels[args.channel])]       # :52-53
-    if world > 1:
-        pairs = [pairs[i] for i in phfdist.shard_problems([1.0] * len(pairs), world)[rank]]
     temperatures = dr.temperature_ladder(args.rungs)                     # :151
     print("\nDoing temperatures: {}\n".format(temperatures))
-    return run_tempered(pairs, temperatures, args, device) if pairs else []
+    try:
+        return run_tempered(pairs, temperatures, args, device, rank, world)
+    finally:
+        phfdist.finalize()
 
 
 if __name__ == "__main__":

@@ -73,39 +73,49 @@ class StreamWriters(object):
     """Chain files written WHILE the GPU samples: every file belongs to one of `workers` single-process executors (spawned,
     torch-free like WriterPool's), which executes its jobs in submission order — create the file with its header lines, then
     append the rows of each segment as the sampler delivers them.  The text is what one np.savetxt call would have
-    produced.  workers <= 0, or processes that cannot start, fall back to writing in the caller."""
+    produced.  workers <= 0, or processes that cannot start, write in the caller.
+
+    A worker that dies may have written any part of its last job.  Its files are therefore not patched but REWRITTEN by the
+    caller from the job history (create truncates the file, then every segment delivered so far, in order); the healthy
+    lanes keep their own files and go on.  The history holds references to the caller's row arrays, not copies."""
 
     def __init__(self, workers):
         ctx = mp.get_context("spawn")
         self.lanes = [ProcessPoolExecutor(1, mp_context=ctx) for _ in range(max(workers, 0))]
-        self.pending = []
+        self.dead = set()
+        self.pending = []                                       # (future, lane)
+        self.history = {}                                       # path -> [(fn, args), ...] in submission order
 
-    def _submit(self, key, fn, *args):
+    def _lane_of(self, path):
+        return hash(path) % len(self.lanes)
+
+    def _submit(self, path, fn, *args):
+        self.history.setdefault(path, []).append((fn, args))
         if self.lanes:
-            try:
-                self.pending.append((self.lanes[hash(key) % len(self.lanes)].submit(fn, *args), fn, args))
-                return
-            except BrokenProcessPool:
-                self._broken()
+            lane = self._lane_of(path)
+            if lane not in self.dead:
+                try:
+                    self.pending.append((self.lanes[lane].submit(fn, *args), lane))
+                    return
+                except BrokenProcessPool:
+                    self._lane_broke(lane)                      # rewrites the lane's files from the history, this job included
+                    return
         fn(*args)
 
-    def _broken(self):
-        print("chainio.StreamWriters: worker processes unavailable, continuing in the main process")
-        done = []
-        for f, fn, args in self.pending:                      # replay, in order, whatever did not complete
-            try:
-                if f.done() and f.exception() is None:
-                    continue
-            except Exception:
-                pass
-            done.append((fn, args))
-        for lane in self.lanes:
-            lane.shutdown(wait=False)
-        self.lanes, self.pending = [], []
-        for fn, args in done:
-            fn(*args)
+    def _lane_broke(self, lane):
+        if lane in self.dead:
+            return
+        print("chainio.StreamWriters: a writer process died, its files are rewritten in the main process")
+        self.dead.add(lane)
+        self.lanes[lane].shutdown(wait=False)
+        self.pending = [(f, l) for f, l in self.pending if l != lane]
+        for path, jobs in self.history.items():
+            if self._lane_of(path) == lane:
+                for fn, args in jobs:                           # the first job of a file is its create ('w': truncates)
+                    fn(*args)
 
     def create(self, path, header_lines, first_rows=None):
+        self.history.pop(path, None)
         self._submit(path, _create_file, path, header_lines, first_rows)
 
     def append(self, path, rows):
@@ -113,17 +123,18 @@ class StreamWriters(object):
 
     def close(self):
         try:
-            for f, fn, args in list(self.pending):
+            while self.pending:
+                f, lane = self.pending.pop(0)
                 try:
                     f.result()
                 except BrokenProcessPool:
-                    self._broken()
-                    break
+                    self._lane_broke(lane)
         finally:
             self.pending = []
-            for lane in self.lanes:
-                lane.shutdown()
-            self.lanes = []
+            for k, lane in enumerate(self.lanes):
+                if k not in self.dead:
+                    lane.shutdown()
+            self.lanes, self.history = [], {}
 
 
 def _create_file(path, header_lines, first_rows):

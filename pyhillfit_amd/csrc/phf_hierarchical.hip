@@ -269,114 +269,22 @@ __global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Generic path for any Ne <= PHF_HIER_MAX_EXPTS (dim = 5 + 2 Ne known only at run time): theta, mean and the factor stay
-// in the HBM state buffer (struct-of-arrays, coalesced across the lanes of a wave); proposal, normals and the update
-// vector live in LDS, lane-interleaved.  16 chains per block so that 3*dim doubles per chain fit (dim 105 -> 40 KB).
-constexpr int kGenBlock = 16;
+// Pairs with more experiments than the per-Ne kernels are compiled for (Ne > PHF_HIER_FAST_EXPTS, up to PHF_HIER_MAX_EXPTS = 64:
+// dim = 5 + 2 Ne known only at run time).
 
 __device__ __forceinline__ double gen_target(const HierArgs& a, int ne, int pair, const double* th, int ts, phf_ktab k_exp, phf_ktab k_log) {
   return phf_hier_log_target_any(ne, a.pts.expt_start + (size_t)pair * (ne + 1), a.pts.ln_conc + (size_t)pair * a.pts.stride,
                                  a.pts.response + (size_t)pair * a.pts.stride, th, ts, &a.prior, k_exp, k_log);
 }
 
-__global__ __launch_bounds__(kGenBlock) void hier_generic_advance_kernel(const HierArgs a) {
-  extern __shared__ double s_mem[];
-  const int ne = a.pts.n_expts;
-  const int D = 5 + 2 * ne;
-  double* s_star = s_mem + threadIdx.x;                       // element i: s_star[i * kGenBlock]
-  double* s_z = s_star + (size_t)D * kGenBlock;
-  double* s_w = s_z + (size_t)D * kGenBlock;
-  const int q = blockIdx.x / a.blocks_per_problem;
-  const int chunk = blockIdx.x - q * a.blocks_per_problem;
-  const int C = a.prob.chains_per_problem;
-  const int c = chunk * kGenBlock + threadIdx.x;
-  if (c >= C) return;
-  const int pair = a.prob.pair_index[q];
-  const uint32_t pid = a.prob.problem_id[q];
-  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
-  const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
-  const size_t nch = (size_t)a.prob.num_problems * C;
-  const size_t g = (size_t)q * C + c;
-  double* th = a.state + g;                                   // element i: th[i * nch]
-  double* plt = th + (size_t)D * nch;
-  double* mean = plt + nch;
-  double* L = mean + (size_t)D * nch;                         // packed lower triangle, element e: L[e * nch]
-  double* ploga = L + (size_t)(D * (D + 1) / 2) * nch;
-  double* pnacc = ploga + nch;
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
-  double lt = *plt, loga = *ploga, nacc = *pnacc;
-  double sc = phf_exp_fast_k(0.5 * loga, k_exp);
-  const int thin = a.cfg.thinning;
-  int until_save = thin - (int)(a.t_begin % thin);
-  double* out = a.rows ? a.rows + ((size_t)q * (D + 1)) * C + c : nullptr;
-  const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
-  for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
-    const double log_u = phf_hier_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, s_z, kGenBlock);
-    for (int i = 0; i < D; ++i) {
-      double v = L[(size_t)(i * (i + 1) / 2 + i) * nch] * s_z[i * kGenBlock];
-      for (int k = i - 1; k >= 0; --k) v = phf_fma(L[(size_t)(i * (i + 1) / 2 + k) * nch], s_z[k * kGenBlock], v);
-      s_star[i * kGenBlock] = phf_fma(sc, v, th[(size_t)i * nch]);
-    }
-    const double lt_star = gen_target(a, ne, pair, s_star, kGenBlock, k_exp, k_log);
-    const bool acc = log_u < lt_star - lt;
-    if (acc) {
-      for (int i = 0; i < D; ++i) th[(size_t)i * nch] = s_star[i * kGenBlock];
-      lt = lt_star;
-    }
-    nacc += acc ? 1.0 : 0.0;
-    if (t > a.cfg.adapt_start) {
-      const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
-      const double omg = 1.0 - gs;
-      const double sqa = phf_sqrt_pos(omg), sqg = phf_sqrt_pos(gs);
-      for (int i = 0; i < D; ++i) s_w[i * kGenBlock] = sqg * (th[(size_t)i * nch] - mean[(size_t)i * nch]);
-      for (int i = 0; i < D; ++i) mean[(size_t)i * nch] = phf_fma(gs, th[(size_t)i * nch], omg * mean[(size_t)i * nch]);
-      loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
-      for (int k = 0; k < D; ++k) {
-        const double wk = s_w[k * kGenBlock];
-        const double tkk = sqa * L[(size_t)(k * (k + 1) / 2 + k) * nch];
-        const double r = phf_sqrt_nonneg(phf_fma(tkk, tkk, wk * wk));
-        const double inv = (r > 0.0) ? phf_rcp(r) : 0.0;
-        const double cs = (r > 0.0) ? tkk * inv : 1.0;
-        const double sn = wk * inv;
-        L[(size_t)(k * (k + 1) / 2 + k) * nch] = r;
-        for (int i = k + 1; i < D; ++i) {
-          const double tik = sqa * L[(size_t)(i * (i + 1) / 2 + k) * nch];
-          const double wi = s_w[i * kGenBlock];
-          L[(size_t)(i * (i + 1) / 2 + k) * nch] = phf_fma(cs, tik, sn * wi);
-          s_w[i * kGenBlock] = phf_fma(cs, wi, -(sn * tik));
-        }
-      }
-      sc = phf_exp_fast_k(0.5 * loga, k_exp);
-    }
-    if (--until_save == 0) {
-      until_save = thin;
-      if (out) {
-        for (int i = 0; i < D; ++i) out[(size_t)i * C] = th[(size_t)i * nch];
-        out[(size_t)D * C] = lt;
-        out += row_stride;
-      }
-      if (a.moments && t > a.moments_after) {
-        for (int i = 0; i < D; ++i) {
-          const double x = th[(size_t)i * nch];
-          a.moments[(size_t)i * nch + g] += x;
-          a.moments[(size_t)(D + 1 + i) * nch + g] = phf_fma(x, x, a.moments[(size_t)(D + 1 + i) * nch + g]);
-        }
-        a.moments[(size_t)D * nch + g] += lt;
-        a.moments[(size_t)(2 * D + 1) * nch + g] = phf_fma(lt, lt, a.moments[(size_t)(2 * D + 1) * nch + g]);
-      }
-    }
-  }
-  *plt = lt; *ploga = loga; *pnacc = nacc;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // One WAVEFRONT per chain, for pairs with many experiments (dim = 5 + 2 Ne up to 133): the chain's factor (dim(dim+1)/2
 // doubles: 44.5 KB at dim 105), theta, mean, proposal and normals live in LDS; the 64 lanes take one experiment each in
 // the target (phf_hier_experiment_terms) and the rows lane, lane+64, ... of the factor in the proposal and in the Givens
-// sweep.  Every element is computed by the same operations in the same order as in hier_generic_advance_kernel and the
-// twin (the per-experiment sums are added in experiment order by every lane), so results are bit-identical; what changes
-// is the cost: the state no longer streams through HBM once per iteration (1.2 ms per iteration at dim 105 -> tens of us).
+// sweep.  Every element is computed by the same operations in the same order as in the twin (the per-experiment sums are
+// added in experiment order by every lane), so results are bit-identical.  (A first version kept the state in HBM, 16 chains
+// per block: 1.2 ms per iteration at dim 105 against tens of us here.  It was unreachable once this kernel covered every
+// supported dimension — 71 KB of LDS at Ne = 64 — and has been removed.)
 struct WaveLds {
   int D, tri, stride, ne;
   __host__ __device__ size_t doubles() const { return (size_t)tri + 4 * (size_t)D + 3 * 64 + 2 * (size_t)stride; }
@@ -593,8 +501,7 @@ int check(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_p
   if (prob) {
     if (prob->num_problems <= 0 || prob->chains_per_problem <= 0 || !prob->pair_index || !prob->problem_id)
       return phf_fail(PHF_ERR_INVALID_ARGUMENT, "incomplete phf_problems");
-    const int blk = (pts->n_expts > PHF_HIER_FAST_EXPTS) ? kGenBlock : kBlock;
-    const int64_t bpp = (prob->chains_per_problem + blk - 1) / blk;
+    const int64_t bpp = (pts->n_expts > PHF_HIER_FAST_EXPTS) ? prob->chains_per_problem : (prob->chains_per_problem + kBlock - 1) / kBlock;
     if (bpp * prob->num_problems > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
     if ((int64_t)prob->num_problems * prob->chains_per_problem > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains");
   }
@@ -673,7 +580,7 @@ int launch_wave_advance(const HierArgs& a, hipStream_t stream, bool* launched) {
   WaveLds w;
   w.ne = a.pts.n_expts; w.D = 5 + 2 * w.ne; w.tri = w.D * (w.D + 1) / 2; w.stride = a.pts.stride;
   *launched = false;
-  if (w.bytes() > 160 * 1024) return PHF_OK;                     // dimension too large for LDS: the HBM-state kernel below
+  if (w.bytes() > 160 * 1024) return PHF_OK;                     // dimension too large for LDS (cannot happen for Ne <= 64): caller reports it
   const int64_t blocks = (int64_t)a.prob.num_problems * a.prob.chains_per_problem;
   if (blocks > 0x7fffffffLL) return PHF_OK;
   static bool configured[kMaxDevices] = {};
@@ -694,21 +601,7 @@ int launch_generic_advance(HierArgs a, hipStream_t stream) {
   bool launched = false;
   const int rc = launch_wave_advance(a, stream, &launched);
   if (rc != PHF_OK || launched) return rc;
-  const int D = 5 + 2 * a.pts.n_expts;
-  const size_t lds = (size_t)3 * D * kGenBlock * 8;
-  if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "dimension too large for the generic hierarchical kernel");
-  static bool configured[kMaxDevices] = {};
-  const int dev = current_device();
-  if (!configured[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_generic_advance_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    configured[dev] = true;
-  }
-  a.blocks_per_problem = (a.prob.chains_per_problem + kGenBlock - 1) / kGenBlock;
-  hipLaunchKernelGGL(hier_generic_advance_kernel, dim3((unsigned)(a.blocks_per_problem * a.prob.num_problems)), dim3(kGenBlock), lds, stream, a);
-  return phf_check_launch("phf_hierarchical_advance (generic Ne)");
+  return phf_fail(PHF_ERR_UNSUPPORTED, "hierarchical state does not fit in LDS (dimension too large, or too many chains for one launch)");
 }
 
 int launch_generic_init(HierArgs a, hipStream_t stream) {

@@ -34,6 +34,22 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def collective_device(device):
+    """where a tensor must live to go through the current process group: the GPU for RCCL, host memory for gloo"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return device
+    return "cpu"
+
+
+def finalize():
+    """leave the process group (every CLI does this in a `finally`, so that a rank that fails does not leave the others
+    waiting in a collective for ever: their next collective then raises instead of hanging)"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def shard_problems(costs, world):
     """Partition problems over ranks, balancing cost (a problem costs ~ its number of points):
     longest-processing-time greedy, deterministic.  Returns a list of index arrays, one per rank."""

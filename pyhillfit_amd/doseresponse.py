@@ -331,13 +331,14 @@ def hierarchical_output_dirs_and_chain_file(drug, channel, Ne=0):
     return drug, channel, output_dir, chain_dir, figs_dir, chain_file
 
 
-def nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature):
-    """doseresponse.py:115-128."""
+def nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature, make_dirs=True):
+    """doseresponse.py:115-128.  (make_dirs=False: only name the files — rank 0 lists the chain files other ranks wrote)"""
     drug, channel = _clean(drug), _clean(channel)
     temperature = py2_str(temperature)
     output_dir = '{}/{}/single-level/{}/{}/model_{}/temperature_{}/'.format(output_root, dir_name, drug, channel, model, temperature)
     chain_dir, images_dir = output_dir + 'chain/', output_dir + 'figures/'
-    _mk(output_dir, chain_dir, images_dir)
+    if make_dirs:
+        _mk(output_dir, chain_dir, images_dir)
     chain_file = chain_dir + '{}_{}_model_{}_temp_{}_chain_single-level.txt'.format(drug, channel, model, temperature)
     return drug, channel, chain_file, images_dir
 

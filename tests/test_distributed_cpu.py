@@ -73,3 +73,71 @@ def test_broadcast_and_gather_world_size_2():
     assert np.array_equal(ids, np.arange(210))                                        # every problem summarised once
     allrows = np.vstack([np.array(r_) for r_ in rows])
     assert np.array_equal(np.unique(allrows[:, 1] / (0.5 * np.log(2 * np.pi))).round().astype(int), [6, 7, 12, 13, 14, 15, 16, 18, 19, 20])   # pi_bit payload intact
+
+
+# ---- PyHillTemp: (pair, rung) work units over the ranks (python/PyHillTemp.py:151-161 maps the rungs of ONE pair over its pool) ----
+def test_tempered_units_partition_covers_every_pair_and_rung():
+    from pyhillfit_amd import PyHillTemp as T
+    for points, R, world in (([12], 41, 8), ([12, 20, 6], 32, 2), ([12] * 210, 32, 8), ([7], 3, 8)):
+        parts = T.partition_units(points, R, world)
+        assert len(parts) == world
+        allu = np.sort(np.concatenate(parts))
+        assert np.array_equal(allu, np.arange(len(points) * R))                       # disjoint and complete
+        sizes = [len(p) for p in parts]
+        if len(set(points)) == 1:
+            assert max(sizes) - min(sizes) <= 1                                        # ONE pair on 8 GPUs: 41 rungs -> 6,5,5,5,5,5,5,5
+    assert sorted(len(p) for p in T.partition_units([12], 41, 8)) == [5] * 7 + [6]
+
+
+def _tempered_worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from pyhillfit_amd import PyHillTemp as T
+    from pyhillfit_amd import distributed as pd
+    from pyhillfit_amd import doseresponse as dr
+    pd.init(backend="gloo")
+    try:
+        pd.setup_data_file(os.path.join(REPO, "data", "crumb_dataset.json") if rank == 0 else "/nonexistent.json", src=0)
+        dr.define_model(2)
+        dr.output_root = tmp
+        pairs = [("Amiodarone", "hERG"), ("Bepridil", "Kv4.3")]
+        temperatures = dr.temperature_ladder(4)                                        # 5 rungs
+        R, d = len(temperatures), 3
+        mine = T.partition_units([12, 16], R, world)[rank]
+        # stand-in for the sampler's per-unit expectations: a known function of (pair, rung), so the assembly can be checked
+        rows = np.array([[u // R, u % R, -100.0 + 7 * (u // R) + 10 * temperatures[u % R], -99.0 + u, 6.0, 1.0, 8.0, -40.0 - u] for u in mine]).reshape(-1, 4 + d + 1)
+        gathered = pd.gather_rows(torch.as_tensor(rows, device=pd.collective_device("cuda:0")), dst=0)
+        out = None
+        if rank == 0:
+            rungs, tis = T.assemble_thermodynamic_integration(np.concatenate(gathered), pairs, temperatures, 2, {"chains": 64, "ranks": world})
+            out = (len(rungs), [r_["temperature"] for r_ in rungs[:R]], [t["expectation_pooled"] for t in tis], tis[1]["log_py_chain0"],
+                   rungs[R]["drug"], rungs[R]["chain_file"], tis[0]["ranks"])
+        q.put((rank, len(mine), out))
+        dist.barrier()
+    finally:
+        pd.finalize()
+    assert not dist.is_initialized()
+
+
+def test_tempered_pair_rung_units_gathered_and_assembled_world_size_2(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tempered_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    assert res[0][1] + res[1][1] == 10 and min(res[0][1], res[1][1]) >= 4             # both ranks sampled rungs of the 2 pairs
+    n, temps, expect, chain0, drug, chain_file, ranks = res[0][2]
+    lad = (np.arange(5) / 4.) ** 3
+    assert res[1][2] is None and n == 10 and np.allclose(temps, lad) and ranks == 2
+    trap = lambda v: float(np.sum(0.5 * (v[1:] + v[:-1]) * np.diff(lad)))             # doseresponse.py:192-193
+    assert expect == pytest.approx([trap(-100.0 + 10 * lad), trap(-93.0 + 10 * lad)], rel=1e-12)
+    assert chain0 == [-99.0 + u for u in range(5, 10)] and drug == "Bepridil"
+    assert chain_file.endswith("single-level/Bepridil/Kv4.3/model_2/temperature_0.0/chain/Bepridil_Kv4.3_model_2_temp_0.0_chain_single-level.txt")
+    with pytest.raises(RuntimeError):                                                  # a missing unit is an error, not a silent gap
+        from pyhillfit_amd import PyHillTemp as T
+        from pyhillfit_amd import doseresponse as dr
+        dr.setup(os.path.join(REPO, "data", "crumb_dataset.json")); dr.define_model(2)
+        T.assemble_thermodynamic_integration(np.zeros((3, 8)), [("Amiodarone", "hERG")], lad, 2, {})
