@@ -47,8 +47,9 @@ def test_pyhillfit_single_level_cli(csv_file, tmp_path):
         best = np.loadtxt(os.path.join(base, "figures", "%s_%s_best_fit_params.txt" % (drug, cc)))
         ne, _, ex = dr.load_crumb_data(drug, channel)
         concs, y = dr.concatenate_experiments(ne, ex)
-        th0, _ = bestfit.best_fit(concs, y, 2)
+        th0 = bestfit.best_fit_batch([(concs, y)], 2)[0][0]                # a pair's fit does not depend on its batch
         assert np.array_equal(best, th0)
+        assert bestfit.best_fit(concs, y, 2)[0] == pytest.approx(th0, rel=1e-5)   # the scalar Nelder-Mead fit it replaces
         # chain 0 == CPU twin started at the same point, same Philox stream (problem id = index in drugs x channels)
         pk = co.PackedPair(concs, y, 2, 1.0)
         st = pk.init_state(th0, False, 0.05)

@@ -55,7 +55,7 @@ def main():
     kernels = [k for k in ks if "SQ_INSTS_VALU" in ks[k]]
     key = max(kernels, key=lambda k: ks[k]["SQ_INSTS_VALU"]) if a.kernel is None else [k for k in kernels if k.startswith(a.kernel)][0]
     # a workload made of several kernels (c4: one per Ne group): sums over the kernels
-    group = kernels if w == "c4" else [key]
+    group = [k for k in kernels if "advance" in k] if w == "c4" else [key]
     tot = lambda c: sum(ks[k].get(c, 0.0) for k in group)
     waves = tot("SQ_WAVES")
     per = lambda c: tot(c) / (waves * a.iters)

@@ -21,10 +21,10 @@ if want two_ranks; then PHF_BENCH_BACKEND=gloo step bench_2rank 500 python bench
 cd /tmp && export TMPDIR=/tmp
 if want rocprof; then
   step rocprof 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -- python $R/bench.py --steps 5 --warmup 5 --no-cpu-baseline
-  if want c4; then step rocprof_c4 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c4 -- python $R/bench.py --workload c4 --steps 3 --warmup 4 --no-cpu-baseline; fi
+  for W in ${PHF_ROCPROF_EXTRA:-}; do step rocprof_$W 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$W -- python $R/bench.py --workload $W --steps 3 --warmup 4 --no-cpu-baseline; done
 fi
 if want pmc; then
-  W="${PHF_PMC_WORKLOAD:-c3}"
+ for W in ${PHF_PMC_WORKLOAD:-c3}; do
   i=0
   for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64" \
              "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES SQ_INST_CYCLES_VMEM" \
@@ -32,5 +32,6 @@ if want pmc; then
     i=$((i+1))
     step pmc_${W}_$i 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${W}_$i -- python $R/bench.py --workload $W --steps 3 --warmup 2 --no-cpu-baseline
   done
-  cd $R && python tools/pmc_summary.py gpurun_out/pmc_${W}_*/ > gpurun_out/pmc_${W}_summary.txt 2>&1; tail -n 30 gpurun_out/pmc_${W}_summary.txt
+  (cd $R && rm -f gpurun_out/pmc_${W}_summary.txt && python tools/pmc_summary.py gpurun_out/pmc_${W}_[0-9]*/ > gpurun_out/pmc_${W}_summary.txt 2>&1; tail -n 20 gpurun_out/pmc_${W}_summary.txt)
+ done
 fi
