@@ -106,3 +106,51 @@ def test_bayes_factor_fused_equals_chain_file_sweep(csv_file, tmp_path):
         assert np.all(np.diff(ti["log_py_pooled"]) > 0)            # hotter rungs fit the data better
     assert 1e-3 < fused["B12"] < 1e3      # evidence ratio of two nested, similarly good models (better fit vs Occam factor)
     assert fused["expectations"][1] == pytest.approx(swept["expectations"][1], abs=0.5)   # pooled 64 chains vs chain 0
+
+
+def test_rccl_backend_collectives_of_the_multi_gpu_path(tmp_path):
+    """The N > 1 path runs over RCCL (backend "nccl") and can only be launched by the driver on a multi-GPU node; the gloo
+    world-2 tests cover its logic on CPU.  Here the SAME helper calls (one-reader data set-up, packed-points broadcast,
+    ragged gather, MAX/SUM all-reduce, barrier, finalize) go through the RCCL backend itself in a world of one rank on the
+    GPU — a fresh process, like a torchrun rank — so that API use the gloo tests cannot see (device placement of the
+    collectives' tensors, gather support of the backend) is exercised before the scaling run."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    script = tmp_path / "rank.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from pyhillfit_amd import distributed as D, doseresponse as dr
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl" and D.collective_device(dev) == dev
+box = [("a", 1)]
+dist.broadcast_object_list(box, src=0)
+D.setup_data_file(os.path.join(%r, "data", "crumb_dataset.json"))
+packed = dr.pack_single_level([(d, c) for d in dr.drugs[:3] for c in dr.channels])
+shape = torch.tensor([packed.num_pairs, packed.stride], dtype=torch.int64, device=dev)
+dist.broadcast(shape, 0)
+for a in (packed.ln_conc, packed.counts):
+    t = torch.from_numpy(a).to(dev); dist.broadcast(t, 0); assert np.array_equal(t.cpu().numpy(), a)
+local = torch.arange(12, dtype=torch.float64, device=dev).reshape(4, 3)
+n = torch.tensor([4], dtype=torch.int64, device=dev); sizes = [torch.zeros_like(n)]
+dist.all_gather(sizes, n)
+outs = [torch.zeros_like(local)]
+dist.gather(local, outs, dst=0)
+assert torch.equal(outs[0], local) and int(sizes[0]) == 4
+tt = torch.tensor([1.25], dtype=torch.float64, device=dev)
+dist.all_reduce(tt, op=dist.ReduceOp.MAX); dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+assert float(tt) == 1.25
+dist.barrier()
+torch.cuda.synchronize()
+D.finalize()
+assert not dist.is_initialized()
+print("RCCL_WORLD1_OK")
+''' % (REPO, REPO))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
