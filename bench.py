@@ -123,6 +123,7 @@ def parse_args(argv=None):
     ap.add_argument("--chains", type=int, default=None, help="chains per problem (default: 65536 c2, 4096 c3, 1024 c4/c5)")
     ap.add_argument("--thinning", type=int, default=5)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--moments", action="store_true", help="also accumulate posterior moments and <log L> on the device (what the CLIs and the thermodynamic-integration path run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args(argv)
 
@@ -284,6 +285,8 @@ def main():
         s.chains = Q * C
         s.make_rows = lambda I: torch.empty((s.rows_between(0, I), Q, s.d + 1, C), dtype=torch.float64, device=dev)
         s.acceptance_summary = lambda: s.acceptance().mean(dim=1)
+        if a.moments:
+            s.enable_moments(after_iteration=0)
     s.reserve((a.warmup + a.steps) * I)
     rows = s.make_rows(I)
 
@@ -335,7 +338,7 @@ def main():
             "metric": "MCMC samples/sec (whole node)", "value": value, "unit": "MH samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "real Crumb dose-response rows (data/crumb_dataset.json), synthetic chain batch",
-            "config": {"workload": label, "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": s.chains,
+            "config": {"workload": label + (" + on-device moments" if a.moments else ""), "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": s.chains,
                        "chains_all_gpus": chains_total,
                        "adaptation": "on (steps start after iteration %d > adapt_start %d)" % (a.warmup * I, s.adapt_start),
                        "mean_acceptance": float(acc_all.mean()), "problems_reporting": int(acc_all.shape[0])},

@@ -238,7 +238,9 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
 }
 
 // Entry-count shapes with a straight-line body: 1..4 uncensored x 0..4 censored entries = 203 of the 210 Crumb pairs
-// (the set has 4 nominal doses per pair); anything else, and the moment-accumulating variant, runs the run-time loops.
+// (the set has 4 nominal doses per pair); anything else runs the run-time loops.  The moment-accumulating builds (what the
+// command lines and the thermodynamic-integration path run) have the same bodies: with the run-time loops a wavefront that has
+// its SIMD to itself — 64 chains per pair — was 25 % slower (C2 shape: 4.34 ms against 3.27).
 #define PHF_SHAPE_CASE(ko, kc) \
   case (ko) * 8 + (kc): advance_body<MODEL, MOMENTS, ko, kc, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens); break;
 #define PHF_SHAPE_ROW(ko) PHF_SHAPE_CASE(ko, 0) PHF_SHAPE_CASE(ko, 1) PHF_SHAPE_CASE(ko, 2) PHF_SHAPE_CASE(ko, 3) PHF_SHAPE_CASE(ko, 4)
@@ -256,14 +258,12 @@ __global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceAr
   stage_points(a.pts, pair, s_pts, n_other, n_zero, n_hundred);
   if (c >= a.prob.chains_per_problem) return;
   const int n_cens = n_zero + n_hundred;
-  if constexpr (!MOMENTS) {
-    if (n_other <= 4 && n_cens <= 4) {
-      switch (n_other * 8 + n_cens) {                   // wave-uniform
-        PHF_SHAPE_ROW(1) PHF_SHAPE_ROW(2) PHF_SHAPE_ROW(3) PHF_SHAPE_ROW(4)
-        default: advance_body<MODEL, MOMENTS, -1, -1, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens); break;
-      }
-      return;
+  if (n_other <= 4 && n_cens <= 4) {
+    switch (n_other * 8 + n_cens) {                     // wave-uniform
+      PHF_SHAPE_ROW(1) PHF_SHAPE_ROW(2) PHF_SHAPE_ROW(3) PHF_SHAPE_ROW(4)
+      default: advance_body<MODEL, MOMENTS, -1, -1, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens); break;
     }
+    return;
   }
   advance_body<MODEL, MOMENTS, -1, -1, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens);
 }
@@ -437,15 +437,15 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
   const size_t lds = (size_t)pts->stride * 24;
   const bool lone = (int64_t)grid.x <= phf_simd_count();      // one wavefront per SIMD at most: let it have the whole register file
   hipStream_t s = (hipStream_t)stream;
+#define PHF_LAUNCH_ADVANCE(M, MOM, W) hipLaunchKernelGGL((mh_advance_kernel<M, MOM, W>), grid, block, lds, s, a)
   if (cfg->model == 1) {
-    if (moments) hipLaunchKernelGGL((mh_advance_kernel<1, true, 2>), grid, block, lds, s, a);
-    else if (lone) hipLaunchKernelGGL((mh_advance_kernel<1, false, 1>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((mh_advance_kernel<1, false, 2>), grid, block, lds, s, a);
+    if (moments) { if (lone) PHF_LAUNCH_ADVANCE(1, true, 1); else PHF_LAUNCH_ADVANCE(1, true, 2); }
+    else { if (lone) PHF_LAUNCH_ADVANCE(1, false, 1); else PHF_LAUNCH_ADVANCE(1, false, 2); }
   } else {
-    if (moments) hipLaunchKernelGGL((mh_advance_kernel<2, true, 2>), grid, block, lds, s, a);
-    else if (lone) hipLaunchKernelGGL((mh_advance_kernel<2, false, 1>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((mh_advance_kernel<2, false, 2>), grid, block, lds, s, a);
+    if (moments) { if (lone) PHF_LAUNCH_ADVANCE(2, true, 1); else PHF_LAUNCH_ADVANCE(2, true, 2); }
+    else { if (lone) PHF_LAUNCH_ADVANCE(2, false, 1); else PHF_LAUNCH_ADVANCE(2, false, 2); }
   }
+#undef PHF_LAUNCH_ADVANCE
   return phf_check_launch("phf_single_level_advance");
 }
 

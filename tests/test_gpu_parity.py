@@ -219,6 +219,18 @@ def test_every_entry_count_shape_bit_identical_to_cpu_twin(model, chains, gpu):
             rows = pk.advance(st, 0, T, thin, adapt, False, gam, seed=99, chain_id=c, problem_id=q)
             assert np.array_equal(chain[:, q, :, c], rows), (shapes[q], c)
             assert np.array_equal(state[:, q, c], st), (shapes[q], c)
+    # the moment-accumulating builds of the same bodies (what the command lines run): same chains bit for bit, and the device
+    # accumulators are the sums of the rows saved after `after_iteration`
+    m = SingleLevelSampler(packed, model, list(range(Q)), [1.0] * Q, chains, thinning=thin, seed=99, adapt_start=adapt, device=gpu)
+    m.init(theta0, cov_identity=False, cov_scale=0.05)
+    m.enable_moments(after_iteration=adapt)
+    chain_m = np.concatenate([m.advance(k).cpu().numpy() for k in (adapt + 1, T - adapt - 1)])
+    assert np.array_equal(chain_m, chain) and np.array_equal(m.state.cpu().numpy().reshape(s.S, Q, chains), state)
+    mean, var, n = m.posterior_moments()
+    keep = chain[adapt // thin:]
+    assert n == len(keep)
+    np.testing.assert_allclose(mean.cpu().numpy(), keep.mean(axis=0).transpose(1, 0, 2), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(var.cpu().numpy(), keep.var(axis=0, ddof=1).transpose(1, 0, 2), rtol=1e-7, atol=1e-10)
 
 
 def test_shard_invariance_and_resume_full_width(gpu, dr):
