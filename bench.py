@@ -264,6 +264,8 @@ def main():
     if a.workload == "c4":
         s = HierarchicalBatch(dr, names, C, a.thinning, chain_id_base, dev, torch)
         kernel_name = "hier_advance_kernel<Ne=3..6>"
+        if a.moments:
+            [h.enable_moments(after_iteration=0) for h in s.samplers]
     else:
         packed = dr.pack_single_level(names) if rank == 0 or a.scaling == "strong" else None
         if a.scaling == "weak":
