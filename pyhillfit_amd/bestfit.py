@@ -170,14 +170,87 @@ def best_fit_batch(pairs, model):
 
 
 # ---- hierarchical start point (replaces the CMA-ES / scipy fits of PyHillFit.py:243-257,310-336) ---------------------
+def _logistic_mle_batch(values, s_floor=1e-4, iterations=60):
+    """Maximum-likelihood (mu, s) of a logistic distribution for every row of a ragged list of small samples, all rows at
+    once: damped Newton on (mu, ln s) of  NLL = sum_i [ z_i + ln s + 2 ln(1 + exp(-z_i)) ],  z = (y - mu)/s.
+    A sample that does not identify a scale (identical values, one value) runs into s_floor."""
+    width = [max(8, 1 << (len(v) - 1).bit_length()) for v in values]
+    if len(set(width)) > 1:                                          # a row's result must not depend on its batch: group by own width
+        mu = np.empty(len(values)); sc = np.empty(len(values))
+        for wd in sorted(set(width)):
+            idx = [k for k in range(len(values)) if width[k] == wd]
+            mu[idx], sc[idx] = _logistic_mle_batch([values[k] for k in idx], s_floor, iterations)
+        return mu, sc
+    P, N = len(values), width[0]
+    y = np.zeros((P, N)); w = np.zeros((P, N))
+    for k, v in enumerate(values):
+        y[k, :len(v)] = v; w[k, :len(v)] = 1.0
+    n = w.sum(axis=1)
+    mu = (w * y).sum(axis=1) / n
+    sd = np.sqrt((w * (y - mu[:, None]) ** 2).sum(axis=1) / n)
+    ls = np.log(np.maximum(sd * np.sqrt(3.0) / np.pi, s_floor))
+
+    def nll(mu_, ls_):
+        s_ = np.exp(ls_)[:, None]
+        z = (y - mu_[:, None]) / s_
+        return (w * (z + 2.0 * np.logaddexp(0.0, -z))).sum(axis=1) + n * ls_
+
+    cur = nll(mu, ls)
+    for _ in range(iterations):
+        s_ = np.exp(ls)
+        z = (y - mu[:, None]) / s_[:, None]
+        t = np.tanh(0.5 * z)                                         # 1 - 2/(1+e^z)
+        q = 0.5 * (1.0 - t * t)                                      # 2 e^z/(1+e^z)^2
+        g_mu = -(w * t).sum(axis=1) / s_                             # d NLL / d mu
+        g_ls = n - (w * z * t).sum(axis=1)                           # d NLL / d ln s
+        h_mm = (w * q).sum(axis=1) / s_ ** 2
+        h_ml = ((w * (t + z * q)).sum(axis=1)) / s_
+        h_ll = (w * (z * t + z * z * q)).sum(axis=1)
+        lam = 1e-9 * (h_mm + h_ll) + 1e-300
+        det = (h_mm + lam) * (h_ll + lam) - h_ml ** 2
+        ok = det > 0
+        d_mu = np.where(ok, -((h_ll + lam) * g_mu - h_ml * g_ls) / np.where(ok, det, 1.0), -g_mu / (h_mm + lam))
+        d_ls = np.where(ok, -((h_mm + lam) * g_ls - h_ml * g_mu) / np.where(ok, det, 1.0), 0.0)
+        d_ls = np.clip(d_ls, -1.0, 1.0)
+        step = np.ones(P)
+        for _h in range(8):                                          # backtracking, row by row
+            mu_new = mu + step * d_mu
+            ls_new = np.maximum(ls + step * d_ls, np.log(s_floor))
+            trial = nll(mu_new, ls_new)
+            worse = ~(trial <= cur)
+            if not worse.any():
+                break
+            step = np.where(worse, 0.5 * step, step)
+        better = trial <= cur
+        mu, ls, cur = np.where(better, mu_new, mu), np.where(better, ls_new, ls), np.where(better, trial, cur)
+    return mu, np.exp(ls)
+
+
+def _hyper_start_batch(tables, locs):
+    """(alpha, beta, mu, s, sigma) for every pair from its per-experiment fits (PyHillFit.py:303-334): the log-logistic fit of
+    the Hill coefficients (:310-324) is the logistic fit of their logarithms — alpha = exp(location), beta = 1/scale, capped at
+    20 like the scalar search it replaces — and the pIC50s get a logistic fit (:330); both for all pairs at once."""
+    P = len(tables)
+    sigma = np.array([np.mean(t[:, -1]) for t in tables])                                # :303-305
+    sigma = np.where(sigma <= locs[3], locs[3] + 0.1, sigma)
+    loc_h, scale_h = _logistic_mle_batch([np.log(np.maximum(t[:, 1], 1e-3)) for t in tables], s_floor=1.0 / 20.0)
+    alpha, beta = np.exp(loc_h), np.minimum(1.0 / scale_h, 20.0)
+    alpha = np.where(alpha <= locs[0], locs[0] + 0.1, alpha)
+    beta = np.where(beta <= locs[1], locs[1] + 0.1, beta)
+    mu, s_ = _logistic_mle_batch([t[:, 0] for t in tables])
+    mu = np.where(mu <= locs[2], locs[2] + 0.1, mu)
+    s_ = np.where(s_ <= locs[3], locs[3] + 0.1, s_)
+    return np.column_stack([alpha, beta, mu, s_, sigma])
+
+
 def _fisk_logpdf(x, c, scale):
-    """log-logistic (scipy.stats.fisk) log-density, written out: the generic scipy.stats machinery costs ~100 us per call"""
+    """log-logistic (scipy.stats.fisk) log-density, written out (the scalar cross-check of _hyper_start_batch)"""
     z = x / scale
     return np.log(c) - np.log(scale) + (c - 1.0) * np.log(z) - 2.0 * np.log1p(z ** c)
 
 
 def _hyper_start(best_fits, locs):
-    """(alpha, beta, mu, s, sigma) from a pair's per-experiment fits (PyHillFit.py:303-334)"""
+    """one pair, with scipy's scalar optimisers: what _hyper_start_batch replaces (kept as its cross-check in the tests)"""
     sigma_cur = np.mean(best_fits[:, -1])                            # :303-305
     if sigma_cur <= locs[3]:
         sigma_cur = locs[3] + 0.1
@@ -208,8 +281,7 @@ def hierarchical_first_iteration_batch(experiments_per_pair, locs, pool_map=None
         m = len(exs)
         tables.append(np.column_stack([p[k:k + m], hill[k:k + m], np.sqrt(ss[k:k + m] / n[k:k + m])]))   # initial_sigma, :101-102,255
         k += m
-    locs = np.asarray(locs, float)
-    hypers = pool_map(_hyper_start, [(t, locs) for t in tables]) if pool_map is not None else [_hyper_start(t, locs) for t in tables]
+    hypers = _hyper_start_batch(tables, np.asarray(locs, float))
     return [np.concatenate((hy[:4], t[:, :-1].flatten(), [hy[4]])) for t, hy in zip(tables, hypers)]
 
 

@@ -208,6 +208,12 @@ def test_hierarchical_start_points_batched(dr):
     for e, th in zip(exs, out):
         assert len(th) == 5 + 2 * len(e) and np.all(th[:4] > locs[:4]) and th[-1] > locs[4]
         assert np.array_equal(th, bestfit.hierarchical_first_iteration(e, locs))
+        # the two distribution fits (PyHillFit.py:310-334) against scipy's scalar optimisers
+        m = len(e)
+        table = np.column_stack([th[4:-1:2], th[5:-1:2], np.full(m, th[-1])])
+        a_nm, b_nm, mu_nm, s_nm, _ = bestfit._hyper_start(table, np.asarray(locs))
+        assert th[2] == pytest.approx(mu_nm, rel=1e-6) and th[3] == pytest.approx(s_nm, rel=1e-5)
+        assert th[1] == pytest.approx(b_nm, rel=1e-5) and th[0] == pytest.approx(a_nm, rel=(1e-5 if b_nm < 19.99 else 0.02))
         for i, ex in enumerate(e):
             th_nm, ss_nm = bestfit._fit_pic50_hill(ex[:, 0], ex[:, 1])
             assert bestfit.sum_of_square_diffs([th[4 + 2 * i], th[5 + 2 * i]], ex[:, 0], ex[:, 1]) <= ss_nm + 1e-7 * (1 + ss_nm)
