@@ -322,9 +322,11 @@ PHF_HD void phf_box_muller_k(uint32_t w1, uint32_t w2, double* z0, double* z1, p
   *z1 = rad * sn;
 }
 
-PHF_HD double phf_hier_draws(int dim, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
-                             uint32_t seed_hi, phf_ktab k_log, double* z, int zs) {
-  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
+/* k_sc_resident: the 12 sin/cos coefficients already in registers, or NULL (a literal at the call site): fetched through the
+ * scalar cache here (builds that have no VGPRs to spare for them).                                                */
+PHF_HD double phf_hier_draws_k(int dim, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
+                               uint32_t seed_hi, phf_ktab k_log, phf_ktab k_sc_resident, int sc_resident, double* z, int zs) {
+  PHF_KFETCH_UNLESS(k_sc, sc_resident, k_sc_resident, phf_k_sincos, 12);
   const int nb = (dim + 3) / 4;
   PHF_UNROLL
   for (int b = 0; b < nb; ++b) {
@@ -342,6 +344,12 @@ PHF_HD double phf_hier_draws(int dim, uint32_t chain_id, uint32_t problem_id, ui
   const double u = phf_uniform53(wu.w[0], wu.w[1]);
   const phf_logred lu = phf_log_reduce(u);
   return phf_log_from_recip(u, lu, phf_rcp(2.0 + lu.f), k_log);
+}
+
+PHF_HD double phf_hier_draws(int dim, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
+                             uint32_t seed_hi, phf_ktab k_log, double* z, int zs) {
+  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
+  return phf_hier_draws_k(dim, chain_id, problem_id, t, seed_lo, seed_hi, k_log, k_sc, 1, z, zs);
 }
 
 #endif /* PHF_HIER_MODEL_H */

@@ -40,21 +40,29 @@ struct HierArgs {
   double* row0;
 };
 
-// LDS layout: [tri - NREG][64] factor elements, then ln_conc[stride], response[stride], expt_start[NE+1].
-// WPS = wavefronts per SIMD the kernel is built for.  1: the whole factor in LDS (34..78 KB per wavefront: at most 4 wavefronts
-// per CU) and all 512 registers for the iteration.  2: eight wavefronts must share a CU's 160 KB, so only kLdsElems2 = 39
-// elements of the factor (19.5 KB) stay in LDS and the first NREG = tri - 39 live in registers, inside a 256-register budget:
-// two wavefronts per SIMD hide each other's fp64 latency (measured on a lone wavefront: one instruction per ~3.8 ns against
-// 2.1-2.25 ns when the SIMD is shared).  Same arithmetic, same order: both builds are bit-identical to each other and the twin.
+// Where a chain's factor lives.  WPS = wavefronts per SIMD the kernel is built for.
+//   WPS 1: the whole factor in LDS ([tri][64] doubles, 34..78 KB per wavefront: at most 4 wavefronts per CU) and all 512
+//          registers for the iteration.
+//   WPS 2: eight wavefronts share a CU's 160 KB, so kLdsElems2 = 39 elements (19.5 KB) stay in LDS.  During the target —
+//          two thirds of an iteration, and the phase that wants the registers — theta, mean and the factor are all idle, so
+//          the rest is split: kRegElems2 elements in registers and the remainder, with the running mean, IN PLACE IN THE STATE
+//          BUFFER in HBM (struct-of-arrays: one coalesced 512-B access per element and wavefront), read before the proposal
+//          and read/written in the adaptation step.  The parked set is sized to stay in the XCD's L2 (24 doubles per lane x
+//          256 wavefronts = 3 MB of 4): left to itself hipcc parks ~38 doubles per lane in scratch instead, which thrashes L2
+//          (profiles/r02/c4_wps_ab.txt: 38.3 ms against 27.9 for the one-wavefront build).
+// Same arithmetic, same order: the builds are bit-identical to each other and to the twin.
 constexpr int kLdsElems2 = 39;
+constexpr int kRegElems2 = 14;
 constexpr int kLdsPointBytes2 = 160 * 1024 / 8 - kLdsElems2 * kBlock * 8;        // 512 B left for the pair's points
 template <int NE, int WPS>
 struct Lds {
   static constexpr int dim = 5 + 2 * NE;
   static constexpr int tri = dim * (dim + 1) / 2;
-  static constexpr int nreg = (WPS == 2) ? (tri > kLdsElems2 ? tri - kLdsElems2 : 0) : 0;
+  static constexpr int nlds = (WPS == 2 && tri > kLdsElems2) ? kLdsElems2 : tri;              // elements [0, nlds) ... see PHF_LGET
+  static constexpr int nreg = (WPS == 2) ? ((tri - nlds) < kRegElems2 ? (tri - nlds) : kRegElems2) : 0;
+  static constexpr int nglob = tri - nlds - nreg;
   static size_t point_bytes(int stride) { return (size_t)stride * 16 + (NE + 1) * 4 + 8; }
-  static size_t bytes(int stride) { return (size_t)(tri - nreg) * kBlock * 8 + point_bytes(stride); }
+  static size_t bytes(int stride) { return (size_t)nlds * kBlock * 8 + point_bytes(stride); }
 };
 
 template <int NE>
@@ -70,15 +78,20 @@ __device__ __forceinline__ void stage(const phf_hier_points& pts, int pair, doub
 
 // The whole launch of one wavefront.  FIXED_N > 0: every experiment of the pair has exactly FIXED_N points, known at compile
 // time (the point loops unroll: straight-line iteration); 0: run-time experiment boundaries.
-template <int NE, int FIXED_N, int NREG>
+template <int NE, int FIXED_N, int NREG, int NGLOB>
 __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_mem, const double* s_lc, const double* s_y,
                                                   const int* s_es, int q, int c) {
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
-  double* sL = s_mem + threadIdx.x;                       // element e >= NREG of this lane's factor: sL[(e - NREG) * 64]
-  double Lr[NREG > 0 ? NREG : 1];                         // elements e < NREG: registers (every index below is a constant)
-#define PHF_LGET(e) (((e) < NREG) ? Lr[((e) < NREG) ? (e) : 0] : sL[(((e) < NREG) ? 0 : (e) - NREG) * kBlock])
-#define PHF_LSET(e, v) do { if ((e) < NREG) Lr[((e) < NREG) ? (e) : 0] = (v); else sL[(((e) < NREG) ? 0 : (e) - NREG) * kBlock] = (v); } while (0)
+  constexpr bool LEAN = NGLOB > 0;                        // the two-wavefronts-per-SIMD build
+  // factor element e: registers for e < NREG, the state buffer in HBM for NREG <= e < NREG + NGLOB, LDS (sL[.. * 64]) above
+  double* sL = s_mem + threadIdx.x;
+  double Lr[NREG > 0 ? NREG : 1];
+#define PHF_LIDX_R(e) (((e) < NREG) ? (e) : 0)
+#define PHF_LIDX_S(e) (((e) < NREG + NGLOB) ? 0 : (e) - NREG - NGLOB)
+#define PHF_LGET(e) (((e) < NREG) ? Lr[PHF_LIDX_R(e)] : ((e) < NREG + NGLOB) ? PHF_SP(2 * D + 1 + (e)) : sL[PHF_LIDX_S(e) * kBlock])
+#define PHF_LSET(e, v) do { if ((e) < NREG) Lr[PHF_LIDX_R(e)] = (v); else if ((e) < NREG + NGLOB) PHF_SP(2 * D + 1 + (e)) = (v); \
+                            else sL[PHF_LIDX_S(e) * kBlock] = (v); } while (0)
   const int C = a.prob.chains_per_problem;
   const uint32_t pid = a.prob.problem_id[q];
   const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
@@ -86,20 +99,40 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   const size_t nchains = (size_t)a.prob.num_problems * C;
   const size_t g = (size_t)q * C + c;
 
-  double th[D], mean[D];
-  double* sp = a.state + g;
+  double th[D], mean[LEAN ? 1 : D];
+  // element k of this lane's state: a wave-uniform base (scalar registers, recomputed by the scalar unit) + the lane number, so that
+  // the ~60 distinct addresses of an iteration cost no vector registers (as per-lane 64-bit pointers they were hipcc's first spill victims)
+  double* const sbase = a.state + ((size_t)q * C + (size_t)(c - (int)threadIdx.x));
+  const uint32_t lane = threadIdx.x;
+#define PHF_SP(k) (sbase + (size_t)(k) * nchains)[lane]
 #pragma unroll
-  for (int i = 0; i < D; ++i) th[i] = sp[(size_t)i * nchains];
-  double lt = sp[(size_t)D * nchains];
+  for (int i = 0; i < D; ++i) th[i] = PHF_SP(i);
+  double lt = PHF_SP(D);
+  if (!LEAN) {
 #pragma unroll
-  for (int i = 0; i < D; ++i) mean[i] = sp[(size_t)(D + 1 + i) * nchains];
+    for (int i = 0; i < D; ++i) mean[i] = PHF_SP(D + 1 + i);
+  }
 #pragma unroll
-  for (int e = 0; e < TRI; ++e) PHF_LSET(e, sp[(size_t)(2 * D + 1 + e) * nchains]);
-  double loga = sp[(size_t)(2 * D + 1 + TRI) * nchains];
-  double nacc = sp[(size_t)(2 * D + 2 + TRI) * nchains];
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
-  double sc = phf_exp_fast_k(0.5 * loga, k_exp);
+  for (int e = 0; e < TRI; ++e)
+    if (e < NREG || e >= NREG + NGLOB) PHF_LSET(e, PHF_SP(2 * D + 1 + e));
+  double loga = PHF_SP(2 * D + 1 + TRI);
+  double nacc = PHF_SP(2 * D + 2 + TRI);
+  // coefficient tables: VGPRs for the launch (one wavefront per SIMD: a lone wavefront cannot hide the scalar-load latency),
+  // or — LEAN — fetched through the scalar cache where a phase needs them (no VGPRs to spare; a second wavefront hides the loads)
+  double kv_exp[LEAN ? 1 : 10], kv_log[LEAN ? 1 : 7], kv_sc[LEAN ? 1 : 12];
+  if (!LEAN) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { kv_exp[i] = phf_k_exp[i]; asm volatile("" : "+v"(kv_exp[i])); }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { kv_log[i] = phf_k_log[i]; asm volatile("" : "+v"(kv_log[i])); }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { kv_sc[i] = phf_k_sincos[i]; asm volatile("" : "+v"(kv_sc[i])); }
+  }
+  double sc;
+  {
+    PHF_KFETCH_UNLESS(k_exp0, !LEAN, kv_exp, phf_k_exp, 10);
+    sc = phf_exp_fast_k(0.5 * loga, k_exp0);
+  }
 
   const bool want_moments = a.moments != nullptr;
   const int thin = a.cfg.thinning;
@@ -110,7 +143,9 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
     // ---- proposal theta* = theta + e^(loga/2) L z   (PyHillFit.py:485) ----
     double z[D], star[D];
-    const double log_u = phf_hier_draws(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, z, 1);
+    PHF_KFETCH_UNLESS(k_exp, !LEAN, kv_exp, phf_k_exp, 10);
+    PHF_KFETCH_UNLESS(k_log, !LEAN, kv_log, phf_k_log, 7);
+    const double log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, kv_sc, LEAN ? 0 : 1, z, 1);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       double v = PHF_LGET(i * (i + 1) / 2 + i) * z[i];
@@ -118,6 +153,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
       for (int k = i - 1; k >= 0; --k) v = phf_fma(PHF_LGET(i * (i + 1) / 2 + k), z[k], v);
       star[i] = phf_fma(sc, v, th[i]);
     }
+    if (LEAN) asm volatile("" ::: "memory");               // the HBM-resident part of the state is re-read after the target, not kept live across it
     // ---- target, accept (:486-492) ----
     const double lt_star = phf_hier_log_target_n(NE, FIXED_N, s_es, s_lc, s_y, star, 1, &a.prior, k_exp, k_log);
     const bool acc = log_u < lt_star - lt;
@@ -134,9 +170,12 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
       const double sqa = phf_sqrt_pos(omg), sqg = phf_sqrt_pos(gs);
       double w[D];
 #pragma unroll
-      for (int i = 0; i < D; ++i) w[i] = sqg * (th[i] - mean[i]);
-#pragma unroll
-      for (int i = 0; i < D; ++i) mean[i] = phf_fma(gs, th[i], omg * mean[i]);
+      for (int i = 0; i < D; ++i) {
+        const double mi = LEAN ? PHF_SP(D + 1 + i) : mean[LEAN ? 0 : i];
+        w[i] = sqg * (th[i] - mi);
+        const double mn = phf_fma(gs, th[i], omg * mi);
+        if (LEAN) PHF_SP(D + 1 + i) = mn; else mean[LEAN ? 0 : i] = mn;
+      }
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
 #pragma unroll
       for (int k = 0; k < D; ++k) {                        // Givens sweep down column k
@@ -180,25 +219,31 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   }
 
 #pragma unroll
-  for (int i = 0; i < D; ++i) sp[(size_t)i * nchains] = th[i];
-  sp[(size_t)D * nchains] = lt;
+  for (int i = 0; i < D; ++i) PHF_SP(i) = th[i];
+  PHF_SP(D) = lt;
+  if (!LEAN) {
 #pragma unroll
-  for (int i = 0; i < D; ++i) sp[(size_t)(D + 1 + i) * nchains] = mean[i];
+    for (int i = 0; i < D; ++i) PHF_SP(D + 1 + i) = mean[i];
+  }
 #pragma unroll
-  for (int e = 0; e < TRI; ++e) sp[(size_t)(2 * D + 1 + e) * nchains] = PHF_LGET(e);
-  sp[(size_t)(2 * D + 1 + TRI) * nchains] = loga;
-  sp[(size_t)(2 * D + 2 + TRI) * nchains] = nacc;
+  for (int e = 0; e < TRI; ++e)
+    if (e < NREG || e >= NREG + NGLOB) PHF_SP(2 * D + 1 + e) = PHF_LGET(e);
+  PHF_SP(2 * D + 1 + TRI) = loga;
+  PHF_SP(2 * D + 2 + TRI) = nacc;
 #undef PHF_LGET
 #undef PHF_LSET
+#undef PHF_LIDX_R
+#undef PHF_LIDX_S
+#undef PHF_SP
 }
 
 template <int NE, int WPS>
 __global__ __launch_bounds__(kBlock, WPS) void hier_advance_kernel(const HierArgs a) {
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
-  constexpr int NREG = Lds<NE, WPS>::nreg;
+  constexpr int NREG = Lds<NE, WPS>::nreg, NGLOB = Lds<NE, WPS>::nglob;
   extern __shared__ double s_mem[];
-  double* s_lc = s_mem + (size_t)(TRI - NREG) * kBlock;
+  double* s_lc = s_mem + (size_t)Lds<NE, WPS>::nlds * kBlock;
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
   const int q = blockIdx.x / a.blocks_per_problem;
@@ -211,8 +256,8 @@ __global__ __launch_bounds__(kBlock, WPS) void hier_advance_kernel(const HierArg
   bool four_each = true;
 #pragma unroll
   for (int i = 1; i <= NE; ++i) four_each = four_each && (a.pts.expt_start[(size_t)pair * (NE + 1) + i] == 4 * i);
-  if (four_each) hier_advance_body<NE, 4, NREG>(a, s_mem, s_lc, s_y, s_es, q, c);
-  else hier_advance_body<NE, 0, NREG>(a, s_mem, s_lc, s_y, s_es, q, c);
+  if (four_each) hier_advance_body<NE, 4, NREG, NGLOB>(a, s_mem, s_lc, s_y, s_es, q, c);
+  else hier_advance_body<NE, 0, NREG, NGLOB>(a, s_mem, s_lc, s_y, s_es, q, c);
 }
 
 template <int NE>
