@@ -12,6 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpyhillfit_amd.so")
+TEXTIO_SRC = os.path.join(CSRC, "phf_textio.cpp")                 # host-only C++ (chain-file text), built with g++
+TEXTIO_LIB = os.path.join(LIB_DIR, "libphf_textio.so")
 SOURCES = ["phf_capi.hip", "phf_single_level.hip", "phf_hierarchical.hip", "phf_predictive.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
@@ -19,6 +21,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 
 def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_textio(force=False, verbose=False):
+    """the chain-file text formatter: no GPU code, g++ alone"""
+    if not force and os.path.exists(TEXTIO_LIB) and os.path.getmtime(TEXTIO_LIB) >= os.path.getmtime(TEXTIO_SRC):
+        return TEXTIO_LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", TEXTIO_LIB, TEXTIO_SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TEXTIO_LIB
 
 
 def needs_build():
@@ -41,6 +55,7 @@ def _compile_one(src, obj, extra_flags, verbose):
 
 def build(force=False, verbose=False, extra_flags=()):
     """one object per source (compiled side by side: the sampler kernels take a minute each), then one link"""
+    build_textio(force, verbose)
     if not force and not needs_build():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor

@@ -80,3 +80,24 @@ def test_sampler_refuses_cpu_device(lib):
     packed = PackedPoints([(np.array([0.1, 1.0]), np.array([10.0, 60.0]))])
     with pytest.raises(PhfError, match="HIP device only"):
         SingleLevelSampler(packed, 2, [0], [1.0], 64, device="cpu")
+
+
+def test_textio_library_exports_its_header():
+    """include/pyhillfit_textio.h <-> pyhillfit_amd/lib/libphf_textio.so (host-only chain-file text formatter)"""
+    import __graft_entry__ as g
+    g.build()
+    with open(os.path.join(REPO, "include", "pyhillfit_textio.h")) as f:
+        src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(phf_[a-z0-9_]+)\s*\(", src)))
+    assert names == ["phf_format_rows", "phf_savetxt"]
+    lib = C.CDLL(os.path.join(REPO, "pyhillfit_amd", "lib", "libphf_textio.so"))
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.phf_format_rows.restype = C.c_int64
+    lib.phf_format_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64]
+    import numpy as np
+    a = np.array([[1.0, -2.5], [np.inf, np.nan]])
+    buf = C.create_string_buffer(4 * 28)
+    n = lib.phf_format_rows(a.ctypes.data, 2, 2, 2, buf, len(buf))
+    assert buf.raw[:n] == b"1.000000000000000000e+00 -2.500000000000000000e+00\ninf nan\n"
+    assert lib.phf_format_rows(a.ctypes.data, 2, 2, 2, buf, 10) == -4 * 28

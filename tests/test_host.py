@@ -356,3 +356,35 @@ def test_product_code_never_imports_the_oracle():
     for fn in [n for n in bench.body if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
         assert uses == (fn.name == "cpu_baseline"), fn.name
+
+
+def test_native_text_formatter_is_numpy_savetxt_byte_for_byte(tmp_path):
+    """csrc/phf_textio.cpp (std::to_chars, scientific, 18 digits) against np.savetxt's default '%.18e': random bit patterns over
+    the whole exponent range, subnormals, exact decimal ties (2^-28 has 20 significant digits ending in 5), signed zeros,
+    infinities and NaN, headers, appending, one column, no rows"""
+    import io
+    from pyhillfit_amd import chainio
+    assert chainio._textio(), "libphf_textio.so not built (python -c 'import __graft_entry__ as g; g.build()')"
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2 ** 64, 200000, dtype=np.uint64).view(np.float64)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, -np.nan, 5e-324, -5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+                        2.0 ** -28, 2.0 ** -29, 3 * 2.0 ** -30, 9.999999999999999e22, 1e23, 0.1, 1 / 3., 123456789.123456789, 2.5e-9, 1e100])
+    vals = np.concatenate([bits, special, rng.standard_normal(20000) * 10.0 ** rng.integers(-30, 30, 20000)])
+    vals = vals[:len(vals) // 4 * 4]
+    for cols in (4, 1, 12):
+        table = vals[:len(vals) // cols * cols].reshape(-1, cols)
+        want = io.BytesIO()
+        with np.errstate(all="ignore"):
+            np.savetxt(want, table)
+        path = str(tmp_path / ("t%d.txt" % cols))
+        chainio.write_text(path, False, ("# header one\n", "# two\n"), table[:1000])
+        chainio.write_text(path, True, (), table[1000:])
+        chainio.write_text(path, True, (), table[:0])
+        got = open(path, "rb").read()
+        assert got == b"# header one\n# two\n" + want.getvalue(), cols
+    view = vals[:4000].reshape(1000, 4)[:, ::2]                      # a non-contiguous view is copied, not misread
+    chainio.write_text(str(tmp_path / "v.txt"), False, (), view)
+    want = io.BytesIO(); np.savetxt(want, view)
+    assert open(str(tmp_path / "v.txt"), "rb").read() == want.getvalue()
+    with pytest.raises(OSError):
+        chainio.write_text(str(tmp_path / "no_such_dir" / "x.txt"), False, (), table[:2])
