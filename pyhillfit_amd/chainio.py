@@ -4,7 +4,7 @@ downstream readers (np.loadtxt with usecols, last column = log-target) work unch
 import ctypes
 import multiprocessing as mp
 import os
-from concurrent.futures import ProcessPoolExecutor
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
 from concurrent.futures.process import BrokenProcessPool
 
 import numpy as np
@@ -19,8 +19,13 @@ class WriterPool(object):
     cannot start (spawn re-imports the main script, which an interactive session does not have): every job is a pure
     function of its arguments, so it is simply redone here.  close() waits and re-raises the first failure."""
 
-    def __init__(self, workers):
-        self.pool = ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) if workers > 0 else None
+    def __init__(self, workers, processes=None):
+        # with the native formatter (libphf_textio.so) a job spends its time inside one C call that has released the GIL:
+        # threads of THIS process do it — no interpreter start-up, no pickling of the rows (0.5 GB per `-a` run) to a worker
+        if workers > 0 and _textio() and not processes:
+            self.pool = ThreadPoolExecutor(workers)
+        else:
+            self.pool = ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) if workers > 0 else None
         self.pending = []
 
     def _broken(self):
@@ -80,9 +85,12 @@ class StreamWriters(object):
     caller from the job history (create truncates the file, then every segment delivered so far, in order); the healthy
     lanes keep their own files and go on.  The history holds references to the caller's row arrays, not copies."""
 
-    def __init__(self, workers):
+    def __init__(self, workers, processes=None):
         ctx = mp.get_context("spawn")
-        self.lanes = [ProcessPoolExecutor(1, mp_context=ctx) for _ in range(max(workers, 0))]
+        if _textio() and not processes:                         # native formatter: one thread per lane (see WriterPool)
+            self.lanes = [ThreadPoolExecutor(1) for _ in range(max(workers, 0))]
+        else:
+            self.lanes = [ProcessPoolExecutor(1, mp_context=ctx) for _ in range(max(workers, 0))]
         self.dead = set()
         self.pending = []                                       # (future, lane)
         self.history = {}                                       # path -> [(fn, args), ...] in submission order

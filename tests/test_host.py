@@ -262,9 +262,9 @@ def test_writer_pool_files_equal_the_synchronous_ones(tmp_path):
     rng = np.random.RandomState(3)
     chains = [rng.standard_normal((200 + 10 * i, 4)) for i in range(5)]
     hier = rng.standard_normal((300, 12))
-    for workers, sub in ((0, "sync"), (2, "pool")):
+    for workers, processes, sub in ((0, None, "sync"), (2, None, "pool"), (2, True, "procs")):   # caller / threads (native formatter) / processes
         os.makedirs(str(tmp_path / sub))
-        with chainio.WriterPool(workers) as w:
+        with chainio.WriterPool(workers, processes=processes) as w:
             for i, c in enumerate(chains):
                 w.submit(chainio.save_single_level_chain, str(tmp_path / sub / ("c%d.txt" % i)), c, "Drug", "hERG", 2)
             w.submit(chainio.save_hierarchical_chain, str(tmp_path / sub / "h.txt"), hier)
@@ -273,6 +273,7 @@ def test_writer_pool_files_equal_the_synchronous_ones(tmp_path):
     for name in ["c%d.txt" % i for i in range(5)] + ["h.txt", "am.txt"]:
         a = open(str(tmp_path / "sync" / name), "rb").read()
         assert a == open(str(tmp_path / "pool" / name), "rb").read(), name
+        assert a == open(str(tmp_path / "procs" / name), "rb").read(), name
     assert np.array_equal(chainio.load_chain(str(tmp_path / "pool" / "c2.txt")), chains[2])
     assert np.array_equal(chainio.load_chain(str(tmp_path / "pool" / "h.txt"), usecols=range(4)), hier[:, :4])
     assert chainio.load_chain(str(tmp_path / "pool" / "am.txt")).shape == (50, 2)
@@ -296,8 +297,8 @@ def test_stream_writers_produce_the_file_of_one_savetxt(tmp_path):
     chains = {str(tmp_path / ("h%d.txt" % i)): rng.standard_normal((130 + i, 9)) for i in range(7)}
     for path, chain in chains.items():
         chainio.save_hierarchical_chain(path + ".whole", chain)
-    for workers in (0, 3):
-        sw = chainio.StreamWriters(workers)
+    for workers, processes in ((0, None), (3, None), (2, True)):      # caller / threads around the native formatter / spawned processes
+        sw = chainio.StreamWriters(workers, processes=processes)
         for path, chain in chains.items():
             sw.create(path, chainio.HIERARCHICAL_HEADER, chain[0:1])
         for lo in range(1, 140, 17):
@@ -320,7 +321,7 @@ def test_stream_writer_survives_a_dead_worker(tmp_path):
     chains = {str(tmp_path / ("chain_%d.txt" % k)): rng.standard_normal((90 + k, 5)) for k in range(6)}
     for path, chain in chains.items():
         chainio.save_hierarchical_chain(path + ".whole", chain)
-    sw = chainio.StreamWriters(2)
+    sw = chainio.StreamWriters(2, processes=True)
     for path, chain in chains.items():
         sw.create(path, chainio.HIERARCHICAL_HEADER, chain[0:1])
     for path, chain in chains.items():
