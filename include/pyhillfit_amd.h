@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PHF_ABI_VERSION 2
+#define PHF_ABI_VERSION 3
 
 enum {
   PHF_OK = 0,
@@ -69,6 +69,11 @@ typedef struct phf_problems {
   const uint32_t* problem_id;    /* device [Q]  global problem number (Philox counter word 1) */
   uint32_t chain_id_base;        /* global number of local chain 0 (Philox counter word 0) */
   uint32_t reserved;
+  const int32_t* launch_order;   /* device [Q] or NULL: a permutation of 0..Q-1 — the order in which the problems' wavefronts are
+                                    handed to the GPU (ABI 3).  Results do not depend on it (every problem writes its own rows and
+                                    state); what does is the tail of a launch whose problems differ in cost: pairs have 2..8 entries,
+                                    an iteration 550..1 500 instructions, and most expensive first (what the reference's pool gets by
+                                    luck or not) took 6.5 % off the full-Crumb-set launch.  NULL = 0, 1, 2, ... */
 } phf_problems;
 
 /* Adaptive-Metropolis schedule: python/PyHillFit.py:787-848 / python/PyHillTemp.py:76-123. */

@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpyhillfit_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/pyhillfit_amd.h declares
 EXPORTS = ["phf_version", "phf_last_error", "phf_single_level_state_size", "phf_single_level_init",
@@ -27,7 +27,7 @@ class Points(C.Structure):
 class Problems(C.Structure):
     _fields_ = [("num_problems", C.c_int32), ("chains_per_problem", C.c_int32), ("pair_index", C.c_void_p),
                 ("temperature", C.c_void_p), ("problem_id", C.c_void_p), ("chain_id_base", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("launch_order", C.c_void_p)]
 
 
 class MhConfig(C.Structure):

@@ -246,8 +246,9 @@ __global__ __launch_bounds__(kBlock, WPS) void hier_advance_kernel(const HierArg
   double* s_lc = s_mem + (size_t)Lds<NE, WPS>::nlds * kBlock;
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
-  const int q = blockIdx.x / a.blocks_per_problem;
-  const int chunk = blockIdx.x - q * a.blocks_per_problem;
+  const int slot = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - slot * a.blocks_per_problem;
+  const int q = a.prob.launch_order ? a.prob.launch_order[slot] : slot;     // include/pyhillfit_amd.h: phf_problems.launch_order
   const int c = chunk * kBlock + threadIdx.x;
   const int pair = a.prob.pair_index[q];
   stage<NE>(a.pts, pair, s_lc, s_y, s_es);
@@ -358,8 +359,9 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
   const int C = a.prob.chains_per_problem;
-  const int q = blockIdx.x / C;
-  const int c = blockIdx.x - q * C;
+  const int slot = blockIdx.x / C;
+  const int c = blockIdx.x - slot * C;
+  const int q = a.prob.launch_order ? a.prob.launch_order[slot] : slot;
   const int pair = a.prob.pair_index[q];
   const uint32_t pid = a.prob.problem_id[q];
   const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;

@@ -250,8 +250,9 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
 template <int MODEL, bool MOMENTS, int WPS>
 __global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceArgs a) {
   extern __shared__ double s_pts[];
-  const int q = blockIdx.x / a.blocks_per_problem;
-  const int chunk = blockIdx.x - q * a.blocks_per_problem;
+  const int slot = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - slot * a.blocks_per_problem;
+  const int q = a.prob.launch_order ? a.prob.launch_order[slot] : slot;     // which problem this wavefront works on (wave-uniform)
   const int c = chunk * kBlock + threadIdx.x;
   int n_other, n_zero, n_hundred;
   const int pair = a.prob.pair_index[q];

@@ -139,8 +139,11 @@ class HierarchicalSampler(object):
         self.temperature = torch.ones(self.Q, dtype=torch.float64, device=dev)
         ids = np.arange(self.Q) if problem_ids is None else np.asarray(problem_ids)
         self.problem_ids = torch.tensor(ids.astype(np.int64), device=dev).to(torch.int32)
+        # pairs with more points first (the cost of an iteration grows with the points; include/pyhillfit_amd.h: launch_order)
+        npts = self.points.packed.expt_start[np.asarray(pair_index, dtype=np.int64), -1]
+        self.launch_order = torch.tensor(np.argsort(-npts, kind="stable").astype(np.int32), device=dev)
         self.prob = _lib.Problems(self.Q, self.C, self.pair_index.data_ptr(), self.temperature.data_ptr(),
-                                  self.problem_ids.data_ptr(), int(chain_id_base) & 0xFFFFFFFF, 0)
+                                  self.problem_ids.data_ptr(), int(chain_id_base) & 0xFFFFFFFF, 0, self.launch_order.data_ptr())
         self.S = self.lib.phf_hierarchical_state_size(self.n_expts)
         if self.S < 0:
             raise _lib.PhfError(self.lib.phf_last_error().decode())

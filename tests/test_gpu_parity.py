@@ -233,6 +233,30 @@ def test_every_entry_count_shape_bit_identical_to_cpu_twin(model, chains, gpu):
     np.testing.assert_allclose(var.cpu().numpy(), keep.var(axis=0, ddof=1).transpose(1, 0, 2), rtol=1e-7, atol=1e-10)
 
 
+def test_launch_order_does_not_change_results(gpu, dr):
+    """phf_problems.launch_order (ABI 3) only chooses which problem's wavefronts the GPU gets first (most expensive first by
+    default: a shorter tail); rows and state land at the problem's own place whatever the order"""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    names = [(d, c) for d in dr.drugs[:9] for c in dr.channels]
+    packed = dr.pack_single_level(names)
+    Q = len(names)
+    temps = [1.0 if q % 3 else 0.25 for q in range(Q)]
+    runs = []
+    for order in (None, "cost", np.random.default_rng(4).permutation(Q)):
+        s = SingleLevelSampler(packed, 2, list(range(Q)), temps, 192, thinning=5, seed=8, adapt_start=40, device=gpu, launch_order=order)
+        s.init([6.0, 0.8, 8.0])
+        runs.append((s.run(120), s.state.clone()))
+        if isinstance(order, str):
+            o = s.launch_order.cpu().numpy()
+            cnt = packed.counts
+            cost = 28.0 * cnt[o, 0] + 115.0 * (cnt[o, 1] + cnt[o, 2])
+            assert sorted(o.tolist()) == list(range(Q)) and np.all(np.diff(cost) <= 0)       # a permutation, most expensive first
+    for chain, state in runs[1:]:
+        assert torch.equal(chain, runs[0][0]) and torch.equal(state, runs[0][1])
+    with pytest.raises(ValueError):
+        SingleLevelSampler(packed, 2, list(range(Q)), temps, 64, device=gpu, launch_order=[0] * Q)
+
+
 def test_shard_invariance_and_resume_full_width(gpu, dr):
     """BASELINE config 2 width (65 536 chains of Amiodarone-hERG): the same chains computed (a) in one launch,
     (b) as two half-batches with chain_id_base — the multi-GPU partition — and (c) through a checkpoint/restore
