@@ -101,7 +101,7 @@ class SingleLevelSampler(object):
         # instructions (tools/isa_stats.py), 550..1 500 over the Crumb pairs; in file order the launch ends with a ragged
         # tail — 46.4 ms against 43.4 for the 210 pairs x 4 096 chains.  Results do not depend on it.  None = as given.
         self.launch_order = None
-        if launch_order == "cost":
+        if isinstance(launch_order, str) and launch_order == "cost":
             cnt = self.points.packed.counts[np.asarray(pair_index, dtype=np.int64)]
             cost = 525.0 + 28.0 * cnt[:, 0] + 115.0 * (cnt[:, 1] + cnt[:, 2])
             self.launch_order = torch.tensor(np.argsort(-cost, kind="stable").astype(np.int32), device=dev)
