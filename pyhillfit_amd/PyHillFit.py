@@ -183,6 +183,13 @@ def main(argv=None):
         sys.exit(1)
     args = parser.parse_args(argv)
     rank, local_rank, world = phfdist.init()
+    try:
+        return _run(args, rank, local_rank, world)
+    finally:
+        phfdist.finalize()       # also on an error or SystemExit of this rank: the others' next collective fails instead of hanging
+
+
+def _run(args, rank, local_rank, world):
     device = args.device or "cuda:%d" % local_rank
     if args.write_workers is None:
         args.write_workers = chainio.default_write_workers(world)
@@ -199,23 +206,20 @@ def main(argv=None):
                 costs.append(0)
         mine = phfdist.shard_problems(costs, world)[rank]
         pairs = [pairs[i] for i in mine]
-    try:
-        if args.hierarchical:
-            from .hierarchical import run_hierarchical
-            summaries = run_hierarchical(pairs, args, device, rank, world)
-        else:
-            summaries = run_single_level(pairs, args, device, rank, world)
-        if world > 1:
-            import torch
-            # gather a compact numeric summary on rank 0 (pooled means of the first 3 columns + acceptance)
-            rows = torch.tensor([[s_["pooled_mean"][0], s_["pooled_mean"][-1], s_["acceptance"]] for s_ in summaries] or
-                                np.zeros((0, 3)), dtype=torch.float64, device=device).reshape(-1, 3)
-            allrows = phfdist.gather_rows(rows, dst=0)
-            if rank == 0:
-                print("gathered summaries from %d ranks: %d pairs" % (world, sum(len(a) for a in allrows)))
-        return summaries
-    finally:
-        phfdist.finalize()       # also on an error or SystemExit of this rank: the others' next collective fails instead of hanging
+    if args.hierarchical:
+        from .hierarchical import run_hierarchical
+        summaries = run_hierarchical(pairs, args, device, rank, world)
+    else:
+        summaries = run_single_level(pairs, args, device, rank, world)
+    if world > 1:
+        import torch
+        # gather a compact numeric summary on rank 0 (pooled means of the first 3 columns + acceptance)
+        rows = torch.tensor([[s_["pooled_mean"][0], s_["pooled_mean"][-1], s_["acceptance"]] for s_ in summaries] or
+                            np.zeros((0, 3)), dtype=torch.float64, device=phfdist.collective_device(device)).reshape(-1, 3)
+        allrows = phfdist.gather_rows(rows, dst=0)
+        if rank == 0:
+            print("gathered summaries from %d ranks: %d pairs" % (world, sum(len(a) for a in allrows)))
+    return summaries
 
 
 if __name__ == "__main__":

@@ -183,20 +183,20 @@ def main(argv=None):
         sys.exit(1)
     args = parser.parse_args(argv)
     rank, local_rank, world = phfdist.init()
-    device = args.device or "cuda:%d" % local_rank
-    dr.define_model(args.model)                                          # PyHillTemp.py:45
-    phfdist.setup_data_file(args.data_file)                              # :48
-    dr.output_root = args.output_root
-    if args.all_pairs:
-        pairs = [(a, b) for a in dr.drugs for b in dr.channels]
-    else:
-        pairs = [(dr.drugs[args.drug], dr.channels[args.channel])]       # :52-53
-    temperatures = dr.temperature_ladder(args.rungs)                     # :151
-    print("\nDoing temperatures: {}\n".format(temperatures))
     try:
+        device = args.device or "cuda:%d" % local_rank
+        dr.define_model(args.model)                                      # PyHillTemp.py:45
+        phfdist.setup_data_file(args.data_file)                          # :48
+        dr.output_root = args.output_root
+        if args.all_pairs:
+            pairs = [(a, b) for a in dr.drugs for b in dr.channels]
+        else:
+            pairs = [(dr.drugs[args.drug], dr.channels[args.channel])]   # :52-53
+        temperatures = dr.temperature_ladder(args.rungs)                 # :151
+        print("\nDoing temperatures: {}\n".format(temperatures))
         return run_tempered(pairs, temperatures, args, device, rank, world)
     finally:
-        phfdist.finalize()
+        phfdist.finalize()       # also when this rank fails: the others' next collective raises instead of hanging
 
 
 if __name__ == "__main__":
