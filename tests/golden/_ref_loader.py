@@ -60,3 +60,26 @@ class Py2Int(int):
 
     def __rtruediv__(self, other):
         return Py2Int(int(other) // int(self))
+
+
+def lift_statements(filename, func_name, ranges, glb):
+    """exec consecutive top-level statements of the BODY of one reference function, unmodified, in `glb`.
+
+    ranges: list of (first, last) pairs; `first` / `last` are predicates on the Python-3 source text of a statement
+    (ast.unparse) choosing the first and last statement of a run.  Used for the Metropolis loops that the reference inlines
+    in run_single_level / run_hierarchical between its CMA-ES search and its plotting code (python/PyHillFit.py:748-751,
+    787-864 and :431-511): the functions cannot be called (cma absent, matplotlib API drift), their loop statements can."""
+    path = os.path.join(REF_PY, filename)
+    with open(path) as f:
+        src3 = _to_py3(f.read(), filename)
+    tree = ast.parse(src3)
+    func = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == func_name)
+    texts = [ast.unparse(s) for s in func.body]
+    picked = []
+    for first, last in ranges:
+        i0 = next(i for i, t in enumerate(texts) if first(t))
+        i1 = next(i for i in range(i0, len(texts)) if last(texts[i]))
+        picked.append((func.body[i0].lineno, func.body[i1].end_lineno))
+        code = compile(ast.Module(body=func.body[i0:i1 + 1], type_ignores=[]), path, "exec")
+        exec(code, glb)
+    return picked

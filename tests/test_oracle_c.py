@@ -204,3 +204,65 @@ def test_predictive_twin_matches_reference_function(name):
             ref = g[name + "_" + k]
             assert np.all(np.abs(sums[f] - ref) <= 1e-70 + 1e-11 * np.abs(ref)), (name, k, chunk)
         assert sums[0][0] == 0.0 and sums[2][0] == 0.0
+
+
+# ---- G9: the reference's inlined single-level and hierarchical loops (tests/golden/make_golden_loops.py) through the C twin -----
+def _g9():
+    import json
+    with open(os.path.join(GOLDEN, "g9_loop_traces_meta.json")) as f:
+        return np.load(os.path.join(GOLDEN, "g9_loop_traces.npz")), json.load(f)
+
+
+@pytest.mark.parametrize("run", ["sl_amio_m2", "sl_amio_m1", "sl_moxi_m2"])
+def test_single_level_loop_replays_reference_statements(run, oracle_pair):
+    """python/PyHillFit.py:748-751,787-856 executed from the reference's own statements: its recorded proposals and uniforms
+    through the C loop (start = given point, covariance 0.05 diag|theta0|, no mean reset: the kernels' PyHillFit mode) give the
+    same accept/reject at every iteration, the same chain and the same adapted covariance"""
+    g, meta = _g9()
+    m = next(r for r in meta["single_level"] if r["name"] == run)
+    p = oracle_pair(m["drug"], m["channel"])
+    pk = co.PackedPair(p.concs, p.responses, m["model"], 1.0)
+    T, d = m["iterations"], pk.d
+    st = pk.init_state(np.array(m["theta0"]), False, 0.05)        # :748-751
+    want = g[run + "_chain"]
+    assert st[d] == pytest.approx(want[0, d], rel=1e-12)
+    rows, cov = pk.advance(st, 0, T, 1, 1000 * d, False, co.gamma_table(T), star_replay=g[run + "_star"], u_replay=g[run + "_u"], trace_cov=True)
+    chain = np.vstack([want[:1], rows])
+    assert np.array_equal(np.diff(chain[:, 0]) != 0, np.diff(want[:, 0]) != 0)
+    _close(chain[:, :d], want[:, :d], 0)
+    _close(chain[:, d], want[:, d], 1e-12)
+    np.testing.assert_allclose(cov[::20], g[run + "_cov_every20"], rtol=1e-10)
+    np.testing.assert_allclose(cov[-1], g[run + "_cov_last"], rtol=1e-10)
+    final = g[run + "_final"]                                     # cov_estimate, mean_estimate, loga, acceptance after the last iteration
+    tri = st[2 * d + 1:2 * d + 1 + d * (d + 1) // 2]
+    full = np.zeros((d, d)); full[np.tril_indices(d)] = tri; full = full + np.tril(full, -1).T
+    np.testing.assert_allclose(full.ravel(), final[:d * d], rtol=1e-10)
+    np.testing.assert_allclose(st[d + 1:2 * d + 1], final[d * d:d * d + d], rtol=1e-12)
+    assert st[2 * d + 1 + d * (d + 1) // 2] == pytest.approx(final[-2], rel=1e-11)            # loga
+    assert st[2 * d + 2 + d * (d + 1) // 2] / T == pytest.approx(final[-1], rel=1e-12)        # accepted count / T = running acceptance
+
+
+@pytest.mark.parametrize("run", ["hier_amio", "hier_amit"])
+def test_hierarchical_loop_replays_reference_statements(run, oracle_pair):
+    """python/PyHillFit.py:431-511 from the reference's own statements (Ne = 3 and 6): same accept sequence and chain; the factor the
+    twin carries squares to the reference's final covariance"""
+    g, meta = _g9()
+    m = next(r for r in meta["hierarchical"] if r["name"] == run)
+    p = oracle_pair(m["drug"], m["channel"])
+    shapes, scales, locs = orc.hierarchical_prior_params()
+    pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+    T, d = m["iterations"], pk.dim
+    theta0 = np.array(m["theta0"])
+    st = pk.init_state(theta0, 0.01)                              # :431
+    want = g[run + "_chain"]
+    assert st[d] == pytest.approx(want[0, d], rel=1e-12)
+    rows = pk.advance(st, 0, T, 1, 100 * d, co.gamma_table(T), star_replay=g[run + "_star"], u_replay=g[run + "_u"])
+    chain = np.vstack([want[:1], rows])
+    assert np.array_equal(np.diff(chain[:, 0]) != 0, np.diff(want[:, 0]) != 0) and (np.diff(want[:, 0]) != 0).sum() > 300
+    _close(chain[:, :d], want[:, :d], 0)
+    _close(chain[:, d], want[:, d], 1e-11)
+    final = g[run + "_final"]
+    L = np.zeros((d, d)); L[np.tril_indices(d)] = st[2 * d + 1:2 * d + 1 + d * (d + 1) // 2]
+    np.testing.assert_allclose(L @ L.T, final[:d * d].reshape(d, d), rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(st[d + 1:2 * d + 1], final[d * d:d * d + d], rtol=1e-12)
+    assert st[2 * d + 1 + d * (d + 1) // 2] == pytest.approx(final[-2], rel=1e-11)

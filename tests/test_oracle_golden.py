@@ -153,3 +153,89 @@ def test_predictive_samples_are_inverse_cdf_draws():
         inside = (uu > c[0] + 1e-9) & (uu < c[-1] - 1e-9)                   # outside the tabulated range np.interp clamps
         assert inside.sum() > 1900
         assert np.allclose(np.interp(smp[inside], x, c), uu[inside], atol=1e-9)
+
+
+# ---- G9: the reference's two INLINED loops, executed from its own statements (tests/golden/make_golden_loops.py) ----------------
+def _g9():
+    with open(os.path.join(GOLDEN, "g9_loop_traces_meta.json")) as f:
+        return np.load(os.path.join(GOLDEN, "g9_loop_traces.npz")), json.load(f)
+
+
+@pytest.mark.parametrize("run", ["sl_amio_m2", "sl_amio_m1", "sl_moxi_m2"])
+def test_single_level_loop_replays_the_reference_statements(run, oracle_pair):
+    """python/PyHillFit.py:748-751,787-856 (covariance 0.05 diag|theta0|, NO mean reset, adaptation after 1000 d): the recorded
+    proposals and uniforms through the oracle's loop give the reference's accept sequence, chain, adapted covariance at every
+    iteration, and its final (cov, mean, loga, acceptance)"""
+    g, meta = _g9()
+    m = next(r for r in meta["single_level"] if r["name"] == run)
+    assert m["reference_lines"] == [[748, 751], [787, 864]] and m["when_to_adapt"] == 1000 * (m["model"] + 1)
+    p = oracle_pair(m["drug"], m["channel"])
+    theta0 = np.array(m["theta0"])
+    cov0 = 0.05 * np.diag(np.abs(theta0))
+    trace = {}
+    chain, fin = orc.adaptive_mh(lambda th: orc.log_target(m["model"], p, th, 1), theta0, cov0, m["iterations"], 1, m["when_to_adapt"],
+                                 orc.RecordedDraws(g[run + "_star"], g[run + "_u"]), trace=trace)
+    want = g[run + "_chain"]
+    assert np.array_equal(np.diff(chain[:, 0]) != 0, np.diff(want[:, 0]) != 0) and (np.diff(want[:, 0]) != 0).sum() > 500
+    _same(chain, want, rtol=1e-13)
+    covs = np.array(trace["cov"])
+    np.testing.assert_allclose(covs[::20], g[run + "_cov_every20"], rtol=1e-11)
+    np.testing.assert_allclose(covs[-1], g[run + "_cov_last"], rtol=1e-11)
+    d = len(theta0)
+    final = g[run + "_final"]
+    np.testing.assert_allclose(fin["cov"].ravel(), final[:d * d], rtol=1e-11)
+    np.testing.assert_allclose(fin["mean"], final[d * d:d * d + d], rtol=1e-12)
+    assert fin["loga"] == pytest.approx(final[-2], rel=1e-12) and fin["acceptance"] == pytest.approx(final[-1], rel=1e-12)
+    # the convenience wrapper is that same loop
+    chain2, _ = orc.single_level_chain(m["model"], p, theta0, m["iterations"], 1, orc.RecordedDraws(g[run + "_star"], g[run + "_u"]))
+    assert np.array_equal(chain2, chain)
+
+
+def test_single_level_loop_thinning_burn_in_and_seed(oracle_pair):
+    """:805-814,847-848,861-864 (thinning 5, burn-in = saved/4 rows) and :824-825 (the loop seeds numpy with 25 itself)"""
+    g, meta = _g9()
+    m = next(r for r in meta["single_level"] if r["name"] == "sl_amio_m2_thin5_burn4")
+    p = oracle_pair(m["drug"], m["channel"])
+    chain, _ = orc.single_level_chain(2, p, np.array(m["theta0"]), m["iterations"], 5, orc.LegacyNumpyDraws(25))
+    out = orc.drop_burn_in(chain, 4)
+    want = g["sl_amio_m2_thin5_burn4_chain"]
+    assert out.shape == want.shape == (751, 4) and m["rows"] == 751
+    _same(out, want, rtol=1e-9)                                   # numpy's own generator: draw for draw up to LAPACK's SVD
+
+
+@pytest.mark.parametrize("run", ["hier_amio", "hier_amit"])
+def test_hierarchical_loop_replays_the_reference_statements(run, oracle_pair):
+    """python/PyHillFit.py:431-511 (covariance 0.01 diag|theta0|, adaptation after 100 dim), Ne = 3 and Ne = 6"""
+    g, meta = _g9()
+    m = next(r for r in meta["hierarchical"] if r["name"] == run)
+    assert m["reference_lines"] == [[431, 511]]
+    p = oracle_pair(m["drug"], m["channel"])
+    theta0 = np.array(m["theta0"])
+    dim = len(theta0)
+    assert m["when_to_adapt"] == 100 * dim and dim == 5 + 2 * m["Ne"]
+    shapes, scales, locs = orc.hierarchical_prior_params()
+    trace = {}
+    chain, fin = orc.adaptive_mh(lambda th: orc.hier_log_target(p.experiments, th, shapes, scales, locs), theta0, np.diag(0.01 * np.abs(theta0)),
+                                 m["iterations"], 1, 100 * dim, orc.RecordedDraws(g[run + "_star"], g[run + "_u"]), trace=trace)
+    want = g[run + "_chain"]
+    assert np.array_equal(np.diff(chain[:, 0]) != 0, np.diff(want[:, 0]) != 0) and (np.diff(want[:, 0]) != 0).sum() > 300
+    _same(chain, want, rtol=1e-12)
+    covs = np.array(trace["cov"])
+    np.testing.assert_allclose(covs[::50], g[run + "_cov_every50"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(covs[-1], g[run + "_cov_last"], rtol=1e-10, atol=1e-300)
+    final = g[run + "_final"]
+    np.testing.assert_allclose(fin["cov"].ravel(), final[:dim * dim], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(fin["mean"], final[dim * dim:dim * dim + dim], rtol=1e-12)
+    assert fin["loga"] == pytest.approx(final[-2], rel=1e-12)
+    chain2, _ = orc.hierarchical_chain(p.experiments, theta0, m["iterations"], 1, orc.RecordedDraws(g[run + "_star"], g[run + "_u"]))
+    assert np.array_equal(chain2, chain)
+
+
+def test_hierarchical_loop_thinning_and_burn(oracle_pair):
+    """:469-472,502-503: saved_iterations = T/thin + 1, burn = saved/4 (only used for the alpha/mu subsample), full chain kept"""
+    g, meta = _g9()
+    m = next(r for r in meta["hierarchical"] if r["name"] == "hier_amio_thin5")
+    assert m["saved_iterations"] == m["iterations"] // 5 + 1 == m["rows"] and m["burn"] == m["saved_iterations"] // 4
+    p = oracle_pair(m["drug"], m["channel"])
+    chain, _ = orc.hierarchical_chain(p.experiments, np.array(m["theta0"]), m["iterations"], 5, orc.LegacyNumpyDraws(1))
+    _same(chain, g["hier_amio_thin5_chain"], rtol=1e-8)
