@@ -124,6 +124,7 @@ def parse_args(argv=None):
     ap.add_argument("--thinning", type=int, default=5)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--moments", action="store_true", help="also accumulate posterior moments and <log L> on the device (what the CLIs and the thermodynamic-integration path run)")
+    ap.add_argument("--queue-quanta", type=int, default=None, help="quanta per block of the work-queue launch (0: plain launch; default: the sampler's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args(argv)
 
@@ -278,7 +279,8 @@ def main():
             pair_index, temps = list(range(len(names))), [1.0] * len(names)
         Q = len(pair_index)
         s = SingleLevelSampler(packed, 2, pair_index, temps, C, thinning=a.thinning, seed=25, chain_id_base=chain_id_base,
-                               reset_mean_at_adapt_start=(a.workload == "c5"), device=dev)
+                               reset_mean_at_adapt_start=(a.workload == "c5"), device=dev,
+                               **({} if a.queue_quanta is None else {"queue_quanta": a.queue_quanta}))
         if a.workload == "c5":
             s.init(np.ones(3), cov_identity=True, cov_scale=1.0)          # PyHillTemp.py:63,80 start
         else:

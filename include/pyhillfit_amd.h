@@ -119,6 +119,18 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
                              int64_t t_begin, int64_t t_end, double* state, double* rows,
                              double* moments, int64_t moments_after, void* stream);
 
+/* The same advance as a WORK QUEUE inside one launch (ABI 3).  The launch is cut into quanta of `quantum` iterations; the grid is
+ * only as large as the chip holds at once and its wavefronts pull (quantum, block) tasks — quantum-major, blocks in
+ * prob->launch_order — from a counter, a block's quanta chaining through its state in HBM with agent-scope release/acquire.
+ * Results are identical to phf_single_level_advance (same chains, rows, state, moments); what changes is the tail of a launch
+ * whose problems differ in cost (the reference's unit of work, one pair, varies 2.5x in cost over the Crumb set; its process pool
+ * balances that dynamically too, python/PyHillFit.py:997-1003).  Falls back to the plain launch when queueing cannot pay
+ * (fewer blocks than the chip holds, or fewer than two quanta).
+ *   queue   device int32 [1 + Q * ceil(C/64)] workspace owned by the caller; zeroed here, on the stream, before the launch */
+int phf_single_level_advance_queued(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg,
+                                    int64_t t_begin, int64_t t_end, double* state, double* rows, double* moments,
+                                    int64_t moments_after, int32_t quantum, int32_t* queue, void* stream);
+
 /* Batch evaluation of the single-level log-likelihood and log-prior at M parameter vectors.
  * Replaces calls of dr.log_data_likelihood / dr.log_priors / dr.log_target
  * (python/doseresponse.py:187-189,203-248,166-184), e.g. the Bayes-factor sweep

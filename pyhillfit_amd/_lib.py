@@ -10,7 +10,7 @@ ABI_VERSION = 3
 
 # every symbol include/pyhillfit_amd.h declares
 EXPORTS = ["phf_version", "phf_last_error", "phf_single_level_state_size", "phf_single_level_init",
-           "phf_single_level_advance", "phf_single_level_log_target", "phf_debug_math", "phf_debug_philox",
+           "phf_single_level_advance", "phf_single_level_advance_queued", "phf_single_level_log_target", "phf_debug_math", "phf_debug_philox",
            "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance",
            "phf_hierarchical_log_target", "phf_predictive_scratch_bytes", "phf_predictive_accumulate"]
 
@@ -63,6 +63,8 @@ def load():
     lib.phf_single_level_init.argtypes = [C.POINTER(Points), C.POINTER(Problems), i32, i32, f64, vp, vp, vp, vp]
     lib.phf_single_level_advance.argtypes = [C.POINTER(Points), C.POINTER(Problems), C.POINTER(MhConfig), i64, i64, vp,
                                              vp, vp, i64, vp]
+    lib.phf_single_level_advance_queued.argtypes = [C.POINTER(Points), C.POINTER(Problems), C.POINTER(MhConfig), i64, i64, vp,
+                                                    vp, vp, i64, i32, vp, vp]
     lib.phf_single_level_log_target.argtypes = [C.POINTER(Points), i32, i64, vp, vp, vp, vp, vp, vp]
     lib.phf_debug_math.argtypes = [i32, i64, vp, vp, vp]
     lib.phf_debug_philox.argtypes = [i64, vp, vp, vp]

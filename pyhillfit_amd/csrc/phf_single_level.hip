@@ -55,6 +55,9 @@ struct AdvanceArgs {
   double* moments;
   int64_t moments_after;
   int32_t blocks_per_problem;
+  // work queue (phf_single_level_advance_queued): queue[0] = next task, queue[1 + b] = quanta of block b that are complete
+  int32_t* queue;
+  int32_t quantum;
 };
 
 // stage one pair's entries into LDS (lc = s_pts, y = s_pts + stride, w = s_pts + 2 stride); returns counts
@@ -77,7 +80,7 @@ __device__ __forceinline__ void stage_points(const phf_points& pts, int pair, do
 // on Amiodarone-hERG); -1: read from the data at run time.  Either way the same operations in the same order.
 template <int MODEL, bool MOMENTS, int KO, int KC, bool ERFCX_IN_VGPRS>
 __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double* s_pts, int q, int c, int pair,
-                                             int n_other_rt, int n_cens_rt) {
+                                             int n_other_rt, int n_cens_rt, const int64_t t_begin, const int64_t t_end) {
   constexpr int D = Dim<MODEL>::d;
   constexpr int NTRI = D * (D + 1) / 2;
   const int C = a.prob.chains_per_problem;
@@ -134,11 +137,12 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   }
 
   const int thin = a.cfg.thinning;
-  int until_save = thin - (int)(a.t_begin % thin);   // iterations until the next t with t % thin == 0
+  int until_save = thin - (int)(t_begin % thin);   // iterations until the next t with t % thin == 0
   // rows[r][q][f][c]
   const bool save_rows = a.rows != nullptr;             // wave-uniform (scalar) test, not a per-lane pointer compare
-  double* out = a.rows + ((size_t)q * (D + 1)) * C + c;
   const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
+  // a.rows holds the rows of the whole launch (from a.t_begin on); this call may start later (a quantum of a queued launch)
+  double* out = a.rows + ((size_t)q * (D + 1)) * C + c + (size_t)(t_begin / thin - a.t_begin / thin) * row_stride;
 
   // The iteration is ONE basic block up to the sample store: the adaptation is applied unconditionally with gamma = 0 before
   // it starts (cov, mean, loga are then reproduced exactly: (1-0) x + 0 y), and the random numbers of iteration t+1 — a
@@ -146,9 +150,9 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   // chains of an iteration (Philox -> log -> sqrt, and sqrt -> divide -> sqrt -> divide -> sqrt) overlap each other and
   // the likelihood instead of being exposed one after the other on a wavefront that has its SIMD to itself.
   double z[4];
-  double log_u = phf_mh_draws(D, cid, pid, (uint32_t)(a.t_begin + 1), seed_lo, seed_hi, k_log, k_sc, z);
+  double log_u = phf_mh_draws(D, cid, pid, (uint32_t)(t_begin + 1), seed_lo, seed_hi, k_log, k_sc, z);
   const bool reset_mean = a.cfg.reset_mean_at_adapt_start != 0;
-  for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
+  for (int64_t t = t_begin + 1; t <= t_end; ++t) {
     // ---- proposal: theta* = theta + e^(loga/2) L z  (PyHillFit.py:831) ----
     double star[D];
 #pragma unroll
@@ -242,16 +246,14 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
 // command lines and the thermodynamic-integration path run) have the same bodies: with the run-time loops a wavefront that has
 // its SIMD to itself — 64 chains per pair — was 25 % slower (C2 shape: 4.34 ms against 3.27).
 #define PHF_SHAPE_CASE(ko, kc) \
-  case (ko) * 8 + (kc): advance_body<MODEL, MOMENTS, ko, kc, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens); break;
+  case (ko) * 8 + (kc): advance_body<MODEL, MOMENTS, ko, kc, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens, t_begin, t_end); break;
 #define PHF_SHAPE_ROW(ko) PHF_SHAPE_CASE(ko, 0) PHF_SHAPE_CASE(ko, 1) PHF_SHAPE_CASE(ko, 2) PHF_SHAPE_CASE(ko, 3) PHF_SHAPE_CASE(ko, 4)
 
-// WPS = wavefronts per SIMD the register allocation allows for: 2 (256 registers) for launches that fill the chip more than
-// once, 1 (512 registers: VGPRs + AGPRs, nothing spills to scratch) when every wavefront has a SIMD to itself anyway.
+// One block (= one wavefront = 64 chains of one problem) from iteration t_begin to t_end: state in, samples out, state out.
 template <int MODEL, bool MOMENTS, int WPS>
-__global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceArgs a) {
-  extern __shared__ double s_pts[];
-  const int slot = blockIdx.x / a.blocks_per_problem;
-  const int chunk = blockIdx.x - slot * a.blocks_per_problem;
+__device__ __forceinline__ void run_block(const AdvanceArgs& a, double* s_pts, int block, const int64_t t_begin, const int64_t t_end) {
+  const int slot = block / a.blocks_per_problem;
+  const int chunk = block - slot * a.blocks_per_problem;
   const int q = a.prob.launch_order ? a.prob.launch_order[slot] : slot;     // which problem this wavefront works on (wave-uniform)
   const int c = chunk * kBlock + threadIdx.x;
   int n_other, n_zero, n_hundred;
@@ -262,11 +264,63 @@ __global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceAr
   if (n_other <= 4 && n_cens <= 4) {
     switch (n_other * 8 + n_cens) {                     // wave-uniform
       PHF_SHAPE_ROW(1) PHF_SHAPE_ROW(2) PHF_SHAPE_ROW(3) PHF_SHAPE_ROW(4)
-      default: advance_body<MODEL, MOMENTS, -1, -1, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens); break;
+      default: advance_body<MODEL, MOMENTS, -1, -1, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens, t_begin, t_end); break;
     }
     return;
   }
-  advance_body<MODEL, MOMENTS, -1, -1, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens);
+  advance_body<MODEL, MOMENTS, -1, -1, WPS == 1>(a, s_pts, q, c, pair, n_other, n_cens, t_begin, t_end);
+}
+
+// WPS = wavefronts per SIMD the register allocation allows for: 2 (256 registers) for launches that fill the chip more than
+// once, 1 (512 registers: VGPRs + AGPRs, nothing spills to scratch) when every wavefront has a SIMD to itself anyway.
+//
+// Plain launch (a.queue == NULL): block b of the grid runs block b of the batch for the whole launch.
+// Queued launch: the grid is only as large as the chip holds at once and its wavefronts PULL tasks from a counter in HBM.  A task
+// is one QUANTUM (a.quantum iterations) of one block; tasks are numbered quantum-major, so that within every quantum the blocks
+// come most expensive first (launch_order) and the last tasks of the launch are short: pairs have 2..8 entries, an iteration
+// 550..1 500 instructions, and with one whole-launch job per block the chip idles ~5 % at the end of a 210-pair launch even in
+// the best order (1.7 % with 4 quanta, 0.7 % with 8: list-scheduling simulation).  A block's quanta chain
+// through its chain state in HBM: the wavefront that finishes quantum k of block b releases (agent scope) and publishes
+// queue[1 + b] = k + 1; the one that pulled quantum k + 1 — issued a whole round of tasks later, so normally long complete —
+// polls that word, acquires, and loads the state.  No cycle is possible (a task waits only for a task with a smaller number,
+// which a RUNNING wavefront holds), whatever part of the grid is resident; a poll that does not end within ~2^24 sleeps poisons
+// the counter so that every wavefront drains.
+template <int MODEL, bool MOMENTS, int WPS>
+__global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceArgs a) {
+  extern __shared__ double s_pts[];
+  const bool queued = a.queue != nullptr;                         // wave-uniform; ONE call site of run_block serves both kinds of launch
+  const int nblocks = a.blocks_per_problem * a.prob.num_problems;
+  const int total = queued ? nblocks * (int)((a.t_end - a.t_begin + a.quantum - 1) / a.quantum) : 0;
+  for (;;) {
+    int b = blockIdx.x, k = 0;
+    int64_t t0 = a.t_begin, t1 = a.t_end;
+    if (queued) {
+      int task = 0;
+      if (threadIdx.x == 0) task = atomicAdd(a.queue, 1);
+      task = __builtin_amdgcn_readfirstlane(task);
+      if (task >= total) break;
+      k = task / nblocks; b = task - k * nblocks;
+      if (k > 0) {
+        int polls = 0;
+        while (__hip_atomic_load(a.queue + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++polls > (1 << 24)) {                             // cannot happen in a correct run: drain instead of hanging
+            if (threadIdx.x == 0) __hip_atomic_store(a.queue, 0x40000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      t0 = a.t_begin + (int64_t)k * a.quantum;
+      t1 = (t0 + a.quantum < a.t_end) ? t0 + a.quantum : a.t_end;
+    }
+    run_block<MODEL, MOMENTS, WPS>(a, s_pts, b, t0, t1);
+    if (!queued) break;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // this block's state (and rows) are in HBM ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_store(a.queue + 1 + b, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the word that says so
+    __syncthreads();                                             // s_pts is restaged by the next task
+  }
 }
 
 struct InitArgs {
@@ -421,9 +475,9 @@ int phf_single_level_init(const phf_points* pts, const phf_problems* prob, int m
   return phf_check_launch("phf_single_level_init");
 }
 
-int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg,
-                             int64_t t_begin, int64_t t_end, double* state, double* rows, double* moments,
-                             int64_t moments_after, void* stream) {
+static int advance_impl(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg, int64_t t_begin, int64_t t_end,
+                        double* state, double* rows, double* moments, int64_t moments_after, int32_t quantum, int32_t* queue,
+                        void* stream) {
   if (!cfg) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null config");
   if (int rc = check_common(pts, prob, cfg->model)) return rc;
   if (!state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null state");
@@ -432,12 +486,25 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
   // gamma[0] is read (and multiplied by zero) on every iteration before the adaptation starts: the table is always needed
   if (!cfg->gamma) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "gamma table required (gamma[0] is read even before adaptation starts)");
   if (t_end == t_begin) return PHF_OK;
-  AdvanceArgs a{*pts, *prob, *cfg, t_begin, t_end, state, rows, moments, moments_after, 0};
+  AdvanceArgs a{*pts, *prob, *cfg, t_begin, t_end, state, rows, moments, moments_after, 0, nullptr, 0};
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
-  const dim3 grid((unsigned)(a.blocks_per_problem * prob->num_problems)), block(kBlock);
+  const int64_t nblocks = (int64_t)a.blocks_per_problem * prob->num_problems;
   const size_t lds = (size_t)pts->stride * 24;
-  const bool lone = (int64_t)grid.x <= phf_simd_count();      // one wavefront per SIMD at most: let it have the whole register file
+  const bool lone = nblocks <= phf_simd_count();            // one wavefront per SIMD at most: let it have the whole register file
   hipStream_t s = (hipStream_t)stream;
+  int64_t grid_blocks = nblocks;
+  if (queue && quantum > 0) {
+    // queued: worth it only when the launch is several rounds of the chip's 2-per-SIMD slots and has at least two quanta
+    const int64_t slots = 2 * phf_simd_count();
+    const int64_t nquanta = (t_end - t_begin + quantum - 1) / quantum;
+    if (nquanta * nblocks > 0x3fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many tasks for one queued launch");
+    if (!lone && nquanta >= 2 && nblocks > slots) {
+      if (hipMemsetAsync(queue, 0, (size_t)(1 + nblocks) * sizeof(int32_t), s) != hipSuccess) return phf_check_launch("phf_single_level_advance_queued (memset)");
+      a.queue = queue; a.quantum = quantum;
+      grid_blocks = slots;
+    }
+  }
+  const dim3 grid((unsigned)grid_blocks), block(kBlock);
 #define PHF_LAUNCH_ADVANCE(M, MOM, W) hipLaunchKernelGGL((mh_advance_kernel<M, MOM, W>), grid, block, lds, s, a)
   if (cfg->model == 1) {
     if (moments) { if (lone) PHF_LAUNCH_ADVANCE(1, true, 1); else PHF_LAUNCH_ADVANCE(1, true, 2); }
@@ -448,6 +515,19 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
   }
 #undef PHF_LAUNCH_ADVANCE
   return phf_check_launch("phf_single_level_advance");
+}
+
+int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg,
+                             int64_t t_begin, int64_t t_end, double* state, double* rows, double* moments,
+                             int64_t moments_after, void* stream) {
+  return advance_impl(pts, prob, cfg, t_begin, t_end, state, rows, moments, moments_after, 0, nullptr, stream);
+}
+
+int phf_single_level_advance_queued(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg,
+                                    int64_t t_begin, int64_t t_end, double* state, double* rows, double* moments,
+                                    int64_t moments_after, int32_t quantum, int32_t* queue, void* stream) {
+  if (quantum <= 0 || !queue) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "queued advance needs a positive quantum and a queue workspace");
+  return advance_impl(pts, prob, cfg, t_begin, t_end, state, rows, moments, moments_after, quantum, queue, stream);
 }
 
 int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, const int32_t* pair_index,

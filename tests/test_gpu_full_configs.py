@@ -106,6 +106,36 @@ def test_hierarchical_sampled_rows_recomputed_by_the_numpy_oracle(gpu, dr, oracl
     assert checked == 630 and worst <= 1.0, (checked, worst)        # in units of the tolerance above
 
 
+# ------------------------------------------------------------------------------------- work-queue launch
+@pytest.mark.parametrize("model,moments", [(2, False), (2, True), (1, False)])
+def test_queued_launch_is_bit_identical_to_the_plain_launch(model, moments, gpu, dr):
+    """phf_single_level_advance_queued (quanta of a block chained through HBM state with agent-scope release/acquire, tasks pulled
+    from a counter) against phf_single_level_advance: same rows, state and moments bit for bit — 210 pairs x 1 024 chains
+    (3 360 blocks over 2 048 resident wavefronts), 2 launches of uneven length, tempered problems mixed in"""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    names = _all_names(dr)
+    packed = dr.pack_single_level(names)
+    Q = len(names)
+    temps = [1.0 if q % 4 else 0.3 for q in range(Q)]
+    got = []
+    for quanta in (0, 4):
+        s = SingleLevelSampler(packed, model, list(range(Q)), temps, 1024, thinning=5, seed=41, adapt_start=600, device=gpu, queue_quanta=quanta)
+        s.init([6.0, 0.8, 8.0] if model == 2 else [6.0, 8.0])
+        if moments:
+            s.enable_moments(after_iteration=500)
+        rows = torch.cat([s.advance(1700), s.advance(2305)])
+        assert (s._queue is not None) == (quanta > 0)
+        if quanta:
+            q_ = s._queue.cpu().numpy()
+            nq = -(-2305 // max(100, -(-(-(-2305 // quanta)) // 5) * 5))
+            assert q_[0] >= 3360 * nq and q_[0] < 0x40000000 and np.all(q_[1:] == nq)      # every task pulled, every block through all its quanta
+        got.append((rows, s.state.clone(), None if s.moments is None else s.moments.clone()))
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    if moments:
+        assert torch.equal(got[0][2], got[1][2])
+    assert torch.isfinite(got[1][0]).all()
+
+
 # ------------------------------------------------------------------------------------- C3 / C4 at full width
 def test_c3_full_width_shard_invariance_and_checkpoint(gpu, dr):
     """210 pairs x 4 096 chains (BASELINE configs[2]): one launch == the pairs split over 3 'ranks' by cost
