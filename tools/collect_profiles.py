@@ -57,7 +57,9 @@ def main():
     # a workload made of several kernels (c4: one per Ne group): sums over the kernels
     group = [k for k in kernels if "advance" in k] if w == "c4" else [key]
     tot = lambda c: sum(ks[k].get(c, 0.0) for k in group)
-    waves = tot("SQ_WAVES")
+    # 64 chains = one wavefront-load of work per launch, whether a wavefront of its own runs it (SQ_WAVES = chains / 64) or the
+    # persistent wavefronts of a queued launch do (SQ_WAVES = the grid)
+    waves = a.chains / 64.0
     per = lambda c: tot(c) / (waves * a.iters)
     fma, mul, add, tr = per("SQ_INSTS_VALU_FMA_F64"), per("SQ_INSTS_VALU_MUL_F64"), per("SQ_INSTS_VALU_ADD_F64"), per("SQ_INSTS_VALU_TRANS_F64")
     facts_path = os.path.join(REPO, "profiles", "pmc_facts.json")
@@ -67,7 +69,7 @@ def main():
         "chains": a.chains, "iterations_per_launch": a.iters, "thinning": a.thinning,
         "flop_per_iteration": round(2 * fma + mul + add + tr, 1),
         "traffic_bytes_per_launch": int(round((tot("WRITE_SIZE") + 2 * tot("FETCH_SIZE")) * 1024)),
-        "derivation": "flop = (2*SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) / (%d waves * %d iterations) = (2*%.1f+%.1f+%.1f+%.1f); "
+        "derivation": "flop = (2*SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) / (%d blocks of 64 chains * %d iterations) = (2*%.1f+%.1f+%.1f+%.1f); "
                       "traffic = WRITE_SIZE %.1f KiB + 2 x FETCH_SIZE %.1f KiB" % (waves, a.iters, fma, mul, add, tr, tot("WRITE_SIZE"), tot("FETCH_SIZE")),
         "instruction_mix_per_iteration": {"VALU": round(per("SQ_INSTS_VALU"), 1), "of which fp64 arithmetic": round(fma + mul + add + tr, 1),
                                           "SALU": round(per("SQ_INSTS_SALU"), 1), "SMEM": round(per("SQ_INSTS_SMEM"), 1), "LDS": round(per("SQ_INSTS_LDS"), 1),
