@@ -149,8 +149,8 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   // function of (chain, t+1) only — are drawn next to the factorisation of iteration t, so that the two long dependency
   // chains of an iteration (Philox -> log -> sqrt, and sqrt -> divide -> sqrt -> divide -> sqrt) overlap each other and
   // the likelihood instead of being exposed one after the other on a wavefront that has its SIMD to itself.
-  double z[4];
-  double log_u = phf_mh_draws(D, cid, pid, (uint32_t)(t_begin + 1), seed_lo, seed_hi, k_log, k_sc, z);
+  double z[3], spare;                                // spare: the second half of a 3-parameter chain's Box-Muller pair B (phf_model.h)
+  double log_u = phf_mh_draws_spare(D, cid, pid, (uint32_t)(t_begin + 1), seed_lo, seed_hi, k_log, k_sc, z, &spare);
   const bool reset_mean = a.cfg.reset_mean_at_adapt_start != 0;
   for (int64_t t = t_begin + 1; t <= t_end; ++t) {
     // ---- proposal: theta* = theta + e^(loga/2) L z  (PyHillFit.py:831) ----
@@ -195,12 +195,12 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
     }
     // ---- draws of the next iteration, factor and scale of the next proposal ----
-    double z_next[4];
-    const double log_u_next = phf_mh_draws(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, k_sc, z_next);
+    double z_next[3];
+    const double log_u_next = phf_mh_draws_carry(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, k_sc, z_next, &spare);
     chol_packed<D>(cov, L);
     sc = phf_exp_fast_k(0.5 * loga, k_exp);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) z[i] = z_next[i];
+    for (int i = 0; i < 3; ++i) z[i] = z_next[i];
     log_u = log_u_next;
     // ---- thinning + sample store (PyHillFit.py:847-848) ----
     if (--until_save == 0) {

@@ -100,3 +100,13 @@ def test_draw_distributions():
     z2 = np.array([co.draws(2, 5, 9, t)[0] for t in range(1, 20001)])       # d = 2: 32-bit fields, 53-bit accept uniform
     assert np.all(z2[:, 2:] == 0) and abs(z2[:, :2].std() - 1) < 0.02 and abs(z2[:, :2].mean()) < 0.02
     assert np.abs(zz).max() < 5.9 and np.abs(z2).max() < 6.7                 # documented truncation of the normals
+    # d = 3: one Box-Muller pair B serves two iterations — cosine half = z2 of the even iteration, sine half = z2 of the odd one after
+    # it (phf_model.h) — so consecutive z2 must be uncorrelated (also in their squares: they share a radius only within a pair, whose
+    # two halves are independent normals), uncorrelated with z0, z1 of both iterations, and z2(t)^2 + z2(t+1)^2 of a pair is chi^2_2
+    zc = z[:, 2]
+    even, odd = zc[1::2][:-1], zc[2::2]                                       # t = 2, 4, ...  and  t = 3, 5, ...: halves of the same pair
+    assert len(even) == len(odd) and abs(np.corrcoef(even, odd)[0, 1]) < 0.03 and abs(np.corrcoef(even ** 2, odd ** 2)[0, 1]) < 0.03
+    r2 = even ** 2 + odd ** 2
+    assert abs(r2.mean() - 2) < 0.06 and abs(r2.var() - 4) < 0.35             # exponential with mean 2
+    assert abs(np.corrcoef(zc[:-1], zc[1:])[0, 1]) < 0.02 and abs(np.corrcoef(zc[1:], z[:-1, 0])[0, 1]) < 0.02
+    assert co.draws(3, 7, 3, 9)[0][2] != co.draws(3, 7, 3, 8)[0][2] and np.all(z[:, 3] == 0)
