@@ -136,6 +136,29 @@ def test_queued_launch_is_bit_identical_to_the_plain_launch(model, moments, gpu,
     assert torch.isfinite(got[1][0]).all()
 
 
+def test_queued_launch_at_the_bench_shape(gpu, dr):
+    """the C3 launch exactly as bench.py runs it — 210 pairs x 4 096 chains = 13 440 blocks over 2 048 persistent wavefronts, 2 000
+    iterations in 4 quanta, three launches back to back — ends in the same state and moments as the plain launches"""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    names = _all_names(dr)
+    packed = dr.pack_single_level(names)
+    Q = len(names)
+    got = []
+    for quanta in (0, 4):
+        s = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, 4096, thinning=5, seed=25, device=gpu, queue_quanta=quanta)
+        s.init([6.0, 0.8, 8.0], cov_identity=False, cov_scale=0.05)
+        s.enable_moments(after_iteration=2000)
+        for _ in range(3):
+            s.advance(2000, save=False)
+        if quanta:
+            q_ = s._queue.cpu().numpy()
+            assert q_[0] >= 13440 * 4 and q_[0] < 0x40000000 and np.all(q_[1:] == 4)
+        got.append((s.state.clone(), s.moments.clone()))
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    acc = got[1][0][14].view(Q, 4096) / 6000.0                     # accepted count / iterations (state row 2d + 2 + d(d+1)/2)
+    assert 0.15 < float(acc.mean()) < 0.45
+
+
 # ------------------------------------------------------------------------------------- C3 / C4 at full width
 def test_c3_full_width_shard_invariance_and_checkpoint(gpu, dr):
     """210 pairs x 4 096 chains (BASELINE configs[2]): one launch == the pairs split over 3 'ranks' by cost
