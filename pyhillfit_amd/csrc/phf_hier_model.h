@@ -66,14 +66,16 @@ PHF_HD double phf_log_from_recip(double x, phf_logred lr, double inv_den, phf_kt
 /* Truncated-Gaussian terms of two points at once (PyHillFit.py:121-125): returns ln(Phi(b0)-Phi(a0)) + ln(Phi(b1)-Phi(a1))
  * where a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma.  Phi(b)-Phi(a) = 1 - [Q(b) + Phi(a)], both tails through
  * erfcx (no cancellation in the tails); four erfcx share one division, the two logs another.                    */
-PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl) {
+/* ke_given: the 23 erfcx coefficients where the caller keeps them (registers, LDS), or 0 (a literal): fetched through the scalar
+ * cache into SGPRs here.                                                                                          */
+/* ke: the 23 erfcx coefficients; kv: they are read as they stand (registers, LDS: compiler-scheduled fma) rather than from SGPRs */
+PHF_HD double phf_trunc_terms_x2_core(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv) {
   const double a0 = -pred0 * inv_s, b0 = (100.0 - pred0) * inv_s, a1 = -pred1 * inv_s, b1 = (100.0 - pred1) * inv_s;
   const double ya0 = -a0 * PHF_INV_SQRT2, yb0 = b0 * PHF_INV_SQRT2, ya1 = -a1 * PHF_INV_SQRT2, yb1 = b1 * PHF_INV_SQRT2;
   double q[4] = {phf_erfcx_den(ya0), phf_erfcx_den(yb0), phf_erfcx_den(ya1), phf_erfcx_den(yb1)};
   phf_batch_recip(q, 4);
-  PHF_KFETCH(ke, phf_k_erfcx, 24);
-  const double ea0 = phf_erfcx_finish_k(ya0, q[0], ke), eb0 = phf_erfcx_finish_k(yb0, q[1], ke);
-  const double ea1 = phf_erfcx_finish_k(ya1, q[2], ke), eb1 = phf_erfcx_finish_k(yb1, q[3], ke);
+  const double ea0 = phf_erfcx_finish_kx(ya0, q[0], ke, kv), eb0 = phf_erfcx_finish_kx(yb0, q[1], ke, kv);
+  const double ea1 = phf_erfcx_finish_kx(ya1, q[2], ke, kv), eb1 = phf_erfcx_finish_kx(yb1, q[3], ke, kv);
   const double ga0 = phf_exp_capped_k(-0.5 * a0 * a0, kx, 0), gb0 = phf_exp_capped_k(-0.5 * b0 * b0, kx, 0);
   const double ga1 = phf_exp_capped_k(-0.5 * a1 * a1, kx, 0), gb1 = phf_exp_capped_k(-0.5 * b1 * b1, kx, 0);
   const double m0 = 1.0 - 0.5 * phf_fma(ea0, ga0, eb0 * gb0), m1 = 1.0 - 0.5 * phf_fma(ea1, ga1, eb1 * gb1);
@@ -83,60 +85,167 @@ PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s, phf_k
   return phf_log_from_recip(m0, l0, d[0], kl) + phf_log_from_recip(m1, l1, d[1], kl);
 }
 
-PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl) {
+/* ke_given: the erfcx coefficients where the caller keeps them (LDS) if have_ke (a literal at the call site), else fetched
+ * through the scalar cache into SGPRs here.  Two call sites rather than a selected pointer: the compiler then knows the address
+ * space of each; a literal flag rather than a null test: an LDS address cannot be proven non-null.                  */
+PHF_HD double phf_trunc_terms_x2_ke(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke_given, int have_ke) {
+  if (have_ke) return phf_trunc_terms_x2_core(pred0, pred1, inv_s, kx, kl, ke_given, 1);
+  PHF_KFETCH(ke, phf_k_erfcx, 24);
+  return phf_trunc_terms_x2_core(pred0, pred1, inv_s, kx, kl, ke, 0);
+}
+
+PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl) {
+  return phf_trunc_terms_x2_ke(pred0, pred1, inv_s, kx, kl, 0, 0);
+}
+
+PHF_HD double phf_trunc_term_core(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv) {
   const double a = -pred * inv_s, b = (100.0 - pred) * inv_s;
   const double ya = -a * PHF_INV_SQRT2, yb = b * PHF_INV_SQRT2;
   double q[2] = {phf_erfcx_den(ya), phf_erfcx_den(yb)};
   phf_batch_recip(q, 2);
-  PHF_KFETCH(ke, phf_k_erfcx, 24);
-  const double ea = phf_erfcx_finish_k(ya, q[0], ke), eb = phf_erfcx_finish_k(yb, q[1], ke);
+  const double ea = phf_erfcx_finish_kx(ya, q[0], ke, kv), eb = phf_erfcx_finish_kx(yb, q[1], ke, kv);
   const double ga = phf_exp_capped_k(-0.5 * a * a, kx, 1), gb = phf_exp_capped_k(-0.5 * b * b, kx, 1);
   const double m = 1.0 - 0.5 * phf_fma(ea, ga, eb * gb);
   const phf_logred lr = phf_log_reduce(m);
   return phf_log_from_recip(m, lr, phf_rcp(2.0 + lr.f), kl);
 }
 
-/* n_expts must be a compile-time constant at the call site (PHF_HIER_MAX_EXPTS at most) when theta lives in registers. */
-/* fixed_n > 0: every experiment has exactly fixed_n points (a literal at the call site: the point loops then unroll and
- * an iteration of the sampler is straight-line code; 147 of the 210 Crumb pairs are 3 experiments x 4 points);
- * 0: experiment i's points are expt_start[i] .. expt_start[i+1]-1.  Same operations in the same order either way. */
-PHF_HD double phf_hier_log_target_n(int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
-                                    const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
+PHF_HD double phf_trunc_term_ke(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke_given, int have_ke) {
+  if (have_ke) return phf_trunc_term_core(pred, inv_s, kx, kl, ke_given, 1);
+  PHF_KFETCH(ke, phf_k_erfcx, 24);
+  return phf_trunc_term_core(pred, inv_s, kx, kl, ke, 0);
+}
+
+PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl) { return phf_trunc_term_ke(pred, inv_s, kx, kl, 0, 0); }
+
+/* ---- the target as the sum of two HALVES ---------------------------------------------------------------------------
+ * log target = P_0 + P_1 (or -inf outside the support), where each half is a fixed sequence of operations on its own share of
+ * the work.  The halves exist so that TWO LANES can share one chain (hier_advance2_kernel: lane 2c computes P_0, lane 2c+1
+ * computes P_1 of chain c, one cross-lane addition joins them); a kernel or the twin that gives a chain one lane evaluates
+ * the two halves one after the other.  Same value either way, bit for bit — the addition commutes.
+ *
+ *   first batch of logarithms (9 + Ne of them), in this order:
+ *       ln alpha | ln Hill_1 .. ln Hill_Ne | ln beta | ln(alpha-loc0) ln(beta-loc1) ln(mu-loc2) ln(s-loc3) ln(sigma-loc4) | ln s | ln sigma
+ *     with weights
+ *       -Ne beta |  beta - 1  (each)       |   Ne    |   shape_k - 1  (each: the Gamma priors, :187)                       | -Ne  | -n_pts
+ *     half 0 takes the first ceil((9+Ne)/2) (always ln alpha and every ln Hill_i), half 1 the rest; each half shares ONE
+ *     division among its logarithms, 1/sigma and 1/s;
+ *   half 0: + sum_k -(x_k - loc_k)/scale_k   (linear part of the Gamma priors)
+ *           - 2 sum_i ln(1 + (Hill_i/alpha)^beta)                            (log-logistic, :134-142)
+ *   half 1: + sum_i -(pIC50_i - mu)/s  - 2 sum_i ln(1 + exp(-(pIC50_i - mu)/s))   (logistic, :144-154)
+ *   both:   - [ SSE_h / (2 sigma^2) + sum over the half's points of ln(Phi((100-p)/sigma) - Phi((0-p)/sigma)) ]   (:113-132)
+ *     where experiment i's n points are split  first 2*floor((n+2)/4) -> half 0, the others -> half 1  (4 points: 2 + 2).
+ *
+ * `h` is a literal at the call site (twin, one-lane kernels: the selects below fold away) or the lane's parity (two-lane
+ * kernel: each select is a v_cndmask pair; only ARGUMENTS and WEIGHTS are selected, never results of expensive work).
+ * n_expts must be a compile-time constant at the call site when theta lives in registers.
+ * fixed_n > 0: every experiment has exactly fixed_n points (a literal: the point loops unroll, an iteration of the sampler is
+ * straight-line code; 147 of the 210 Crumb pairs are 3 experiments x 4 points); 0: experiment i's points are
+ * expt_start[i] .. expt_start[i+1]-1.  Same operations in the same order either way.                                      */
+#define PHF_PICK(h, x0, x1) ((h) ? (x1) : (x0))
+/* a value the optimiser must treat as computed here: keeps a pick between two ARRAY ELEMENTS a select of two registers (left to
+ * itself hipcc turns it into one load with a selected index, which puts the whole array in scratch memory)               */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PHF_OPAQUE(x) asm("" : "+v"(x))
+#else
+#define PHF_OPAQUE(x) ((void)0)
+#endif
+
+/* support (:176,182): the same for both halves */
+PHF_HD int phf_hier_out_of_support(int n_expts, const double* th, int ts, const phf_hier_prior* pr) {
   const int dim = 5 + 2 * n_expts;
   const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
   int bad = (alpha <= pr->loc[0]) | (beta <= pr->loc[1]) | (mu <= pr->loc[2]) | (s <= pr->loc[3]) | (sigma <= pr->loc[4]);
-  /* ---- one division for 1/sigma, 1/s and the 9 + Ne logarithms that depend on theta alone ---- */
-  const double hv[5] = {alpha, beta, mu, s, sigma};
-  double lx[9 + PHF_HIER_CAP];                                   /* arguments: sigma, alpha, beta, s, 5 x (hyper - loc), Hill_i */
-  lx[0] = sigma; lx[1] = alpha; lx[2] = beta; lx[3] = s;
   PHF_UNROLL
-  for (int k = 0; k < 5; ++k) lx[4 + k] = hv[k] - pr->loc[k];
+  for (int i = 0; i < n_expts; ++i) bad |= (th[(5 + 2 * i) * ts] < 0.0) | (th[(4 + 2 * i) * ts] < PHF_HIER_PIC50_LOWER);
+  return bad;
+}
+
+PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
+                                   const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log,
+                                   phf_ktab ke_given, int have_ke) {
+  const int dim = 5 + 2 * n_expts;
+  const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
+  const int n_pts = fixed_n ? n_expts * fixed_n : expt_start[n_expts];
+  const int nl = 9 + n_expts, n0 = (nl + 1) / 2;
+  /* ---- this half's share of the first batch of logarithms, 1/sigma and 1/s: one division ---- */
+  double ga[10 + PHF_HIER_CAP], gw[10 + PHF_HIER_CAP];            /* arguments and weights of all 9 + Ne (cheap), then the pick */
+  double xl[5];
+  ga[0] = alpha; gw[0] = -(double)n_expts * beta;
   PHF_UNROLL
-  for (int i = 0; i < n_expts; ++i) lx[9 + i] = th[(5 + 2 * i) * ts];
-  const int nl = 9 + n_expts;
-  phf_logred lr[9 + PHF_HIER_CAP];
-  double rc[2 + 9 + PHF_HIER_CAP];
+  for (int i = 0; i < n_expts; ++i) { ga[1 + i] = th[(5 + 2 * i) * ts]; gw[1 + i] = beta - 1.0; }
+  ga[n_expts + 1] = beta; gw[n_expts + 1] = (double)n_expts;
+  {
+    const double hv[5] = {alpha, beta, mu, s, sigma};
+    PHF_UNROLL
+    for (int k = 0; k < 5; ++k) { xl[k] = hv[k] - pr->loc[k]; ga[n_expts + 2 + k] = xl[k]; gw[n_expts + 2 + k] = pr->shape_m1[k]; }
+  }
+  ga[n_expts + 7] = s; gw[n_expts + 7] = -(double)n_expts;
+  ga[n_expts + 8] = sigma; gw[n_expts + 8] = -(double)n_pts;
+  ga[nl] = 1.0; gw[nl] = 0.0;                                     /* pads half 1 when 9 + Ne is odd: ln 1 = 0 */
+  double lx[5 + PHF_HIER_CAP / 2 + 1], lw[5 + PHF_HIER_CAP / 2 + 1];
+  phf_logred lr[5 + PHF_HIER_CAP / 2 + 1];
+  double rc[2 + 5 + PHF_HIER_CAP / 2 + 1];
   rc[0] = sigma; rc[1] = s;
   PHF_UNROLL
-  for (int k = 0; k < nl; ++k) { lr[k] = phf_log_reduce(lx[k]); rc[2 + k] = 2.0 + lr[k].f; }
-  phf_batch_recip(rc, 2 + nl);
+  for (int j = 0; j < n0; ++j) {
+    double a0 = ga[j], a1 = ga[n0 + j], w0 = gw[j], w1 = gw[n0 + j];
+    PHF_OPAQUE(a0); PHF_OPAQUE(a1); PHF_OPAQUE(w0); PHF_OPAQUE(w1);
+    lx[j] = PHF_PICK(h, a0, a1);
+    lw[j] = PHF_PICK(h, w0, w1);
+    lr[j] = phf_log_reduce(lx[j]);
+    rc[2 + j] = 2.0 + lr[j].f;
+  }
+  phf_batch_recip(rc, 2 + n0);
   const double inv_s = rc[0], inv_sc = rc[1];
-  double lg[9 + PHF_HIER_CAP];
+  double lg[5 + PHF_HIER_CAP / 2 + 1];
+  double part = 0.0;
   PHF_UNROLL
-  for (int k = 0; k < nl; ++k) lg[k] = phf_log_from_recip(lx[k], lr[k], rc[2 + k], k_log);
-  const double log_sigma = lg[0], ln_alpha = lg[1], ln_beta = lg[2], ln_s = lg[3];
-
-  double sse = 0.0, trunc = 0.0, hyper = 0.0;
-  double la[2 * PHF_HIER_CAP];                                   /* 1 + (Hill_i/alpha)^beta and 1 + exp(-z_i), logged together below */
+  for (int j = 0; j < n0; ++j) {
+    lg[j] = phf_log_from_recip(lx[j], lr[j], rc[2 + j], k_log);
+    part = phf_fma(lw[j], lg[j], part);
+  }
+  /* ---- linear terms: Gamma priors (half 0), logistic density of the pIC50_i (half 1) ---- */
+  double lin0 = 0.0, lin1 = 0.0;
+  PHF_UNROLL
+  for (int k = 0; k < 5; ++k) lin0 = phf_fma(-xl[k], pr->inv_scale[k], lin0);
+  double la[PHF_HIER_CAP];                                         /* 1 + (Hill_i/alpha)^beta (half 0), 1 + exp(-z_i) (half 1) */
+  PHF_UNROLL
+  for (int i = 0; i < n_expts; ++i) {
+    const double z = (th[(4 + 2 * i) * ts] - mu) * inv_sc;
+    lin1 -= z;
+    const double e_arg = PHF_PICK(h, beta * (lg[1 + i] - lg[0]), -z);     /* half 0 holds ln alpha in lg[0], ln Hill_i in lg[1+i] */
+    la[i] = 1.0 + phf_exp_fast_k(e_arg, k_exp);
+  }
+  part += PHF_PICK(h, lin0, lin1);
+  {                                                                 /* the Ne deferred logarithms: one division */
+    phf_logred l2[PHF_HIER_CAP];
+    double d2[PHF_HIER_CAP];
+    PHF_UNROLL
+    for (int i = 0; i < n_expts; ++i) { l2[i] = phf_log_reduce(la[i]); d2[i] = 2.0 + l2[i].f; }
+    phf_batch_recip(d2, n_expts);
+    PHF_UNROLL
+    for (int i = 0; i < n_expts; ++i) {
+      const double v = phf_log_finish_k(l2[i], l2[i].f * d2[i], k_log);
+      part = phf_fma(-2.0, (la[i] > 0x1p1000) ? PHF_INF : v, part);         /* overflowed power: log(inf) = inf */
+    }
+  }
+  /* ---- this half's points (:117-125) ---- */
+  double sse = 0.0, trunc = 0.0;
   PHF_UNROLL
   for (int i = 0; i < n_expts; ++i) {
     const double pic50 = th[(4 + 2 * i) * ts], hill = th[(5 + 2 * i) * ts];
-    bad |= (hill < 0.0) | (pic50 < PHF_HIER_PIC50_LOWER);
     const double ln_ic50 = PHF_LN10 * (6.0 - pic50);
-    int j = fixed_n ? i * fixed_n : expt_start[i];
-    const int jend = fixed_n ? (i + 1) * fixed_n : expt_start[i + 1];
+    /* this half's points of experiment i: [j, jend).  fixed_n (a multiple of 4): fixed_n / 2 each, trip counts known */
+    const int sb = fixed_n ? i * fixed_n : expt_start[i];
+    const int se = fixed_n ? (i + 1) * fixed_n : expt_start[i + 1];
+    const int nf = fixed_n ? fixed_n / 2 : 2 * ((se - sb + 2) / 4);
+    const int cut = sb + ((nf < se - sb) ? nf : se - sb);
+    int j = sb + (h ? 1 : 0) * (cut - sb);                                   /* affine in the lane parity: one per-lane base, immediate offsets */
+    const int jend = fixed_n ? j + fixed_n / 2 : PHF_PICK(h, cut, se);
+    const int npairs = fixed_n ? fixed_n / 4 : (jend - j) / 2;
     PHF_UNROLL
-    for (; j + 2 <= jend; j += 2) {                                          /* :117-125, two points at a time */
+    for (int p = 0; p < npairs; ++p, j += 2) {                               /* two points at a time */
       const phf_ktab ke = k_exp;
       const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
       const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke, 0);
@@ -144,46 +253,25 @@ PHF_HD double phf_hier_log_target_n(int n_expts, int fixed_n, const int* expt_st
       const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
       const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
-      trunc += phf_trunc_terms_x2(pred0, pred1, inv_s, k_exp, k_log);
+      trunc += phf_trunc_terms_x2_ke(pred0, pred1, inv_s, k_exp, k_log, ke_given, have_ke);
     }
-    for (; j < jend; ++j) {
+    if (!fixed_n && j < jend) {                                              /* at most one left */
       const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
       const double pred = phf_fma(-100.0, w, 100.0);
       const double r = y[j] - pred;
       sse = phf_fma(r, r, sse);
-      trunc += phf_trunc_term(pred, inv_s, k_exp, k_log);
-    }
-    /* log-logistic density of Hill_i (:134-142) and logistic density of pIC50_i (:144-154), logs deferred */
-    const double ln_h = lg[9 + i];
-    const phf_ktab kx = k_exp;
-    la[2 * i] = 1.0 + phf_exp_fast_k(beta * (ln_h - ln_alpha), kx);          /* 1 + (Hill_i/alpha)^beta */
-    const double z = (pic50 - mu) * inv_sc;
-    la[2 * i + 1] = 1.0 + phf_exp_fast_k(-z, kx);
-    hyper += (ln_beta - beta * ln_alpha) + (beta - 1.0) * ln_h;
-    hyper += (-z - ln_s);
-  }
-  {                                                                          /* the 2 Ne deferred logs: one division */
-    phf_logred l2[2 * PHF_HIER_CAP];
-    double d2[2 * PHF_HIER_CAP];
-    PHF_UNROLL
-    for (int k = 0; k < 2 * n_expts; ++k) { l2[k] = phf_log_reduce(la[k]); d2[k] = 2.0 + l2[k].f; }
-    phf_batch_recip(d2, 2 * n_expts);
-    const phf_ktab kl = k_log;
-    PHF_UNROLL
-    for (int k = 0; k < 2 * n_expts; ++k) {
-      const double v = phf_log_finish_k(l2[k], l2[k].f * d2[k], kl);
-      hyper -= 2.0 * ((la[k] > 0x1p1000) ? PHF_INF : v);                     /* overflowed power: log(inf) = inf */
+      trunc += phf_trunc_term_ke(pred, inv_s, k_exp, k_log, ke_given, have_ke);
     }
   }
-  const int n_pts = fixed_n ? n_expts * fixed_n : expt_start[n_expts];
-  double total = -(phf_fma((double)n_pts, log_sigma, sse * (0.5 * inv_s * inv_s)) + trunc);   /* :122-125 */
-  total += hyper;
-  PHF_UNROLL
-  for (int k = 0; k < 5; ++k) {                                              /* :187 */
-    const double xl = hv[k] - pr->loc[k];
-    total += phf_fma(pr->shape_m1[k], lg[4 + k], -xl * pr->inv_scale[k]);
-  }
-  return bad ? -PHF_INF : total;
+  return part - phf_fma(sse, 0.5 * inv_s * inv_s, trunc);
+}
+
+PHF_HD double phf_hier_log_target_n(int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
+                                    const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
+  const int bad = phf_hier_out_of_support(n_expts, th, ts, pr);
+  const double p0 = phf_hier_target_half(0, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 0, 0);
+  const double p1 = phf_hier_target_half(1, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 0, 0);
+  return bad ? -PHF_INF : p0 + p1;
 }
 
 PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const double* lc, const double* y,

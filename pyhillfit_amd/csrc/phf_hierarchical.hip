@@ -40,29 +40,14 @@ struct HierArgs {
   double* row0;
 };
 
-// Where a chain's factor lives.  WPS = wavefronts per SIMD the kernel is built for.
-//   WPS 1: the whole factor in LDS ([tri][64] doubles, 34..78 KB per wavefront: at most 4 wavefronts per CU) and all 512
-//          registers for the iteration.
-//   WPS 2: eight wavefronts share a CU's 160 KB, so kLdsElems2 = 39 elements (19.5 KB) stay in LDS.  During the target —
-//          two thirds of an iteration, and the phase that wants the registers — theta, mean and the factor are all idle, so
-//          the rest is split: kRegElems2 elements in registers and the remainder, with the running mean, IN PLACE IN THE STATE
-//          BUFFER in HBM (struct-of-arrays: one coalesced 512-B access per element and wavefront), read before the proposal
-//          and read/written in the adaptation step.  The parked set is sized to stay in the XCD's L2 (24 doubles per lane x
-//          256 wavefronts = 3 MB of 4): left to itself hipcc parks ~38 doubles per lane in scratch instead, which thrashes L2
-//          (profiles/r02/c4_wps_ab.txt: 38.3 ms against 27.9 for the one-wavefront build).
-// Same arithmetic, same order: the builds are bit-identical to each other and to the twin.
-constexpr int kLdsElems2 = 39;
-constexpr int kRegElems2 = 14;
-constexpr int kLdsPointBytes2 = 160 * 1024 / 8 - kLdsElems2 * kBlock * 8;        // 512 B left for the pair's points
-template <int NE, int WPS>
+// One lane per chain: the whole factor in LDS ([tri][64] doubles, 34..78 KB per wavefront: at most 4 wavefronts per CU, one per
+// SIMD) and all 512 registers for the iteration.
+template <int NE>
 struct Lds {
   static constexpr int dim = 5 + 2 * NE;
   static constexpr int tri = dim * (dim + 1) / 2;
-  static constexpr int nlds = (WPS == 2 && tri > kLdsElems2) ? kLdsElems2 : tri;              // elements [0, nlds) ... see PHF_LGET
-  static constexpr int nreg = (WPS == 2) ? ((tri - nlds) < kRegElems2 ? (tri - nlds) : kRegElems2) : 0;
-  static constexpr int nglob = tri - nlds - nreg;
   static size_t point_bytes(int stride) { return (size_t)stride * 16 + (NE + 1) * 4 + 8; }
-  static size_t bytes(int stride) { return (size_t)nlds * kBlock * 8 + point_bytes(stride); }
+  static size_t bytes(int stride) { return (size_t)tri * kBlock * 8 + point_bytes(stride); }
 };
 
 template <int NE>
@@ -78,20 +63,14 @@ __device__ __forceinline__ void stage(const phf_hier_points& pts, int pair, doub
 
 // The whole launch of one wavefront.  FIXED_N > 0: every experiment of the pair has exactly FIXED_N points, known at compile
 // time (the point loops unroll: straight-line iteration); 0: run-time experiment boundaries.
-template <int NE, int FIXED_N, int NREG, int NGLOB>
+template <int NE, int FIXED_N>
 __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_mem, const double* s_lc, const double* s_y,
                                                   const int* s_es, int q, int c) {
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
-  constexpr bool LEAN = NGLOB > 0;                        // the two-wavefronts-per-SIMD build
-  // factor element e: registers for e < NREG, the state buffer in HBM for NREG <= e < NREG + NGLOB, LDS (sL[.. * 64]) above
-  double* sL = s_mem + threadIdx.x;
-  double Lr[NREG > 0 ? NREG : 1];
-#define PHF_LIDX_R(e) (((e) < NREG) ? (e) : 0)
-#define PHF_LIDX_S(e) (((e) < NREG + NGLOB) ? 0 : (e) - NREG - NGLOB)
-#define PHF_LGET(e) (((e) < NREG) ? Lr[PHF_LIDX_R(e)] : ((e) < NREG + NGLOB) ? PHF_SP(2 * D + 1 + (e)) : sL[PHF_LIDX_S(e) * kBlock])
-#define PHF_LSET(e, v) do { if ((e) < NREG) Lr[PHF_LIDX_R(e)] = (v); else if ((e) < NREG + NGLOB) PHF_SP(2 * D + 1 + (e)) = (v); \
-                            else sL[PHF_LIDX_S(e) * kBlock] = (v); } while (0)
+  double* sL = s_mem + threadIdx.x;                        // factor element e: sL[e * 64]
+#define PHF_LGET(e) sL[(e) * kBlock]
+#define PHF_LSET(e, v) sL[(e) * kBlock] = (v)
   const int C = a.prob.chains_per_problem;
   const uint32_t pid = a.prob.problem_id[q];
   const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
@@ -99,7 +78,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   const size_t nchains = (size_t)a.prob.num_problems * C;
   const size_t g = (size_t)q * C + c;
 
-  double th[D], mean[LEAN ? 1 : D];
+  double th[D], mean[D];
   // element k of this lane's state: a wave-uniform base (scalar registers, recomputed by the scalar unit) + the lane number, so that
   // the ~60 distinct addresses of an iteration cost no vector registers (as per-lane 64-bit pointers they were hipcc's first spill victims)
   double* const sbase = a.state + ((size_t)q * C + (size_t)(c - (int)threadIdx.x));
@@ -108,31 +87,17 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #pragma unroll
   for (int i = 0; i < D; ++i) th[i] = PHF_SP(i);
   double lt = PHF_SP(D);
-  if (!LEAN) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) mean[i] = PHF_SP(D + 1 + i);
-  }
+  for (int i = 0; i < D; ++i) mean[i] = PHF_SP(D + 1 + i);
 #pragma unroll
-  for (int e = 0; e < TRI; ++e)
-    if (e < NREG || e >= NREG + NGLOB) PHF_LSET(e, PHF_SP(2 * D + 1 + e));
+  for (int e = 0; e < TRI; ++e) PHF_LSET(e, PHF_SP(2 * D + 1 + e));
   double loga = PHF_SP(2 * D + 1 + TRI);
   double nacc = PHF_SP(2 * D + 2 + TRI);
-  // coefficient tables: VGPRs for the launch (one wavefront per SIMD: a lone wavefront cannot hide the scalar-load latency),
-  // or — LEAN — fetched through the scalar cache where a phase needs them (no VGPRs to spare; a second wavefront hides the loads)
-  double kv_exp[LEAN ? 1 : 10], kv_log[LEAN ? 1 : 7], kv_sc[LEAN ? 1 : 12];
-  if (!LEAN) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { kv_exp[i] = phf_k_exp[i]; asm volatile("" : "+v"(kv_exp[i])); }
-#pragma unroll
-    for (int i = 0; i < 7; ++i) { kv_log[i] = phf_k_log[i]; asm volatile("" : "+v"(kv_log[i])); }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { kv_sc[i] = phf_k_sincos[i]; asm volatile("" : "+v"(kv_sc[i])); }
-  }
-  double sc;
-  {
-    PHF_KFETCH_UNLESS(k_exp0, !LEAN, kv_exp, phf_k_exp, 10);
-    sc = phf_exp_fast_k(0.5 * loga, k_exp0);
-  }
+  // coefficient tables in VGPRs for the launch: a lone wavefront cannot hide the scalar-load latency
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
+  double sc = phf_exp_fast_k(0.5 * loga, k_exp);
 
   const bool want_moments = a.moments != nullptr;
   const int thin = a.cfg.thinning;
@@ -143,9 +108,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
     // ---- proposal theta* = theta + e^(loga/2) L z   (PyHillFit.py:485) ----
     double z[D], star[D];
-    PHF_KFETCH_UNLESS(k_exp, !LEAN, kv_exp, phf_k_exp, 10);
-    PHF_KFETCH_UNLESS(k_log, !LEAN, kv_log, phf_k_log, 7);
-    const double log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, kv_sc, LEAN ? 0 : 1, z, 1);
+    const double log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, k_sc, 1, z, 1);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       double v = PHF_LGET(i * (i + 1) / 2 + i) * z[i];
@@ -153,7 +116,6 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
       for (int k = i - 1; k >= 0; --k) v = phf_fma(PHF_LGET(i * (i + 1) / 2 + k), z[k], v);
       star[i] = phf_fma(sc, v, th[i]);
     }
-    if (LEAN) asm volatile("" ::: "memory");               // the HBM-resident part of the state is re-read after the target, not kept live across it
     // ---- target, accept (:486-492) ----
     const double lt_star = phf_hier_log_target_n(NE, FIXED_N, s_es, s_lc, s_y, star, 1, &a.prior, k_exp, k_log);
     const bool acc = log_u < lt_star - lt;
@@ -171,10 +133,8 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
       double w[D];
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        const double mi = LEAN ? PHF_SP(D + 1 + i) : mean[LEAN ? 0 : i];
-        w[i] = sqg * (th[i] - mi);
-        const double mn = phf_fma(gs, th[i], omg * mi);
-        if (LEAN) PHF_SP(D + 1 + i) = mn; else mean[LEAN ? 0 : i] = mn;
+        w[i] = sqg * (th[i] - mean[i]);
+        mean[i] = phf_fma(gs, th[i], omg * mean[i]);
       }
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
 #pragma unroll
@@ -221,29 +181,21 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #pragma unroll
   for (int i = 0; i < D; ++i) PHF_SP(i) = th[i];
   PHF_SP(D) = lt;
-  if (!LEAN) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) PHF_SP(D + 1 + i) = mean[i];
-  }
+  for (int i = 0; i < D; ++i) PHF_SP(D + 1 + i) = mean[i];
 #pragma unroll
-  for (int e = 0; e < TRI; ++e)
-    if (e < NREG || e >= NREG + NGLOB) PHF_SP(2 * D + 1 + e) = PHF_LGET(e);
+  for (int e = 0; e < TRI; ++e) PHF_SP(2 * D + 1 + e) = PHF_LGET(e);
   PHF_SP(2 * D + 1 + TRI) = loga;
   PHF_SP(2 * D + 2 + TRI) = nacc;
 #undef PHF_LGET
 #undef PHF_LSET
-#undef PHF_LIDX_R
-#undef PHF_LIDX_S
 #undef PHF_SP
 }
 
-template <int NE, int WPS>
-__global__ __launch_bounds__(kBlock, WPS) void hier_advance_kernel(const HierArgs a) {
-  constexpr int D = 5 + 2 * NE;
-  constexpr int TRI = D * (D + 1) / 2;
-  constexpr int NREG = Lds<NE, WPS>::nreg, NGLOB = Lds<NE, WPS>::nglob;
+template <int NE>
+__global__ __launch_bounds__(kBlock, 1) void hier_advance_kernel(const HierArgs a) {
   extern __shared__ double s_mem[];
-  double* s_lc = s_mem + (size_t)Lds<NE, WPS>::nlds * kBlock;
+  double* s_lc = s_mem + (size_t)Lds<NE>::tri * kBlock;
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
   const int slot = blockIdx.x / a.blocks_per_problem;
@@ -257,10 +209,306 @@ __global__ __launch_bounds__(kBlock, WPS) void hier_advance_kernel(const HierArg
   bool four_each = true;
 #pragma unroll
   for (int i = 1; i <= NE; ++i) four_each = four_each && (a.pts.expt_start[(size_t)pair * (NE + 1) + i] == 4 * i);
-  if (four_each) hier_advance_body<NE, 4, NREG, NGLOB>(a, s_mem, s_lc, s_y, s_es, q, c);
-  else hier_advance_body<NE, 0, NREG, NGLOB>(a, s_mem, s_lc, s_y, s_es, q, c);
+  if (four_each) hier_advance_body<NE, 4>(a, s_mem, s_lc, s_y, s_es, q, c);
+  else hier_advance_body<NE, 0>(a, s_mem, s_lc, s_y, s_es, q, c);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TWO LANES PER CHAIN.  One lane per chain keeps 2 dim + dim(dim+1)/2 doubles of state per lane (88 at Ne = 3) beside a target
+// that wants every register: one wavefront per SIMD, which then issues one instruction per ~3.3 ns whatever its kind.  Here
+// lanes 2c and 2c+1 of a wavefront share chain c (32 chains per wavefront) and split
+//   the state   lane h owns rows 2a+h (a = 0..A-1, A = ceil(dim/2)) of theta, mean, the update vector and the factor: half the
+//               registers, half the LDS (A^2 slots of 64 doubles: 18 KB per wavefront at Ne = 3 — eight wavefronts per CU);
+//   the draws   Philox block b is evaluated by lane b mod 2 (normals 4b..4b+3, or the accept uniform), broadcast by DPP;
+//   the target  lane h computes half h of the log target (phf_hier_model.h), one cross-lane addition joins the halves;
+//   the factor  y = L z and the Givens sweep row by row: a column's rotation (one square root, one reciprocal) is computed by
+//               both lanes from the owner's diagonal element, every lane then rotates its own rows.
+// Every number is produced by the same operations in the same order as in the one-lane kernel and the twin (rows of a column
+// are independent; the halves of the target are defined per half): chains, states and moments are bit-identical.
+//
+// Factor element (row 2a+h, column k <= 2a) of lane h sits in slot a^2 + k of the lane's LDS column ([slot][64 lanes] doubles):
+// both lanes address "(a, k)" with the SAME immediate offset from the same base register, so one instruction stream serves both
+// and no per-lane address is kept.  What exists on one lane only runs under a lane-parity mask: lane 0's last row (dim is odd, so
+// lane 1 has no row in pair-row A-1), and lane 1's diagonal elements (a, 2a+1) — stored in the slots (A-1)^2 + a that lane 1's
+// missing last row leaves free in its column.
+template <int NE>
+struct Lds2 {
+  static constexpr int dim = 5 + 2 * NE;
+  static constexpr int A = (dim + 1) / 2;
+  static constexpr int slots = A * A;                      // pair-row a: 2a+1 slots; lane 1's diagonals in its unused last pair-row
+  // constants read through LDS (wave-uniform addresses: broadcast reads on the LDS pipe) instead of occupying scalar or vector
+  // registers: 24 erfcx + 12 sin/cos coefficients and the 15 prior parameters.  With SGPR-resident erfcx coefficients the kernel
+  // spilled ~50 scalar registers to VGPR lanes around every pair of points (420 v_readlane/v_writelane per iteration).
+  static constexpr int consts = 24 + 12 + 15;
+  static size_t point_bytes(int stride) { return (size_t)stride * 16 + (NE + 1) * 4 + 8; }
+  static size_t bytes(int stride) { return (size_t)(slots * kBlock + consts) * 8 + point_bytes(stride); }
+};
+
+__device__ __forceinline__ double phf_dpp_quad(double v, const int ctrl_tag) {
+  // quad_perm within groups of four lanes, applied to the two halves of a double
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if (ctrl_tag == 0) { lo = __builtin_amdgcn_mov_dpp(lo, 0xA0, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xA0, 0xf, 0xf, true); }        // [0,0,2,2]: from the even lane
+  else if (ctrl_tag == 1) { lo = __builtin_amdgcn_mov_dpp(lo, 0xF5, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xF5, 0xf, 0xf, true); }   // [1,1,3,3]: from the odd lane
+  else { lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true); }                       // [1,0,3,2]: the partner's
+  return __hiloint2double(hi, lo);
+}
+#define PHF_FROM_LANE(hsrc, v) phf_dpp_quad((v), (hsrc))
+#define PHF_FROM_PARTNER(v) phf_dpp_quad((v), 2)
+
+// WPS = wavefronts per SIMD the body is compiled for.  2: 256 registers — the erfcx and sin/cos coefficients and the prior
+// parameters are read through LDS (s_k) where they are used; 1: 512 registers — every table resident in registers, the prior in
+// scalar registers (launches whose wavefronts have a SIMD each: nothing would hide an LDS or scalar-cache latency).
+template <int NE, int FIXED_N, int WPS>
+__device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_mem, const double* s_k, const double* s_lc,
+                                                   const double* s_y, const int* s_es, int q, int c0) {
+  constexpr int D = 5 + 2 * NE;
+  constexpr int TRI = D * (D + 1) / 2;
+  constexpr int A = (D + 1) / 2;
+  constexpr bool ODD = (D & 1) != 0;                       // lane 1 has no row in the last pair-row (its row index would be D)
+  const uint32_t lane = threadIdx.x;
+  const int h = (int)(lane & 1u);
+  const int cl = (int)(lane >> 1);                         // chain within the wavefront
+  const int c = c0 + cl;
+  double* const sLane = s_mem + lane;
+#define PHF_L2(a_, k_) sLane[((a_) * (a_) + (k_)) * kBlock]           /* k_ <= 2 a_ */
+#define PHF_L2D(a_) sLane[((A - 1) * (A - 1) + (a_)) * kBlock]        /* lane 1 only: its diagonal element (a_, 2 a_ + 1) */
+  // does this lane have a row in pair-row a_ ?  (a literal a_: folds to true except for lane 1 in the last pair-row of an odd dim)
+#define PHF_HAS_ROW(a_) (!(ODD && (a_) == A - 1) || h == 0)
+  const int C = a.prob.chains_per_problem;
+  const uint32_t pid = a.prob.problem_id[q];
+  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
+  const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
+  const size_t nchains = (size_t)a.prob.num_problems * C;
+  const size_t g = (size_t)q * C + c;
+  double* const sbase = a.state + ((size_t)q * C + (size_t)c0);      // wave-uniform; element k of chain cl: (sbase + k nchains)[cl]
+#define PHF_SP(k) (sbase + (size_t)(k) * nchains)[cl]
+
+  double th[A], mean[A];                                   // rows 2a+h; the missing row of lane 1 is carried as zeros (and stays zero)
+#pragma unroll
+  for (int a_ = 0; a_ < A; ++a_) {
+    th[a_] = 0.0; mean[a_] = 0.0;
+    if (PHF_HAS_ROW(a_)) {
+      const int i = 2 * a_ + h;
+      th[a_] = PHF_SP(i);
+      mean[a_] = PHF_SP(D + 1 + i);
+#pragma unroll
+      for (int k = 0; k <= 2 * a_; ++k) PHF_L2(a_, k) = PHF_SP(2 * D + 1 + i * (i + 1) / 2 + k);
+      if (h) PHF_L2D(a_) = PHF_SP(2 * D + 1 + i * (i + 1) / 2 + i);
+    }
+  }
+  double lt = PHF_SP(D);
+  double loga = PHF_SP(2 * D + 1 + TRI);
+  double nacc = PHF_SP(2 * D + 2 + TRI);
+  PHF_KFETCH_V(k_exp, phf_k_exp, 10);                      // used by every polynomial of the iteration: registers
+  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  double kv_erfcx[WPS == 1 ? 24 : 1], kv_sc[WPS == 1 ? 12 : 1];
+  if (WPS == 1) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { kv_erfcx[WPS == 1 ? i : 0] = phf_k_erfcx[i]; asm volatile("" : "+v"(kv_erfcx[WPS == 1 ? i : 0])); }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { kv_sc[WPS == 1 ? i : 0] = phf_k_sincos[i]; asm volatile("" : "+v"(kv_sc[WPS == 1 ? i : 0])); }
+  }
+  const phf_ktab k_erfcx = (WPS == 1) ? kv_erfcx : s_k, k_sc = (WPS == 1) ? kv_sc : s_k + 24;
+  const phf_hier_prior* const prior = (WPS == 1) ? &a.prior : reinterpret_cast<const phf_hier_prior*>(s_k + 36);
+  double sc = phf_exp_fast_k(0.5 * loga, k_exp);
+
+  const bool want_moments = a.moments != nullptr;
+  const int thin = a.cfg.thinning;
+  int until_save = thin - (int)(a.t_begin % thin);
+  // rows 2a+h of this lane: ONE per-lane pointer (row h of the chain) + wave-uniform offsets 2a C
+  double* out = a.rows ? a.rows + ((size_t)q * (D + 1) + h) * C + c : nullptr;
+  const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
+  double* const mom = want_moments ? a.moments + (size_t)h * nchains + g : nullptr;
+
+  for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
+    // ---- draws: block b by lane b mod 2 — normals 4b..4b+3 for b < NB, the accept uniform for b = NB (phf_hier_draws) ----
+    double z[D];
+    double log_u = 0.0;
+    {
+      constexpr int NB = (D + 3) / 4;
+      constexpr int J = (NB + 2) / 2;                      // evaluations per lane: blocks 2j + h, j < J, cover 0..NB
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int b0 = 2 * j, b1 = 2 * j + 1;              // lane 0's block, lane 1's block
+        const phf_u32x4 w = phf_philox4x32_10(cid, pid, (uint32_t)t, (uint32_t)(2 * j + h), seed_lo, seed_hi);
+        const bool first_pair = (b0 < NB) || (b1 < NB);                                  // normals 4b, 4b+1 always exist for b < NB
+        const bool second_pair = (b0 < NB && 4 * b0 + 2 < D) || (b1 < NB && 4 * b1 + 2 < D);
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+        if (first_pair) phf_box_muller_k(w.w[0], w.w[1], &n0, &n1, k_log, k_sc);
+        if (second_pair) phf_box_muller_k(w.w[2], w.w[3], &n2, &n3, k_log, k_sc);
+        if (b0 < NB) {
+          z[4 * b0] = PHF_FROM_LANE(0, n0);
+          if (4 * b0 + 1 < D) z[4 * b0 + 1] = PHF_FROM_LANE(0, n1);
+          if (4 * b0 + 2 < D) z[4 * b0 + 2] = PHF_FROM_LANE(0, n2);
+          if (4 * b0 + 3 < D) z[4 * b0 + 3] = PHF_FROM_LANE(0, n3);
+        }
+        if (b1 < NB) {
+          z[4 * b1] = PHF_FROM_LANE(1, n0);
+          if (4 * b1 + 1 < D) z[4 * b1 + 1] = PHF_FROM_LANE(1, n1);
+          if (4 * b1 + 2 < D) z[4 * b1 + 2] = PHF_FROM_LANE(1, n2);
+          if (4 * b1 + 3 < D) z[4 * b1 + 3] = PHF_FROM_LANE(1, n3);
+        }
+        if (b0 == NB || b1 == NB) {
+          const double u = phf_uniform53(w.w[0], w.w[1]);
+          const phf_logred lu = phf_log_reduce(u);
+          const double v = phf_log_from_recip(u, lu, phf_rcp(2.0 + lu.f), k_log);
+          log_u = PHF_FROM_LANE((b0 == NB) ? 0 : 1, v);
+        }
+      }
+    }
+    // ---- proposal theta* = theta + e^(loga/2) L z, own rows (PyHillFit.py:485); then every lane gets the whole vector ----
+    double star[D];
+    {
+      double star_o[A];
+#pragma unroll
+      for (int a_ = 0; a_ < A; ++a_) {
+        star_o[a_] = 0.0;
+        if (PHF_HAS_ROW(a_)) {
+          double v = -0.0;                                 // fma(L, z, -0) == L * z bit for bit: lane 0's row starts one column later
+          if (2 * a_ + 1 < D) { if (h) v = PHF_L2D(a_) * z[2 * a_ + 1]; }
+#pragma unroll
+          for (int k = 2 * a_; k >= 0; --k) v = phf_fma(PHF_L2(a_, k), z[k], v);
+          star_o[a_] = phf_fma(sc, v, th[a_]);
+        }
+      }
+#pragma unroll
+      for (int a_ = 0; a_ < A; ++a_) {
+        star[2 * a_] = PHF_FROM_LANE(0, star_o[a_]);
+        if (2 * a_ + 1 < D) star[2 * a_ + 1] = PHF_FROM_LANE(1, star_o[a_]);
+      }
+    }
+    // ---- target: this lane's half + the partner's (:486), accept (:487-492) ----
+    const int bad = phf_hier_out_of_support(NE, star, 1, prior);
+    const double half = phf_hier_target_half(h, NE, FIXED_N, s_es, s_lc, s_y, star, 1, prior, k_exp, k_log, k_erfcx, 1);
+    const double lt_star = bad ? -PHF_INF : half + PHF_FROM_PARTNER(half);
+    const bool acc = log_u < lt_star - lt;
+    if (acc) {                                             // own rows out of the full vector (not kept apart across the target: registers)
+#pragma unroll
+      for (int a_ = 0; a_ < A; ++a_) th[a_] = (2 * a_ + 1 < D) ? (h ? star[2 * a_ + 1] : star[2 * a_]) : (h ? 0.0 : star[2 * a_]);
+      lt = lt_star;
+    }
+    nacc += acc ? 1.0 : 0.0;
+    // ---- adaptation (:495-501): rank-one update of the factor; a column's rotation by both lanes, own rows rotated ----
+    if (t > a.cfg.adapt_start) {
+      const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
+      const double omg = 1.0 - gs;
+      const double sqa = phf_sqrt_pos(omg), sqg = phf_sqrt_pos(gs);
+      double w[A];
+#pragma unroll
+      for (int a_ = 0; a_ < A; ++a_) {
+        w[a_] = sqg * (th[a_] - mean[a_]);
+        mean[a_] = phf_fma(gs, th[a_], omg * mean[a_]);
+      }
+      loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const int m = k >> 1;
+        const bool even = (k & 1) == 0;                    // owner of the diagonal: lane 0 (even k: row 2m) or lane 1 (row 2m+1)
+        const bool below = even && (k + 1 < D);            // even k: lane 1's element of pair-row m is L[k+1][k], a row to rotate
+        double t_own = 0.0;
+        if (even) { if (below || h == 0) t_own = sqa * PHF_L2(m, k); }
+        else { if (h) t_own = sqa * PHF_L2D(m); }
+        const double tkk = PHF_FROM_LANE(even ? 0 : 1, t_own);
+        const double wk = PHF_FROM_LANE(even ? 0 : 1, w[m]);
+        const double r = phf_sqrt_nonneg(phf_fma(tkk, tkk, wk * wk));
+        const double inv = (r > 0.0) ? phf_rcp(r) : 0.0;
+        const double cs = (r > 0.0) ? tkk * inv : 1.0;
+        const double sn = wk * inv;
+        if (below) {
+          const double nl = phf_fma(cs, t_own, sn * w[m]);
+          const double nw = phf_fma(cs, w[m], -(sn * t_own));
+          PHF_L2(m, k) = h ? nl : r;
+          w[m] = nw;                                       // lane 0's w[m] is not read again
+        } else if (even) { if (h == 0) PHF_L2(m, k) = r; }
+        else { if (h) PHF_L2D(m) = r; }
+#pragma unroll
+        for (int a_ = m + 1; a_ < A; ++a_) {
+          if (PHF_HAS_ROW(a_)) {
+            const double tik = sqa * PHF_L2(a_, k);
+            PHF_L2(a_, k) = phf_fma(cs, tik, sn * w[a_]);
+            w[a_] = phf_fma(cs, w[a_], -(sn * tik));
+          }
+        }
+      }
+      sc = phf_exp_fast_k(0.5 * loga, k_exp);
+    }
+    // ---- thinning + sample store (:502-503): own rows; the log target by the even lane ----
+    if (--until_save == 0) {
+      until_save = thin;
+      if (out) {
+#pragma unroll
+        for (int a_ = 0; a_ < A; ++a_)
+          if (PHF_HAS_ROW(a_)) out[(size_t)(2 * a_) * C] = th[a_];
+        if (h == 0) out[(size_t)D * C] = lt;
+        out += row_stride;
+      }
+      if (want_moments && t > a.moments_after) {
+#pragma unroll
+        for (int a_ = 0; a_ < A; ++a_)
+          if (PHF_HAS_ROW(a_)) {
+            phf_accumulate(&mom[(size_t)(2 * a_) * nchains], th[a_]);
+            phf_accumulate(&mom[(size_t)(D + 1 + 2 * a_) * nchains], th[a_] * th[a_]);
+          }
+        if (h == 0) {
+          phf_accumulate(&mom[(size_t)D * nchains], lt);
+          phf_accumulate(&mom[(size_t)(2 * D + 1) * nchains], lt * lt);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int a_ = 0; a_ < A; ++a_) {
+    if (PHF_HAS_ROW(a_)) {
+      const int i = 2 * a_ + h;
+      PHF_SP(i) = th[a_];
+      PHF_SP(D + 1 + i) = mean[a_];
+#pragma unroll
+      for (int k = 0; k <= 2 * a_; ++k) PHF_SP(2 * D + 1 + i * (i + 1) / 2 + k) = PHF_L2(a_, k);
+      if (h) PHF_SP(2 * D + 1 + i * (i + 1) / 2 + i) = PHF_L2D(a_);
+    }
+  }
+  if (h == 0) {
+    PHF_SP(D) = lt;
+    PHF_SP(2 * D + 1 + TRI) = loga;
+    PHF_SP(2 * D + 2 + TRI) = nacc;
+  }
+#undef PHF_L2
+#undef PHF_L2D
+#undef PHF_HAS_ROW
+#undef PHF_SP
+}
+
+constexpr int kChains2 = kBlock / 2;                       // chains per wavefront of the two-lane kernel
+
+template <int NE, int WPS>
+__global__ __launch_bounds__(kBlock, WPS) void hier_advance2_kernel(const HierArgs a) {
+  extern __shared__ double s_mem[];
+  double* s_k = s_mem + (size_t)Lds2<NE>::slots * kBlock;
+  double* s_lc = s_k + Lds2<NE>::consts;
+  double* s_y = s_lc + a.pts.stride;
+  int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
+  const int slot = blockIdx.x / a.blocks_per_problem;
+  const int chunk = blockIdx.x - slot * a.blocks_per_problem;
+  const int q = a.prob.launch_order ? a.prob.launch_order[slot] : slot;
+  const int c0 = chunk * kChains2;
+  const int pair = a.prob.pair_index[q];
+  if (threadIdx.x < 24) s_k[threadIdx.x] = phf_k_erfcx[threadIdx.x];
+  else if (threadIdx.x < 36) s_k[threadIdx.x] = phf_k_sincos[threadIdx.x - 24];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {                            // static indices: a run-time index would copy the argument block to scratch
+    if (threadIdx.x == 36 + i) s_k[36 + i] = a.prior.shape_m1[i];
+    if (threadIdx.x == 41 + i) s_k[41 + i] = a.prior.inv_scale[i];
+    if (threadIdx.x == 46 + i) s_k[46 + i] = a.prior.loc[i];
+  }
+  stage<NE>(a.pts, pair, s_lc, s_y, s_es);
+  if (c0 + (int)(threadIdx.x >> 1) >= a.prob.chains_per_problem) return;    // both lanes of a chain leave together
+  bool four_each = true;
+#pragma unroll
+  for (int i = 1; i <= NE; ++i) four_each = four_each && (a.pts.expt_start[(size_t)pair * (NE + 1) + i] == 4 * i);
+  if (four_each) hier_advance2_body<NE, 4, WPS>(a, s_mem, s_k, s_lc, s_y, s_es, q, c0);
+  else hier_advance2_body<NE, 0, WPS>(a, s_mem, s_k, s_lc, s_y, s_es, q, c0);
+}
 template <int NE>
 __global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
   constexpr int D = 5 + 2 * NE;
@@ -569,45 +817,77 @@ int current_device() {
   return (dev >= 0 && dev < kMaxDevices) ? dev : 0;
 }
 
-// Which build runs: the one-wavefront-per-SIMD build, always, unless PHF_HIER_WPS=2 in the environment asks for the
-// two-wavefronts-per-SIMD one (Ne <= kMaxNe2, points fitting beside 39 factor elements in a 20 KB LDS slice).  Measured on
-// C4 (round 2, profiles/r02/c4_wps_ab.txt): the 256-register build spills ~2 KB per lane (the target alone wants ~260
-// registers) and its scratch traffic makes it SLOWER (38.3 ms per 500 iterations against 29.6), so it is kept for the
-// bit-identity test and for A/B timing only.
-constexpr int kMaxNe2 = 4;
+// Which kernel runs a group of pairs with Ne <= PHF_HIER_FAST_EXPTS experiments (measured on C4's groups and on the command
+// lines' 64 chains per pair, tools/diag_hier_lanes.py, profiles/r02/hier_lanes_ab.txt):
+//   - a launch whose two-lane wavefronts each get a SIMD of their own (blocks <= SIMDs: the command-line regime, where the run
+//     time is the LATENCY of one wavefront-iteration) runs the two-lane kernel built for one wavefront per SIMD: about half the
+//     instructions per iteration;
+//   - bigger launches run the one-lane kernel: a lone wavefront already issues an instruction every ~2.2 ns, the rate at which
+//     the fp64 pipe retires them, so two wavefronts per SIMD gain nothing and the two-lane split costs ~18 % more vector
+//     instructions per chain (rotations and draws computed twice, cross-lane moves).
+// PHF_HIER_LANES=1|2 in the environment forces one, PHF_HIER_WPS=1|2 the register build of the two-lane kernel (read at every
+// launch: the bit-identity test switches them between launches).
+constexpr int kMinNe2 = 3, kMaxNe2 = 6;                           // the two-lane kernel is compiled for the Crumb set's Ne = 3..6
 
-int hier_wps_override() {                                         // read at every launch: tests switch it between launches
-  const char* e = getenv("PHF_HIER_WPS");
+int env_1_or_2(const char* name) {
+  const char* e = getenv(name);
   return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
 }
+int hier_lanes_override() { return env_1_or_2("PHF_HIER_LANES"); }
+int hier_wps_override() { return env_1_or_2("PHF_HIER_WPS"); }   // which build of the two-lane kernel (tests, A/B timing)
 
-template <int NE, int WPS>
-int launch_advance_wps(const HierArgs& a, hipStream_t stream) {
-  const size_t lds = Lds<NE, WPS>::bytes(a.pts.stride);
-  if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
-  static bool configured[kMaxDevices] = {};                      // the attribute is per function AND per device
+template <typename K>
+void allow_big_lds(K kernel, bool* configured) {                  // the attribute is per function AND per device
   const int dev = current_device();
   if (!configured[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_advance_kernel<NE, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void)hipGetLastError();
     }
     configured[dev] = true;
   }
+}
+
+template <int NE>
+int launch_advance1(const HierArgs& a, hipStream_t stream) {
+  const size_t lds = Lds<NE>::bytes(a.pts.stride);
+  if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
+  static bool configured[kMaxDevices] = {};
+  allow_big_lds(&hier_advance_kernel<NE>, configured);
   const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
-  hipLaunchKernelGGL((hier_advance_kernel<NE, WPS>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((hier_advance_kernel<NE>), grid, block, lds, stream, a);
   return phf_check_launch("phf_hierarchical_advance");
+}
+
+template <int NE, int WPS>
+int launch_advance2_wps(const HierArgs& a, size_t lds, hipStream_t stream) {
+  static bool configured[kMaxDevices] = {};
+  allow_big_lds(&hier_advance2_kernel<NE, WPS>, configured);
+  const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
+  hipLaunchKernelGGL((hier_advance2_kernel<NE, WPS>), grid, block, lds, stream, a);
+  return phf_check_launch("phf_hierarchical_advance (two lanes per chain)");
+}
+
+template <int NE>
+int launch_advance2(HierArgs a, hipStream_t stream) {
+  const size_t lds = Lds2<NE>::bytes(a.pts.stride);
+  if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
+  a.blocks_per_problem = (a.prob.chains_per_problem + kChains2 - 1) / kChains2;
+  const int64_t blocks = (int64_t)a.blocks_per_problem * a.prob.num_problems;
+  if (blocks > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
+  const int wps = hier_wps_override();
+  if (wps ? wps == 1 : blocks <= phf_simd_count()) return launch_advance2_wps<NE, 1>(a, lds, stream);
+  return launch_advance2_wps<NE, 2>(a, lds, stream);
 }
 
 template <int NE>
 int launch_advance(const HierArgs& a, hipStream_t stream) {
-  if constexpr (NE <= kMaxNe2) {
-    const bool fits = Lds<NE, 2>::point_bytes(a.pts.stride) <= (size_t)kLdsPointBytes2;
-    const int force = hier_wps_override();
-    const bool two = fits && force == 2;
-    if (two) return launch_advance_wps<NE, 2>(a, stream);
+  if constexpr (NE >= kMinNe2 && NE <= kMaxNe2) {
+    const int force = hier_lanes_override();
+    const int64_t blocks2 = (int64_t)((a.prob.chains_per_problem + kChains2 - 1) / kChains2) * a.prob.num_problems;
+    const bool two = force ? force == 2 : blocks2 <= phf_simd_count();
+    if (two) return launch_advance2<NE>(a, stream);
   }
-  return launch_advance_wps<NE, 1>(a, stream);
+  return launch_advance1<NE>(a, stream);
 }
 
 template <int NE>

@@ -84,11 +84,14 @@ def test_hier_chains_bit_identical_to_cpu_twin(names, gpu, oracle_pair):
 
 
 @pytest.mark.parametrize("names", [[("Amiodarone", "hERG"), ("Verapamil", "hERG")],            # Ne = 3: 4+4+4 points (straight-line body) and 5+5+4
-                                   [("Amiodarone", "Nav1.5-peak"), ("Amiodarone", "Kv4.3")]])  # Ne = 4: 4+4+4+1 and 4+4+4+3
-def test_two_waves_per_simd_build_is_bit_identical(names, gpu, oracle_pair, monkeypatch):
-    """hier_advance_kernel<Ne, 2> (256 registers, part of the factor in registers, 8 wavefronts per CU) against
-    hier_advance_kernel<Ne, 1> (512 registers, whole factor in LDS) and the twin: same chain, same final state, bit for bit;
-    PHF_HIER_WPS forces the build whatever the launch size (big launches choose <Ne, 2> by themselves)"""
+                                   [("Amiodarone", "Nav1.5-peak"), ("Amiodarone", "Kv4.3")],   # Ne = 4: 4+4+4+1 and 4+4+4+3
+                                   [("Moxifloxacin", "KvLQT1/mink"), ("Dofetilide", "hERG")],  # Ne = 5: 4 points each (straight-line) and 5+5+4+2+2
+                                   [("Amitriptyline", "Kv4.3"), ("Cibenzoline", "Kv4.3")]])    # Ne = 6: 4+4+4+4+2+1 and 4+4+4+1+1+1
+def test_two_lanes_per_chain_kernel_is_bit_identical(names, gpu, oracle_pair, monkeypatch):
+    """hier_advance2_kernel<Ne, WPS> (two lanes share a chain: rows of the state, Philox blocks and the halves of the target split
+    between them, 32 chains per wavefront; WPS 1: 512 registers, every table resident — the build small launches run; WPS 2: 256
+    registers, tables and prior through LDS, two wavefronts per SIMD) against hier_advance_kernel<Ne> (one lane per chain) and
+    the twin: same chain, same final state, same moments, bit for bit; PHF_HIER_LANES / PHF_HIER_WPS force kernel and build"""
     from oracle import c_oracle as co
     from pyhillfit_amd import hierarchical as H
     from pyhillfit_amd.sampler import gamma_table
@@ -99,25 +102,28 @@ def test_two_waves_per_simd_build_is_bit_identical(names, gpu, oracle_pair, monk
     d = 5 + 2 * ne
     theta0 = np.array([np.concatenate([[1., 5., 6., .3], np.tile([6.0, 0.8], ne), [8.0]]),
                        np.concatenate([[1.2, 4., 5., .4], np.tile([4.5, 1.1], ne), [5.0]])])
-    C, T, thin, adapt = 200, 600, 5, 140
+    C, T, thin, adapt = 200, 600, 5, 140              # 200 chains: a ragged last wavefront for both kernels (64 and 32 chains each)
     got = {}
-    for wps in ("1", "2"):
-        monkeypatch.setenv("PHF_HIER_WPS", wps)
+    for wps in ("1", "2", "2/2"):
+        monkeypatch.setenv("PHF_HIER_LANES", wps[0])
+        monkeypatch.setenv("PHF_HIER_WPS", "2" if wps == "2/2" else "1")
         s = H.HierarchicalSampler(packed, [0, 1], C, thinning=thin, seed=31337, adapt_start=adapt, problem_ids=[4, 5], chain_id_base=64, device=gpu)
         s.init(theta0, cov_scale=0.01)
         s.enable_moments(after_iteration=adapt)
         chain = np.concatenate([s.advance(k).cpu().numpy() for k in (adapt + 7, T - adapt - 7)])
         mean, var, n = s.posterior_moments()
         got[wps] = (chain, s.state.cpu().numpy().reshape(s.S, 2, C), mean.cpu().numpy())
+    monkeypatch.delenv("PHF_HIER_LANES")
     monkeypatch.delenv("PHF_HIER_WPS")
-    assert np.array_equal(got["1"][0], got["2"][0]) and np.array_equal(got["1"][1], got["2"][1]) and np.array_equal(got["1"][2], got["2"][2])
+    for other in ("2", "2/2"):
+        assert all(np.array_equal(got["1"][i], got[other][i]) for i in range(3)), other
     chain, state, mean = got["2"]
     keep = chain[(adapt // thin):]                                            # rows saved at t > adapt
     np.testing.assert_allclose(mean, keep.mean(axis=0).transpose(1, 0, 2), rtol=1e-12, atol=1e-12)
     gam = gamma_table(T)
     for q in range(2):
         pk = co.PackedHierPair(pairs[q].experiments, shapes, scales, locs)
-        for c in (0, 63, 64, C - 1):
+        for c in (0, 31, 32, 63, 64, C - 1):
             st = pk.init_state(theta0[q], 0.01)
             rows = pk.advance(st, 0, T, thin, adapt, gam, seed=31337, chain_id=64 + c, problem_id=4 + q)
             assert np.array_equal(chain[:, q, :, c], rows), (q, c)
