@@ -146,9 +146,11 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
  * theta = [alpha, beta, mu, s, pIC50_1, Hill_1, ..., pIC50_Ne, Hill_Ne, sigma], dim = 5 + 2 Ne (:178-181).
  * One call handles problems whose pairs all have the same number of experiments Ne (1 <= Ne <= PHF_HIER_MAX_EXPTS);
  * the host groups the pairs by Ne (Crumb: Ne = 3..6).  Ne <= PHF_HIER_FAST_EXPTS runs kernels compiled per Ne (state in
- * registers, proposal factor in LDS); larger Ne (the reference's synthetic set has Ne = 50, dim 105) runs one WAVEFRONT
- * per chain with the whole state in LDS — lanes take an experiment each in the target and a row each in the factor —
- * or, where even that does not fit (never for Ne <= 64), a kernel that keeps the state in the HBM state buffer.  */
+ * registers, proposal factor in LDS) — one lane per chain, or, for Ne = 3..6 when the launch is small enough to give every
+ * wavefront a SIMD of its own, TWO lanes per chain (half the instructions per iteration; same results bit for bit; the
+ * environment variable PHF_HIER_LANES=1|2 forces one or the other) —; larger Ne (the reference's synthetic set has Ne = 50,
+ * dim 105) runs one WAVEFRONT per chain with the whole state in LDS: lanes take an experiment each in the target and a row
+ * each in the factor.                                                                                            */
 #define PHF_HIER_MAX_EXPTS 64
 #define PHF_HIER_FAST_EXPTS 8
 
