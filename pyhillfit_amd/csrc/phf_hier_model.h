@@ -65,58 +65,101 @@ PHF_HD double phf_log_from_recip(double x, phf_logred lr, double inv_den, phf_kt
 
 /* Truncated-Gaussian terms of two points at once (PyHillFit.py:121-125): returns ln(Phi(b0)-Phi(a0)) + ln(Phi(b1)-Phi(a1))
  * where a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma.  Phi(b)-Phi(a) = 1 - [Q(b) + Phi(a)], both tails through
- * erfcx (no cancellation in the tails); four erfcx share one division, the two logs another.                    */
-/* ke_given: the 23 erfcx coefficients where the caller keeps them (registers, LDS), or 0 (a literal): fetched through the scalar
- * cache into SGPRs here.                                                                                          */
-/* ke: the 23 erfcx coefficients; kv: they are read as they stand (registers, LDS: compiler-scheduled fma) rather than from SGPRs */
-PHF_HD double phf_trunc_terms_x2_core(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv) {
+ * erfcx (no cancellation in the tails); the two lower tails share one division, the two upper tails another, the two logs a third.
+ *
+ * An UPPER tail with argument/sqrt2 >= PHF_TAIL_CUT = 6 is DEFINED as zero: Q(6 sqrt2) = 1.1e-17 is below half an ulp of the 1 it is
+ * subtracted from.  That makes it skippable: the upper tails of a pair of points — 2 erfcx, 2 exponentials, a division — are
+ * computed only if SOME lane of the wavefront has one above the cut (a wave-uniform branch; every other lane's result is replaced
+ * by the zero it is defined as, so a chain's value does not depend on its wavefront's other chains, and the scalar twin simply
+ * tests its own).  On the Crumb posteriors the upper tails (100 - pred >= 8.5 sigma) are negligible on all 64 chains for two
+ * thirds of the point pairs (tools/diag_hier_tails.py), the lower ones almost never: those are computed unconditionally.        */
+#define PHF_TAIL_CUT 6.0
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PHF_ANY_LANE(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#else
+#define PHF_ANY_LANE(c) (c)
+#endif
+
+/* The two points' lower tails Phi(a) (always needed) and upper arguments b — first part of phf_trunc_terms_x2_core. */
+PHF_HD void phf_trunc_lower_x2(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab ke, int kv,
+                               double* t0, double* t1, double* b0_out, double* b1_out) {
   const double a0 = -pred0 * inv_s, b0 = (100.0 - pred0) * inv_s, a1 = -pred1 * inv_s, b1 = (100.0 - pred1) * inv_s;
-  const double ya0 = -a0 * PHF_INV_SQRT2, yb0 = b0 * PHF_INV_SQRT2, ya1 = -a1 * PHF_INV_SQRT2, yb1 = b1 * PHF_INV_SQRT2;
-  double q[4] = {phf_erfcx_den(ya0), phf_erfcx_den(yb0), phf_erfcx_den(ya1), phf_erfcx_den(yb1)};
-  phf_batch_recip(q, 4);
-  const double ea0 = phf_erfcx_finish_kx(ya0, q[0], ke, kv), eb0 = phf_erfcx_finish_kx(yb0, q[1], ke, kv);
-  const double ea1 = phf_erfcx_finish_kx(ya1, q[2], ke, kv), eb1 = phf_erfcx_finish_kx(yb1, q[3], ke, kv);
-  const double ga0 = phf_exp_capped_k(-0.5 * a0 * a0, kx, 0), gb0 = phf_exp_capped_k(-0.5 * b0 * b0, kx, 0);
-  const double ga1 = phf_exp_capped_k(-0.5 * a1 * a1, kx, 0), gb1 = phf_exp_capped_k(-0.5 * b1 * b1, kx, 0);
-  const double m0 = 1.0 - 0.5 * phf_fma(ea0, ga0, eb0 * gb0), m1 = 1.0 - 0.5 * phf_fma(ea1, ga1, eb1 * gb1);
+  const double ya0 = -a0 * PHF_INV_SQRT2, ya1 = -a1 * PHF_INV_SQRT2;
+  double qa[2] = {phf_erfcx_den(ya0), phf_erfcx_den(ya1)};
+  phf_batch_recip(qa, 2);
+  const double ea0 = phf_erfcx_finish_kx(ya0, qa[0], ke, kv), ea1 = phf_erfcx_finish_kx(ya1, qa[1], ke, kv);
+  const double ga0 = phf_exp_capped_k(-0.5 * a0 * a0, kx, 0), ga1 = phf_exp_capped_k(-0.5 * a1 * a1, kx, 0);
+  *t0 = ea0 * ga0; *t1 = ea1 * ga1;
+  *b0_out = b0; *b1_out = b1;
+}
+
+/* Second part: the upper tails Q(b) where some lane's is above the cut, then the two logarithms.
+ * skip (a literal): branch around negligible upper tails; 0: compute them regardless and select the zero (same values: the
+ * 256-register two-lane build, whose register allocation spills once the branches cut its straight-line body into blocks).
+ * Measured on one box (one-lane Ne = 3 group of C4): no skipping 17.19 / 17.44 ms, skipping pair by pair 16.52 / 16.82,
+ * skipping in a second pass over the pairs 16.92 / 17.13 (not kept). */
+PHF_HD double phf_trunc_upper_log_x2(double t0, double t1, double b0, double b1, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
+  const double yb0 = b0 * PHF_INV_SQRT2, yb1 = b1 * PHF_INV_SQRT2;
+  const int up0 = yb0 < PHF_TAIL_CUT, up1 = yb1 < PHF_TAIL_CUT;
+  if (!skip || PHF_ANY_LANE(up0 | up1)) {
+    double qb[2] = {phf_erfcx_den(yb0), phf_erfcx_den(yb1)};
+    phf_batch_recip(qb, 2);
+    const double eb0 = phf_erfcx_finish_kx(yb0, qb[0], ke, kv), eb1 = phf_erfcx_finish_kx(yb1, qb[1], ke, kv);
+    const double gb0 = phf_exp_capped_k(-0.5 * b0 * b0, kx, 0), gb1 = phf_exp_capped_k(-0.5 * b1 * b1, kx, 0);
+    t0 += up0 ? eb0 * gb0 : 0.0;
+    t1 += up1 ? eb1 * gb1 : 0.0;
+  }
+  const double m0 = phf_fma(-0.5, t0, 1.0), m1 = phf_fma(-0.5, t1, 1.0);
   const phf_logred l0 = phf_log_reduce(m0), l1 = phf_log_reduce(m1);
   double d[2] = {2.0 + l0.f, 2.0 + l1.f};
   phf_batch_recip(d, 2);
   return phf_log_from_recip(m0, l0, d[0], kl) + phf_log_from_recip(m1, l1, d[1], kl);
 }
 
+/* ke: the 23 erfcx coefficients; kv: they are read as they stand (registers, LDS: compiler-scheduled fma) rather than from SGPRs */
+PHF_HD double phf_trunc_terms_x2_core(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
+  double t0, t1, b0, b1;
+  phf_trunc_lower_x2(pred0, pred1, inv_s, kx, ke, kv, &t0, &t1, &b0, &b1);
+  return phf_trunc_upper_log_x2(t0, t1, b0, b1, kx, kl, ke, kv, skip);
+}
+
 /* ke_given: the erfcx coefficients where the caller keeps them (LDS) if have_ke (a literal at the call site), else fetched
  * through the scalar cache into SGPRs here.  Two call sites rather than a selected pointer: the compiler then knows the address
  * space of each; a literal flag rather than a null test: an LDS address cannot be proven non-null.                  */
-PHF_HD double phf_trunc_terms_x2_ke(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke_given, int have_ke) {
-  if (have_ke) return phf_trunc_terms_x2_core(pred0, pred1, inv_s, kx, kl, ke_given, 1);
+PHF_HD double phf_trunc_terms_x2_ke(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke_given, int have_ke, int skip) {
+  if (have_ke) return phf_trunc_terms_x2_core(pred0, pred1, inv_s, kx, kl, ke_given, 1, skip);
   PHF_KFETCH(ke, phf_k_erfcx, 24);
-  return phf_trunc_terms_x2_core(pred0, pred1, inv_s, kx, kl, ke, 0);
+  return phf_trunc_terms_x2_core(pred0, pred1, inv_s, kx, kl, ke, 0, skip);
 }
 
 PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl) {
-  return phf_trunc_terms_x2_ke(pred0, pred1, inv_s, kx, kl, 0, 0);
+  return phf_trunc_terms_x2_ke(pred0, pred1, inv_s, kx, kl, 0, 0, 1);
 }
 
-PHF_HD double phf_trunc_term_core(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv) {
+PHF_HD double phf_trunc_term_core(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
   const double a = -pred * inv_s, b = (100.0 - pred) * inv_s;
   const double ya = -a * PHF_INV_SQRT2, yb = b * PHF_INV_SQRT2;
-  double q[2] = {phf_erfcx_den(ya), phf_erfcx_den(yb)};
-  phf_batch_recip(q, 2);
-  const double ea = phf_erfcx_finish_kx(ya, q[0], ke, kv), eb = phf_erfcx_finish_kx(yb, q[1], ke, kv);
-  const double ga = phf_exp_capped_k(-0.5 * a * a, kx, 1), gb = phf_exp_capped_k(-0.5 * b * b, kx, 1);
-  const double m = 1.0 - 0.5 * phf_fma(ea, ga, eb * gb);
+  const double ea = phf_erfcx_finish_kx(ya, phf_rcp(phf_erfcx_den(ya)), ke, kv);
+  const double ga = phf_exp_capped_k(-0.5 * a * a, kx, 1);
+  double t = ea * ga;
+  const int up = yb < PHF_TAIL_CUT;
+  if (!skip || PHF_ANY_LANE(up)) {
+    const double eb = phf_erfcx_finish_kx(yb, phf_rcp(phf_erfcx_den(yb)), ke, kv);
+    const double gb = phf_exp_capped_k(-0.5 * b * b, kx, 1);
+    t += up ? eb * gb : 0.0;
+  }
+  const double m = phf_fma(-0.5, t, 1.0);
   const phf_logred lr = phf_log_reduce(m);
   return phf_log_from_recip(m, lr, phf_rcp(2.0 + lr.f), kl);
 }
 
-PHF_HD double phf_trunc_term_ke(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke_given, int have_ke) {
-  if (have_ke) return phf_trunc_term_core(pred, inv_s, kx, kl, ke_given, 1);
+PHF_HD double phf_trunc_term_ke(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke_given, int have_ke, int skip) {
+  if (have_ke) return phf_trunc_term_core(pred, inv_s, kx, kl, ke_given, 1, skip);
   PHF_KFETCH(ke, phf_k_erfcx, 24);
-  return phf_trunc_term_core(pred, inv_s, kx, kl, ke, 0);
+  return phf_trunc_term_core(pred, inv_s, kx, kl, ke, 0, skip);
 }
 
-PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl) { return phf_trunc_term_ke(pred, inv_s, kx, kl, 0, 0); }
+PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl) { return phf_trunc_term_ke(pred, inv_s, kx, kl, 0, 0, 1); }
 
 /* ---- the target as the sum of two HALVES ---------------------------------------------------------------------------
  * log target = P_0 + P_1 (or -inf outside the support), where each half is a fixed sequence of operations on its own share of
@@ -163,7 +206,7 @@ PHF_HD int phf_hier_out_of_support(int n_expts, const double* th, int ts, const 
 
 PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
                                    const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log,
-                                   phf_ktab ke_given, int have_ke) {
+                                   phf_ktab ke_given, int have_ke, int skip_tails) {
   const int dim = 5 + 2 * n_expts;
   const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
   const int n_pts = fixed_n ? n_expts * fixed_n : expt_start[n_expts];
@@ -253,14 +296,14 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
       const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
       const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
-      trunc += phf_trunc_terms_x2_ke(pred0, pred1, inv_s, k_exp, k_log, ke_given, have_ke);
+      trunc += phf_trunc_terms_x2_ke(pred0, pred1, inv_s, k_exp, k_log, ke_given, have_ke, skip_tails);
     }
     if (!fixed_n && j < jend) {                                              /* at most one left */
       const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
       const double pred = phf_fma(-100.0, w, 100.0);
       const double r = y[j] - pred;
       sse = phf_fma(r, r, sse);
-      trunc += phf_trunc_term_ke(pred, inv_s, k_exp, k_log, ke_given, have_ke);
+      trunc += phf_trunc_term_ke(pred, inv_s, k_exp, k_log, ke_given, have_ke, skip_tails);
     }
   }
   return part - phf_fma(sse, 0.5 * inv_s * inv_s, trunc);
@@ -269,8 +312,8 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
 PHF_HD double phf_hier_log_target_n(int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
                                     const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
   const int bad = phf_hier_out_of_support(n_expts, th, ts, pr);
-  const double p0 = phf_hier_target_half(0, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 0, 0);
-  const double p1 = phf_hier_target_half(1, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 0, 0);
+  const double p0 = phf_hier_target_half(0, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 0, 0, 1);
+  const double p1 = phf_hier_target_half(1, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 0, 0, 1);
   return bad ? -PHF_INF : p0 + p1;
 }
 

@@ -379,7 +379,7 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
     }
     // ---- target: this lane's half + the partner's (:486), accept (:487-492) ----
     const int bad = phf_hier_out_of_support(NE, star, 1, prior);
-    const double half = phf_hier_target_half(h, NE, FIXED_N, s_es, s_lc, s_y, star, 1, prior, k_exp, k_log, k_erfcx, 1);
+    const double half = phf_hier_target_half(h, NE, FIXED_N, s_es, s_lc, s_y, star, 1, prior, k_exp, k_log, k_erfcx, 1, WPS == 1);
     const double lt_star = bad ? -PHF_INF : half + PHF_FROM_PARTNER(half);
     const bool acc = log_u < lt_star - lt;
     if (acc) {                                             // own rows out of the full vector (not kept apart across the target: registers)
@@ -851,9 +851,9 @@ template <int NE>
 int launch_advance1(const HierArgs& a, hipStream_t stream) {
   const size_t lds = Lds<NE>::bytes(a.pts.stride);
   if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
+  const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
   static bool configured[kMaxDevices] = {};
   allow_big_lds(&hier_advance_kernel<NE>, configured);
-  const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
   hipLaunchKernelGGL((hier_advance_kernel<NE>), grid, block, lds, stream, a);
   return phf_check_launch("phf_hierarchical_advance");
 }
