@@ -98,7 +98,8 @@ PHF_HD void phf_trunc_lower_x2(double pred0, double pred1, double inv_s, phf_kta
  * 256-register two-lane build, whose register allocation spills once the branches cut its straight-line body into blocks).
  * Measured on one box (one-lane Ne = 3 group of C4): no skipping 17.19 / 17.44 ms, skipping pair by pair 16.52 / 16.82,
  * skipping in a second pass over the pairs 16.92 / 17.13 (not kept). */
-PHF_HD double phf_trunc_upper_log_x2(double t0, double t1, double b0, double b1, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
+PHF_HD void phf_trunc_upper_mass_x2(double t0, double t1, double b0, double b1, phf_ktab kx, phf_ktab ke, int kv, int skip,
+                                    double* m0, double* m1) {
   const double yb0 = b0 * PHF_INV_SQRT2, yb1 = b1 * PHF_INV_SQRT2;
   const int up0 = yb0 < PHF_TAIL_CUT, up1 = yb1 < PHF_TAIL_CUT;
   if (!skip || PHF_ANY_LANE(up0 | up1)) {
@@ -109,18 +110,38 @@ PHF_HD double phf_trunc_upper_log_x2(double t0, double t1, double b0, double b1,
     t0 += up0 ? eb0 * gb0 : 0.0;
     t1 += up1 ? eb1 * gb1 : 0.0;
   }
-  const double m0 = phf_fma(-0.5, t0, 1.0), m1 = phf_fma(-0.5, t1, 1.0);
+  *m0 = phf_fma(-0.5, t0, 1.0);                           /* Phi(b) - Phi(a) = 1 - (Q(b) + Phi(a)) */
+  *m1 = phf_fma(-0.5, t1, 1.0);
+}
+
+/* the truncation masses Phi(b) - Phi(a) of two points */
+PHF_HD void phf_trunc_mass_x2_core(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab ke, int kv, int skip,
+                                   double* m0, double* m1) {
+  double t0, t1, b0, b1;
+  phf_trunc_lower_x2(pred0, pred1, inv_s, kx, ke, kv, &t0, &t1, &b0, &b1);
+  phf_trunc_upper_mass_x2(t0, t1, b0, b1, kx, ke, kv, skip, m0, m1);
+}
+
+/* ke: the 23 erfcx coefficients; kv: they are read as they stand (registers, LDS: compiler-scheduled fma) rather than from SGPRs */
+PHF_HD double phf_trunc_terms_x2_core(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
+  double m0, m1;
+  phf_trunc_mass_x2_core(pred0, pred1, inv_s, kx, ke, kv, skip, &m0, &m1);
   const phf_logred l0 = phf_log_reduce(m0), l1 = phf_log_reduce(m1);
   double d[2] = {2.0 + l0.f, 2.0 + l1.f};
   phf_batch_recip(d, 2);
   return phf_log_from_recip(m0, l0, d[0], kl) + phf_log_from_recip(m1, l1, d[1], kl);
 }
 
-/* ke: the 23 erfcx coefficients; kv: they are read as they stand (registers, LDS: compiler-scheduled fma) rather than from SGPRs */
-PHF_HD double phf_trunc_terms_x2_core(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
-  double t0, t1, b0, b1;
-  phf_trunc_lower_x2(pred0, pred1, inv_s, kx, ke, kv, &t0, &t1, &b0, &b1);
-  return phf_trunc_upper_log_x2(t0, t1, b0, b1, kx, kl, ke, kv, skip);
+/* m0 m1, with the erfcx coefficients from the caller or fetched here (see phf_trunc_terms_x2_ke) */
+PHF_HD double phf_trunc_mass_x2_ke(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab ke_given, int have_ke, int skip) {
+  double m0, m1;
+  if (have_ke) {
+    phf_trunc_mass_x2_core(pred0, pred1, inv_s, kx, ke_given, 1, skip, &m0, &m1);
+  } else {
+    PHF_KFETCH(ke, phf_k_erfcx, 24);
+    phf_trunc_mass_x2_core(pred0, pred1, inv_s, kx, ke, 0, skip, &m0, &m1);
+  }
+  return m0 * m1;
 }
 
 /* ke_given: the erfcx coefficients where the caller keeps them (LDS) if have_ke (a literal at the call site), else fetched
@@ -136,7 +157,7 @@ PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s, phf_k
   return phf_trunc_terms_x2_ke(pred0, pred1, inv_s, kx, kl, 0, 0, 1);
 }
 
-PHF_HD double phf_trunc_term_core(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
+PHF_HD double phf_trunc_mass_core(double pred, double inv_s, phf_ktab kx, phf_ktab ke, int kv, int skip) {
   const double a = -pred * inv_s, b = (100.0 - pred) * inv_s;
   const double ya = -a * PHF_INV_SQRT2, yb = b * PHF_INV_SQRT2;
   const double ea = phf_erfcx_finish_kx(ya, phf_rcp(phf_erfcx_den(ya)), ke, kv);
@@ -148,9 +169,19 @@ PHF_HD double phf_trunc_term_core(double pred, double inv_s, phf_ktab kx, phf_kt
     const double gb = phf_exp_capped_k(-0.5 * b * b, kx, 1);
     t += up ? eb * gb : 0.0;
   }
-  const double m = phf_fma(-0.5, t, 1.0);
+  return phf_fma(-0.5, t, 1.0);
+}
+
+PHF_HD double phf_trunc_term_core(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
+  const double m = phf_trunc_mass_core(pred, inv_s, kx, ke, kv, skip);
   const phf_logred lr = phf_log_reduce(m);
   return phf_log_from_recip(m, lr, phf_rcp(2.0 + lr.f), kl);
+}
+
+PHF_HD double phf_trunc_mass_ke(double pred, double inv_s, phf_ktab kx, phf_ktab ke_given, int have_ke, int skip) {
+  if (have_ke) return phf_trunc_mass_core(pred, inv_s, kx, ke_given, 1, skip);
+  PHF_KFETCH(ke, phf_k_erfcx, 24);
+  return phf_trunc_mass_core(pred, inv_s, kx, ke, 0, skip);
 }
 
 PHF_HD double phf_trunc_term_ke(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke_given, int have_ke, int skip) {
@@ -261,20 +292,33 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
     la[i] = 1.0 + phf_exp_fast_k(e_arg, k_exp);
   }
   part += PHF_PICK(h, lin0, lin1);
-  {                                                                 /* the Ne deferred logarithms: one division */
-    phf_logred l2[PHF_HIER_CAP];
-    double d2[PHF_HIER_CAP];
+  {   /* the Ne deferred logarithms sum_i ln la_i as ONE logarithm of the product (every la_i >= 1: it cannot underflow); only if
+       * the product is not below 2^1000 — an overflowed power somewhere, hundreds of log-units from any posterior — term by term,
+       * under a wave-uniform branch (a chain's value depends on its own product alone) */
+    double prod = la[0];
     PHF_UNROLL
-    for (int i = 0; i < n_expts; ++i) { l2[i] = phf_log_reduce(la[i]); d2[i] = 2.0 + l2[i].f; }
-    phf_batch_recip(d2, n_expts);
-    PHF_UNROLL
-    for (int i = 0; i < n_expts; ++i) {
-      const double v = phf_log_finish_k(l2[i], l2[i].f * d2[i], k_log);
-      part = phf_fma(-2.0, (la[i] > 0x1p1000) ? PHF_INF : v, part);         /* overflowed power: log(inf) = inf */
+    for (int i = 1; i < n_expts; ++i) prod *= la[i];
+    const int big = !(prod < 0x1p1000);
+    const phf_logred lp = phf_log_reduce(prod);
+    double v = phf_log_finish_k(lp, phf_div(lp.f, 2.0 + lp.f), k_log);
+    if (PHF_ANY_LANE(big)) {
+      phf_logred l2[PHF_HIER_CAP];
+      double d2[PHF_HIER_CAP];
+      PHF_UNROLL
+      for (int i = 0; i < n_expts; ++i) { l2[i] = phf_log_reduce(la[i]); d2[i] = 2.0 + l2[i].f; }
+      phf_batch_recip(d2, n_expts);
+      double vs = 0.0;
+      PHF_UNROLL
+      for (int i = 0; i < n_expts; ++i) {
+        const double vi = phf_log_finish_k(l2[i], l2[i].f * d2[i], k_log);
+        vs += (la[i] > 0x1p1000) ? PHF_INF : vi;                             /* overflowed power: log(inf) = inf */
+      }
+      v = big ? vs : v;
     }
+    part = phf_fma(-2.0, v, part);
   }
   /* ---- this half's points (:117-125) ---- */
-  double sse = 0.0, trunc = 0.0;
+  double sse = 0.0, mass = 1.0;                                    /* mass: product of the truncation masses Phi(b) - Phi(a) of this half's points */
   PHF_UNROLL
   for (int i = 0; i < n_expts; ++i) {
     const double pic50 = th[(4 + 2 * i) * ts], hill = th[(5 + 2 * i) * ts];
@@ -296,17 +340,22 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
       const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
       const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
-      trunc += phf_trunc_terms_x2_ke(pred0, pred1, inv_s, k_exp, k_log, ke_given, have_ke, skip_tails);
+      mass *= phf_trunc_mass_x2_ke(pred0, pred1, inv_s, k_exp, ke_given, have_ke, skip_tails);
     }
     if (!fixed_n && j < jend) {                                              /* at most one left */
       const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
       const double pred = phf_fma(-100.0, w, 100.0);
       const double r = y[j] - pred;
       sse = phf_fma(r, r, sse);
-      trunc += phf_trunc_term_ke(pred, inv_s, k_exp, k_log, ke_given, have_ke, skip_tails);
+      mass *= phf_trunc_mass_ke(pred, inv_s, k_exp, ke_given, have_ke, skip_tails);
     }
   }
-  return part - phf_fma(sse, 0.5 * inv_s * inv_s, trunc);
+  /* sum_j ln(Phi(b_j) - Phi(a_j)) as ONE logarithm of the product: every mass is in (0, 1], a half has a handful of points, so the
+   * product cannot overflow and underflows only where sigma ~ 1e27 — there the half is -inf (a proposal to reject), never +inf */
+  const phf_logred lm = phf_log_reduce(mass);
+  const double trunc = phf_log_finish_k(lm, phf_div(lm.f, 2.0 + lm.f), k_log);
+  const double r = part - phf_fma(sse, 0.5 * inv_s * inv_s, trunc);
+  return (mass < PHF_DBL_MIN) ? -PHF_INF : r;
 }
 
 PHF_HD double phf_hier_log_target_n(int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
