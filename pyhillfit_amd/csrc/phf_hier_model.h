@@ -63,9 +63,10 @@ PHF_HD double phf_log_from_recip(double x, phf_logred lr, double inv_den, phf_kt
   return (x < PHF_DBL_MIN) ? -PHF_INF : r;
 }
 
-/* Truncated-Gaussian terms of two points at once (PyHillFit.py:121-125): returns ln(Phi(b0)-Phi(a0)) + ln(Phi(b1)-Phi(a1))
- * where a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma.  Phi(b)-Phi(a) = 1 - [Q(b) + Phi(a)], both tails through
- * erfcx (no cancellation in the tails); the two lower tails share one division, the two upper tails another, the two logs a third.
+/* Truncated-Gaussian terms of two points at once (PyHillFit.py:121-125): the masses Phi(b) - Phi(a) of the two points,
+ * a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma.  Phi(b)-Phi(a) = 1 - [Q(b) + Phi(a)], both tails through erfcx (no cancellation
+ * in the tails); the two lower tails share one division, the two upper tails another.  The per-Ne target multiplies the masses of
+ * a half's points and takes one logarithm (phf_hier_target_half); the per-experiment form logs them two per division.
  *
  * An UPPER tail with argument/sqrt2 >= PHF_TAIL_CUT = 6 is DEFINED as zero: Q(6 sqrt2) = 1.1e-17 is below half an ulp of the 1 it is
  * subtracted from.  That makes it skippable: the upper tails of a pair of points — 2 erfcx, 2 exponentials, a division — are
@@ -93,7 +94,8 @@ PHF_HD void phf_trunc_lower_x2(double pred0, double pred1, double inv_s, phf_kta
   *b0_out = b0; *b1_out = b1;
 }
 
-/* Second part: the upper tails Q(b) where some lane's is above the cut, then the two logarithms.
+/* Second part: the upper tails Q(b) where some lane's is above the cut, then the masses m = Phi(b) - Phi(a) = 1 - t/2 with
+ * t = 2 Phi(a) + 2 Q(b) = erfc(-a/sqrt2) + erfc(b/sqrt2).
  * skip (a literal): branch around negligible upper tails; 0: compute them regardless and select the zero (same values: the
  * 256-register two-lane build, whose register allocation spills once the branches cut its straight-line body into blocks).
  * Measured on one box (one-lane Ne = 3 group of C4): no skipping 17.19 / 17.44 ms, skipping pair by pair 16.52 / 16.82,
