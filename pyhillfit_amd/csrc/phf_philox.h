@@ -19,6 +19,14 @@
 
 typedef struct { uint32_t w[4]; } phf_u32x4;
 
+/* a ^ b ^ c: ONE instruction on gfx950 (v_bitop3_b32 with the truth table of a three-input xor; hipcc does not fuse two
+ * v_xor_b32 into it by itself): 20 instead of 40 logic instructions per Philox block */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PHF_XOR3(a, b, c) ((uint32_t)__builtin_amdgcn_bitop3_b32((int)(a), (int)(b), (int)(c), 0x96))
+#else
+#define PHF_XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#endif
+
 PHF_PHILOX_HD phf_u32x4 phf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                           uint32_t k0, uint32_t k1) {
 #if defined(__HIPCC__)
@@ -27,8 +35,8 @@ PHF_PHILOX_HD phf_u32x4 phf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
   for (int round = 0; round < 10; ++round) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = PHF_XOR3((uint32_t)(p1 >> 32), c1, k0);
+    const uint32_t n2 = PHF_XOR3((uint32_t)(p0 >> 32), c3, k1);
     c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
