@@ -139,6 +139,39 @@ def test_hierarchical_target_against_reference_golden(golden_meta, oracle_pair):
         assert np.isinf(g["target_%d" % ip]).sum() >= 8
 
 
+@pytest.mark.parametrize("drug,channel", [("Amiodarone", "hERG"), ("Amiodarone", "Kv4.3"), ("Dofetilide", "hERG"), ("Amitriptyline", "Kv4.3")])
+def test_hierarchical_target_across_the_tail_cut_against_the_independent_oracle(drug, channel, oracle_pair):
+    """The kernels' target takes an upper truncation tail with (100 - pred)/(sigma sqrt2) >= 6 as zero, logs the PRODUCT of a
+    half's truncation masses and the product of the deferred log-logistic / logistic terms (phf_hier_model.h).  Against the numpy
+    restatement of PyHillFit.py:113-193 — term by term, scipy's ndtr, no shared source — on parameter vectors whose sigma sweeps
+    the points of every experiment across the cut (Ne = 3, 4, 5, 6), and on vectors whose powers overflow the product (the
+    term-by-term fallback): 1e-12 like the goldens."""
+    shapes, scales, locs = orc.hierarchical_prior_params()
+    p = oracle_pair(drug, channel)
+    pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+    ne = len(p.experiments)
+    rng = np.random.RandomState(20 + ne)
+    crossed = [0, 0]
+    for k in range(400):
+        sigma = float(np.exp(rng.uniform(np.log(0.3), np.log(40.0))))
+        pic50s, hills = rng.uniform(3.0, 8.0, ne), np.exp(rng.uniform(np.log(0.3), np.log(3.0), ne))
+        th = np.concatenate([[rng.uniform(0.3, 3.0), rng.uniform(2.1, 9.0), rng.uniform(3.0, 8.0), rng.uniform(0.05, 1.5)],
+                             np.column_stack([pic50s, hills]).ravel(), [sigma]])
+        want = orc.hier_log_target(p.experiments, th, shapes, scales, locs)
+        got = pk.log_target(th)
+        assert got == pytest.approx(want, rel=1e-12, abs=1e-12), (k, th)
+        for i, ex in enumerate(p.experiments):                                  # which side of the cut were this vector's points on?
+            pred = orc.hill_curve(ex[:, 0], hills[i], orc.ic50_of(pic50s[i]))
+            yb = (100.0 - pred) / sigma / np.sqrt(2.0)
+            crossed[0] += int((yb >= 6.0).sum()); crossed[1] += int((yb < 6.0).sum())
+    assert min(crossed) > 200                                                    # both sides well covered
+    # every (Hill_i / alpha)^beta = 1e120 and every exp(-z_i) = e^300: each term finite, their products beyond 2^1000 -> the
+    # term-by-term path
+    th = np.concatenate([[0.5, 120.0, 8.0, 0.01 + 1.0 / 150.0], np.tile([6.0, 5.0], ne), [5.0]])
+    want = orc.hier_log_target(p.experiments, th, shapes, scales, locs)
+    assert np.isfinite(want) and want < -1000 and pk.log_target(th) == pytest.approx(want, rel=1e-12)
+
+
 def test_hierarchical_factor_update_is_the_reference_covariance_recursion(oracle_pair):
     """the twin carries the Cholesky factor and applies cov <- (1-g) cov + g v v' (PyHillFit.py:498-499) as a rank-one
     update: L L' must equal the covariance obtained by iterating the reference formula on the same accepted states"""
