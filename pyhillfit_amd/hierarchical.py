@@ -6,6 +6,7 @@ diag(0.01*|theta0|) (:431), adaptation after 100*dim iterations (:440) — and h
 kernels.  Pairs are grouped by their number of experiments Ne (one kernel instantiation per Ne)."""
 import ctypes as C
 import json
+import os
 import time
 
 import numpy as np
@@ -265,7 +266,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         s.init(theta0, cov_scale=0.01)                                 # :431
         s.enable_moments(after_iteration=max(burn * thinning - 1, 0))
         s.reserve(total_iterations)
-        kept = torch.empty((saved_iterations, Q, d + 1), dtype=torch.float64)
+        kept = torch.empty((saved_iterations, Q, d + 1), dtype=torch.float64, pin_memory=True)   # pinned: the per-segment copies are asynchronous
         kept[0] = s.row0[:, :, 0].cpu()
         files = []
         for q, m in enumerate(members):                               # chain files grow while the GPU samples (:423-426,514-515)
@@ -285,11 +286,21 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     torch.cuda.synchronize(device)
     start = time.time()
     done = 0
-    to_append = []
+    # The groups' streams never join between segments: segment k+1 of every group is queued behind its segment k (and behind the
+    # asynchronous copy of segment k's chain-0 rows to pinned host memory) BEFORE the host waits for segment k's copies and hands
+    # them to the file writers.  A join per segment made every group wait for the slowest one and left the chip with the ragged
+    # tail of a launch (jobs of one whole segment per wavefront) once per segment instead of once per run.
+    in_flight = []                                  # (event, run, first row, number of rows) of the segment whose copies are under way
+    join_segments = os.environ.get("PHF_JOIN_SEGMENTS", "0") == "1"
+    def hand_over(items):
+        for ev, run, r0, nr in items:
+            ev.synchronize()
+            for q, paths in enumerate(run["files"]):
+                chain_streams.append(paths[5], run["kept"][r0:r0 + nr, q].numpy())
     while done < total_iterations:
         k = min(runs[0]["seg"], total_iterations - done) if runs else total_iterations
-        pending = []
-        for run in runs:                       # launch every group first (asynchronous, one stream each) ...
+        queued = []
+        for run in runs:                       # queue this segment of every group (asynchronous, one stream each) ...
             s = run["s"]
             nr = s.rows_between(s.t, s.t + k)
             with torch.cuda.stream(run["stream"]):
@@ -297,21 +308,19 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
                 first = max(0, burn - run["r"])                        # saved rows before `burn` are the burn-in (:84-86 of the CDF script)
                 if run["curves"] is not None and first < nr:
                     run["curves"].accumulate(rows[first:], cdf_chains(args, args.num_chains))
-                pending.append((run, nr, rows))
-        for path, block in to_append:          # ... while the GPU works, hand the PREVIOUS segment's rows to the file writers ...
-            chain_streams.append(path, block)
-        to_append = []
-        for run, nr, rows in pending:          # ... then collect chain 0 of each pair
-            with torch.cuda.stream(run["stream"]):
-                run["kept"][run["r"]:run["r"] + nr] = rows[:, :, :, 0].cpu()
-            for q, paths in enumerate(run["files"]):
-                to_append.append((paths[5], run["kept"][run["r"]:run["r"] + nr, q].numpy()))
+                run["kept"][run["r"]:run["r"] + nr].copy_(rows[:, :, :, 0], non_blocking=True)   # chain 0 of each pair
+                ev = torch.cuda.Event()
+                ev.record(run["stream"])
+            queued.append((ev, run, run["r"], nr))
             run["r"] += nr
+        hand_over(in_flight)                   # ... and, while the GPU works on it, give the PREVIOUS segment's rows to the file writers
+        in_flight = queued
+        if join_segments:                      # diagnostic (PHF_JOIN_SEGMENTS=1): wait for this segment before queueing the next, as round 1 did
+            hand_over(in_flight); in_flight = []
         done += k
+    hand_over(in_flight)
     torch.cuda.synchronize(device)
     elapsed = time.time() - start
-    for path, block in to_append:
-        chain_streams.append(path, block)
     total_chains = sum(len(r_["members"]) for r_ in runs) * args.num_chains
     for run in runs:
         ne, members, theta0, s, kept = run["ne"], run["members"], run["theta0"], run["s"], run["kept"]
