@@ -126,8 +126,8 @@ def run_single_level(pairs, args, device, rank=0, world=1):
             raise SystemExit("--save-all-chains needs {:.1f} GB of device memory for {} pairs x {} chains x {} saved rows, {:.1f} GB are free: "
                              "select fewer pairs (--drugs/--channels), fewer chains or a larger thinning".format(need / 1e9, Q, C, saved_iterations, free / 1e9))
     d = s.d
-    kept = torch.empty((saved_iterations, Q, d + 1, C if keep_all else 1), dtype=torch.float64,
-                       device=device if keep_all else "cpu")
+    kept = (torch.empty((saved_iterations, Q, d + 1, C), dtype=torch.float64, device=device) if keep_all else
+            torch.empty((saved_iterations, Q, d + 1, 1), dtype=torch.float64, pin_memory=True))   # pinned: chain 0 leaves the GPU asynchronously
     kept[0] = s.row0 if keep_all else s.row0[:, :, :1].cpu()
     seg = max(thinning, args.segment - args.segment % thinning)
     buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)
@@ -138,7 +138,9 @@ def run_single_level(pairs, args, device, rank=0, world=1):
         k = min(seg, total_iterations - done)
         nr = k // thinning
         rows = s.advance(k, out=buf[:nr])
-        kept[r:r + nr] = rows if keep_all else rows[:, :, :, :1].cpu()
+        # stream-ordered and asynchronous: the next segment is queued behind this copy while the host moves on (a blocking copy
+        # here left the GPU idle for the gather + transfer + launch latency of every segment)
+        kept[r:r + nr].copy_(rows if keep_all else rows[:, :, :, :1], non_blocking=True)
         done += k; r += nr
     torch.cuda.synchronize(device)
     elapsed = time.time() - start
