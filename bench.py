@@ -184,17 +184,41 @@ class HierarchicalBatch(object):
         return [self.torch.empty((h.rows_between(0, I), h.Q, h.d + 1, self.C), dtype=self.torch.float64, device=self.dev)
                 for h in self.samplers]
 
-    def advance(self, I, out):
+    def advance(self, I, out, join=True):
         # one HIP stream per Ne group: the small groups (Ne = 5, 6: tens of wavefronts) are latency-bound
-        # and hide under the big Ne = 3 launch instead of queueing behind it
+        # and hide under the big Ne = 3 launch instead of queueing behind it.  join=False: the groups' streams are not joined
+        # after the step — consecutive steps of a group follow each other on its stream, the groups drift apart, and the chip sees
+        # the ragged tail of a launch once per run instead of once per step: how pyhillfit_amd.hierarchical.run_hierarchical
+        # drives its segments.  The caller joins once at the end (self.join()).
         torch = self.torch
         cur = torch.cuda.current_stream(self.dev)
         for h, o, st in zip(self.samplers, out, self.streams):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 h.advance(I, out=o)
+        if join:
+            self.join()
+
+    def join(self):
+        cur = self.torch.cuda.current_stream(self.dev)
         for st in self.streams:
             cur.wait_stream(st)
+
+    def mark(self, which):
+        """HIP events on every group's stream (the streams the kernels are launched on): start and end of the timed region"""
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.dev)
+        evs = []
+        for st in self.streams:
+            if which == "start":
+                st.wait_stream(cur)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(st)
+            evs.append(e)
+        setattr(self, "ev_" + which, evs)
+
+    def region_ms(self):
+        return max(b.elapsed_time(e) for b, e in zip(self.ev_start, self.ev_end))
 
     def acceptance_summary(self):
         return self.torch.cat([h.acceptance().mean(dim=1) for h in self.samplers])
@@ -250,7 +274,8 @@ def main():
         label = "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains %s, model 2 (BASELINE configs[4])" % (len(names), C, per)
     else:
         names = all_names
-        label = "hierarchical model, all %d Crumb pairs, %d chains each %s (BASELINE configs[3])" % (len(names), C, per)
+        label = ("hierarchical model, all %d Crumb pairs, %d chains each %s (BASELINE configs[3]); one stream per Ne group, "
+                 "not joined between steps" % (len(names), C, per))
 
     # the partition: weak = this rank's own chain-id range of every problem; strong = this rank's share of the pairs
     chain_id_base = rank * C if a.scaling == "weak" else 0
@@ -305,10 +330,17 @@ def main():
     torch.cuda.synchronize(dev)
     gc.collect(); gc.disable()                      # no collector pause between launches of the timed region
     t0 = time.perf_counter()
-    for k in range(a.steps):
-        ev[k][0].record()
-        s.advance(I, out=rows)
-        ev[k][1].record()
+    if a.workload == "c4":                         # four kernels per step on four streams, not joined between steps
+        s.mark("start")
+        for k in range(a.steps):
+            s.advance(I, out=rows, join=False)
+        s.mark("end")
+        s.join()
+    else:
+        for k in range(a.steps):
+            ev[k][0].record()
+            s.advance(I, out=rows)
+            ev[k][1].record()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -323,7 +355,10 @@ def main():
         ct = torch.tensor([chains_total], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(ct, op=dist.ReduceOp.SUM)
         chains_total = float(ct.item())
-    kernel_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))   # HIP events on the launch stream
+    if a.workload == "c4":
+        kernel_ms = s.region_ms() / a.steps                          # HIP events on the groups' streams: longest stream / steps
+    else:
+        kernel_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))   # HIP events on the launch stream
     for r_ in (rows if isinstance(rows, list) else [rows]):
         assert torch.isfinite(r_).all()
     # "gather samples/summaries" (RCCL, outside the timed region): per-problem mean acceptance of every rank to rank 0
