@@ -127,7 +127,7 @@ def run_single_level(pairs, args, device, rank=0, world=1):
                              "select fewer pairs (--drugs/--channels), fewer chains or a larger thinning".format(need / 1e9, Q, C, saved_iterations, free / 1e9))
     d = s.d
     kept = (torch.empty((saved_iterations, Q, d + 1, C), dtype=torch.float64, device=device) if keep_all else
-            torch.empty((saved_iterations, Q, d + 1, 1), dtype=torch.float64, pin_memory=True))   # pinned: chain 0 leaves the GPU asynchronously
+            chainio.host_buffer((saved_iterations, Q, d + 1, 1)))   # pinned: chain 0 leaves the GPU asynchronously
     kept[0] = s.row0 if keep_all else s.row0[:, :, :1].cpu()
     seg = max(thinning, args.segment - args.segment % thinning)
     buf = torch.empty((seg // thinning, Q, d + 1, C), dtype=torch.float64, device=device)

@@ -125,7 +125,7 @@ def run_tempered(pairs, temperatures, args, device, rank=0, world=1):
         s.init(np.ones(d), cov_identity=True, cov_scale=1.0)                                            # :63,80
         s.enable_moments(after_iteration=max(burn * thinning - 1, 0))
         s.reserve(total_iterations)
-        kept = torch.empty((num_saved, Q, d + 1), dtype=torch.float64, pin_memory=True)   # pinned: chain 0 leaves the GPU asynchronously
+        kept = chainio.host_buffer((num_saved, Q, d + 1))   # pinned: chain 0 leaves the GPU asynchronously
         kept[0] = s.row0[:, :, 0].cpu()
         writers = chainio.WriterPool(args.write_workers if args.write_workers is not None else chainio.default_write_workers(world))
         seg = max(thinning, args.segment - args.segment % thinning)

@@ -264,3 +264,14 @@ def save_best_fit_params(path, theta0, model):
         outfile.write("# least-squares best fit params (start point of the MCMC)\n")
         outfile.write("# pIC50, sigma, (Hill=1, not included)\n" if model == 1 else "# pIC50, Hill, sigma\n")
         np.savetxt(outfile, [theta0])
+
+
+def host_buffer(shape):
+    """float64 host tensor for the rows the command lines keep (chain 0 of every pair): pinned, so that the per-segment copies out of
+    the GPU are asynchronous (the next segment is launched behind them at once); pageable if the host refuses that much pinned
+    memory (0.7-2 GB at the reference's defaults) - the copies are then synchronous, the results the same."""
+    import torch
+    try:
+        return torch.empty(shape, dtype=torch.float64, pin_memory=True)
+    except RuntimeError:
+        return torch.empty(shape, dtype=torch.float64)

@@ -266,7 +266,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         s.init(theta0, cov_scale=0.01)                                 # :431
         s.enable_moments(after_iteration=max(burn * thinning - 1, 0))
         s.reserve(total_iterations)
-        kept = torch.empty((saved_iterations, Q, d + 1), dtype=torch.float64, pin_memory=True)   # pinned: the per-segment copies are asynchronous
+        kept = chainio.host_buffer((saved_iterations, Q, d + 1))   # pinned: the per-segment copies are asynchronous
         kept[0] = s.row0[:, :, 0].cpu()
         files = []
         for q, m in enumerate(members):                               # chain files grow while the GPU samples (:423-426,514-515)
