@@ -158,6 +158,18 @@ def test_hierarchical_cli_and_statistics(gpu, tmp_path):
         w = ref["%s_hERG" % sm["drug"]]
         assert abs(sm["pooled_mean"][0] - w["alpha_mean"]) < 0.12 * w["alpha_mean"] + 0.03
         assert abs(sm["pooled_mean"][2] - w["mu_mean"]) < 0.015 * w["mu_mean"] + 0.03
+        # chain 0 through the text file == the CPU twin, bit for bit: two Ne groups (3 and 5 experiments) on two streams that never
+        # join, three segments of 20 000 iterations each, chain-0 rows copied out asynchronously behind every segment
+        from oracle import c_oracle as co
+        from pyhillfit_amd import hierarchical as H
+        from pyhillfit_amd.sampler import gamma_table
+        shapes, scales, locs = H.prior_params()
+        _, _, ex = dr.load_crumb_data(sm["drug"], "hERG")
+        pk = co.PackedHierPair(ex, shapes, scales, locs)
+        all_pairs = [(a, b) for a in dr.drugs for b in dr.channels]
+        st = pk.init_state(np.array(sm["first_iteration"]), 0.01)
+        rows = pk.advance(st, 0, T, 5, 100 * (5 + 2 * ne), gamma_table(T), seed=25, chain_id=0, problem_id=all_pairs.index((sm["drug"], "hERG")))
+        assert np.array_equal(chain[0, :-1], np.array(sm["first_iteration"])) and np.array_equal(chain[1:], rows)
 
 
 def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):
