@@ -130,6 +130,32 @@ def test_two_lanes_per_chain_kernel_is_bit_identical(names, gpu, oracle_pair, mo
             assert np.array_equal(state[:, q, c], st), (q, c)
 
 
+@pytest.mark.parametrize("C", [1, 33])
+def test_two_lane_kernel_with_one_chain_and_with_a_ragged_wavefront(C, gpu, oracle_pair):
+    """what small command-line runs launch (the default policy picks the two-lane kernel): 1 chain (--num-chains 1: one lane pair of
+    a wavefront) and 33 chains (a second wavefront with one pair active) against the twin, rows and moments"""
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import gamma_table
+    shapes, scales, locs = H.prior_params()
+    p = oracle_pair("Amiodarone", "hERG")
+    packed = H.PackedHierPoints([p.experiments])
+    d = 11
+    theta0 = np.concatenate([[1., 5., 6., .3], np.tile([6.0, 0.8], 3), [8.0]])[None]
+    T, thin, adapt = 400, 5, 120
+    s = H.HierarchicalSampler(packed, [0], C, thinning=thin, seed=77, adapt_start=adapt, problem_ids=[9], device=gpu)
+    s.init(theta0, cov_scale=0.01)
+    s.enable_moments(after_iteration=adapt)
+    chain = np.concatenate([s.advance(k).cpu().numpy() for k in (adapt + 3, T - adapt - 3)])
+    mean, var, n = s.posterior_moments()
+    pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+    for c in sorted({0, C - 1}):
+        st = pk.init_state(theta0[0], 0.01)
+        rows = pk.advance(st, 0, T, thin, adapt, gamma_table(T), seed=77, chain_id=c, problem_id=9)
+        assert np.array_equal(chain[:, 0, :, c], rows), c
+        np.testing.assert_allclose(mean.cpu().numpy()[:, 0, c], rows[(adapt // thin):].mean(axis=0), rtol=1e-12, atol=1e-12)
+
+
 def test_hierarchical_cli_and_statistics(gpu, tmp_path):
     """python PyHillFit.py --hierarchical: files where the reference puts them, (alpha, mu) consistent with the
     reference's stored samples (chaste/samples, coarse: 500 draws of an unseeded run)"""
