@@ -265,6 +265,7 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
   constexpr int TRI = D * (D + 1) / 2;
   constexpr int A = (D + 1) / 2;
   constexpr bool ODD = (D & 1) != 0;                       // lane 1 has no row in the last pair-row (its row index would be D)
+  static_assert(ODD, "dim = 5 + 2 Ne is odd: lane 1's diagonal elements live in the slots of the last pair-row it does not have");
   const uint32_t lane = threadIdx.x;
   const int h = (int)(lane & 1u);
   const int cl = (int)(lane >> 1);                         // chain within the wavefront
