@@ -289,7 +289,7 @@ def main():
 
     if a.workload == "c4":
         s = HierarchicalBatch(dr, names, C, a.thinning, chain_id_base, dev, torch)
-        kernel_name = "hier_advance_kernel<Ne=3..6>"
+        kernel_name = "hier_advance_kernel<Ne=3,4> + hier_advance2_kernel<Ne=5,6> (one stream each)"
         if a.moments:
             [h.enable_moments(after_iteration=0) for h in s.samplers]
     else:
