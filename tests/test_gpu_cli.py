@@ -156,3 +156,32 @@ print("RCCL_WORLD1_OK")
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("workload", ["c3", "c4"])
+def test_bench_line_keeps_the_contract(workload):
+    """`python bench.py` prints ONE JSON line with the keys the driver reads (metric, value, unit, n_gpus, steps, warmup, ms_per_step,
+    higher_is_better, scaling, vs_baseline, dtype, data, config.workload) plus `roofline` and — at N = 1 — `cpu_baseline`; run small
+    (c3: the single-level queue path; c4: four kernels on four free-running streams) in a fresh process, as the driver does."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", workload,
+           "--chains", "128", "--iters-per-step", "400", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and "workload" in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # whole-job throughput = chains x iterations x steps / time
+    chains = d["config"]["chains_per_gpu"]
+    assert d["value"] == pytest.approx(chains * 400 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)
