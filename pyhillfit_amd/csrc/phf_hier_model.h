@@ -207,9 +207,11 @@ PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl
  *     half 0 takes the first ceil((9+Ne)/2) (always ln alpha and every ln Hill_i), half 1 the rest; each half shares ONE
  *     division among its logarithms, 1/sigma and 1/s;
  *   half 0: + sum_k -(x_k - loc_k)/scale_k   (linear part of the Gamma priors)
- *           - 2 sum_i ln(1 + (Hill_i/alpha)^beta)                            (log-logistic, :134-142)
- *   half 1: + sum_i -(pIC50_i - mu)/s  - 2 sum_i ln(1 + exp(-(pIC50_i - mu)/s))   (logistic, :144-154)
- *   both:   - [ SSE_h / (2 sigma^2) + sum over the half's points of ln(Phi((100-p)/sigma) - Phi((0-p)/sigma)) ]   (:113-132)
+ *           - 2 ln prod_i (1 + (Hill_i/alpha)^beta)                          (log-logistic, :134-142: the sum of Ne logarithms as one)
+ *   half 1: + sum_i -(pIC50_i - mu)/s  - 2 ln prod_i (1 + exp(-(pIC50_i - mu)/s))  (logistic, :144-154; either product term by
+ *           term if it is not below 2^1000)
+ *   both:   - [ SSE_h / (2 sigma^2) + ln prod over the half's points of (Phi((100-p)/sigma) - Phi((0-p)/sigma)) ]   (:113-132; an upper
+ *           tail beyond PHF_TAIL_CUT counts as zero; a product that underflows makes the half -inf)
  *     where experiment i's n points are split  first 2*floor((n+2)/4) -> half 0, the others -> half 1  (4 points: 2 + 2).
  *
  * `h` is a literal at the call site (twin, one-lane kernels: the selects below fold away) or the lane's parity (two-lane
