@@ -14,6 +14,10 @@
  *     host thread/process per GPU may call it concurrently.
  *   - all arithmetic is IEEE fp64.  Chain-major arrays are struct-of-arrays with the chain index fastest
  *     ("[f][chain]"), so that the 64 lanes of a wavefront touch 512 contiguous bytes.
+ *   - MEMORY KIND: state, rows, moments, sums and the queue workspace must be ordinary coarse-grained device memory
+ *     (hipMalloc / torch.empty(device="cuda")).  The hierarchical kernels accumulate moments with hardware fp64 atomics
+ *     (global_atomic_add_f64 without return) and the queued launch hands blocks over with agent-scope release/acquire: on
+ *     fine-grained, managed or host-pinned memory neither is guaranteed to take effect.
  */
 #ifndef PYHILLFIT_AMD_H
 #define PYHILLFIT_AMD_H
@@ -24,13 +28,14 @@
 extern "C" {
 #endif
 
-#define PHF_ABI_VERSION 3
+#define PHF_ABI_VERSION 4
 
 enum {
   PHF_OK = 0,
   PHF_ERR_INVALID_ARGUMENT = -1,
   PHF_ERR_HIP = -2,
-  PHF_ERR_UNSUPPORTED = -3
+  PHF_ERR_UNSUPPORTED = -3,
+  PHF_ERR_DRAINED = -4        /* a queued launch gave up waiting and drained (phf_single_level_queue_status): results are stale */
 };
 
 /* Dose-response data of P (drug, channel) pairs for the single-level (non-hierarchical) models.
@@ -91,6 +96,11 @@ typedef struct phf_mh_config {
 int phf_version(void);
 const char* phf_last_error(void);
 
+/* SIMDs of the current HIP device (4 per compute unit on CDNA: 1 024 on an MI355X in SPX mode, fewer on a partitioned one), looked up
+ * once per device (ABI 4).  The launchers below decide with it which register build a launch gets (one wavefront per SIMD: the whole
+ * register file) and whether a queued launch can pay; exported so that a host never has to hard-code the chip. */
+int phf_simd_count(void);
+
 /* doubles of per-chain state for the single-level sampler: theta[d], log-target, mean[d], cov[d(d+1)/2]
  * (packed lower triangle, row-major), loga, accepted-count, untempered log-likelihood of the current state
  * ->  2d + d(d+1)/2 + 4.                                                                                     */
@@ -125,11 +135,22 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
  * Results are identical to phf_single_level_advance (same chains, rows, state, moments); what changes is the tail of a launch
  * whose problems differ in cost (the reference's unit of work, one pair, varies 2.5x in cost over the Crumb set; its process pool
  * balances that dynamically too, python/PyHillFit.py:997-1003).  Falls back to the plain launch when queueing cannot pay
- * (fewer blocks than the chip holds, or fewer than two quanta).
- *   queue   device int32 [1 + Q * ceil(C/64)] workspace owned by the caller; zeroed here, on the stream, before the launch */
+ * (fewer blocks than the chip's 2 x phf_simd_count() wavefront slots, more than 16 rounds of them — the tail is then negligible —,
+ * or fewer than two quanta).
+ *   queue   device int32 [2 + Q * ceil(C/64)] workspace owned by the caller, zeroed by the caller when it is allocated.  Words
+ *           0 .. Q*ceil(C/64) (task counter, per-block progress) are zeroed here, on the stream, before every launch; the LAST word
+ *           is a sticky fault flag (ABI 4) the library only ever sets: a wavefront whose wait for a predecessor quantum does not
+ *           end (cannot happen in a correct run) sets it, poisons the counter so that the launch drains, and returns WITHOUT
+ *           advancing its block — the call has long returned PHF_OK by then, so check phf_single_level_queue_status() wherever the
+ *           host synchronises anyway. */
 int phf_single_level_advance_queued(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg,
                                     int64_t t_begin, int64_t t_end, double* state, double* rows, double* moments,
                                     int64_t moments_after, int32_t quantum, int32_t* queue, void* stream);
+
+/* Synchronise `stream` and read the sticky fault flag of a queue workspace (ABI 4): PHF_OK, or PHF_ERR_DRAINED if any queued launch
+ * on it drained — states, rows and moments written since the flag was last zero are then stale and must be discarded.
+ *   num_blocks = Q * ceil(C/64), as for the launches that used the workspace. */
+int phf_single_level_queue_status(const int32_t* queue, int64_t num_blocks, void* stream);
 
 /* Batch evaluation of the single-level log-likelihood and log-prior at M parameter vectors.
  * Replaces calls of dr.log_data_likelihood / dr.log_priors / dr.log_target
@@ -147,8 +168,8 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
  * One call handles problems whose pairs all have the same number of experiments Ne (1 <= Ne <= PHF_HIER_MAX_EXPTS);
  * the host groups the pairs by Ne (Crumb: Ne = 3..6).  Ne <= PHF_HIER_FAST_EXPTS runs kernels compiled per Ne (state in
  * registers, proposal factor in LDS) — one lane per chain, or, for Ne = 3..6 when the launch is small enough to give every
- * wavefront a SIMD of its own, TWO lanes per chain (half the instructions per iteration; same results bit for bit; the
- * environment variable PHF_HIER_LANES=1|2 forces one or the other) —; larger Ne (the reference's synthetic set has Ne = 50,
+ * wavefront a SIMD of its own, TWO lanes per chain (half the instructions per iteration; same results bit for bit;
+ * phf_hierarchical_set_kernel_policy forces one or the other) —; larger Ne (the reference's synthetic set has Ne = 50,
  * dim 105) runs one WAVEFRONT per chain with the whole state in LDS: lanes take an experiment each in the target and a row
  * each in the factor.                                                                                            */
 #define PHF_HIER_MAX_EXPTS 64
@@ -194,6 +215,11 @@ int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* pro
                              const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
                              double* moments, int64_t moments_after, void* stream);
 
+/* Which kernel runs groups with Ne = 3..6 (ABI 4; A/B timing and the bit-identity tests): lanes 1 | 2 = one | two lanes per chain,
+ * wps 1 | 2 = the register build of the two-lane kernel (512 | 256 registers); 0 = decide from the launch size (default).  The
+ * environment variables PHF_HIER_LANES / PHF_HIER_WPS give the process-wide initial values and are read ONCE, at the first use. */
+int phf_hierarchical_set_kernel_policy(int lanes, int wps);
+
 /* log_target_distribution (python/PyHillFit.py:173-193) at M parameter vectors: theta device [dim][M]. */
 int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior* prior, int64_t m,
                                 const int32_t* pair_index, const double* theta, double* out, void* stream);
@@ -202,7 +228,9 @@ int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior
  * host build of pyhillfit_amd/csrc/phf_math.h bit for bit).
  * fn: 0 exp, 1 log, 2 erfcx(y>=0), 3 log_ndtr, 4 ndtr, 5 sqrt, 6 reciprocal, 7 sin(2 pi w/2^32), 8 cos(...)
  * 9 exp_fast, 10 log_fast, 11 log_ndtr_nonpos — the branch-free forms the kernels use
- * (for 7/8 the input doubles hold integer values w in [0, 2^32)).                                           */
+ * (for 7/8 the input doubles hold integer values w in [0, 2^32));
+ * the MH loops' own division / square root without exponent-range handling (phf_math.h; correctly rounded for operands within
+ * 2^-600..2^600): 12 phf_rcp(x), 13 phf_sqrt_pos(x), 14 phf_div(ln 10, x), 15 phf_sqrt_nonneg(x) (0 -> 0), 16 phf_div(x, ln 10). */
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream);
 
 /* The four Philox words of n (counter, key) tuples: in device uint32 [n][6], out device uint32 [n][4]. */

@@ -6,13 +6,13 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpyhillfit_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/pyhillfit_amd.h declares
-EXPORTS = ["phf_version", "phf_last_error", "phf_single_level_state_size", "phf_single_level_init",
-           "phf_single_level_advance", "phf_single_level_advance_queued", "phf_single_level_log_target", "phf_debug_math", "phf_debug_philox",
-           "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance",
-           "phf_hierarchical_log_target", "phf_predictive_scratch_bytes", "phf_predictive_accumulate"]
+EXPORTS = ["phf_version", "phf_last_error", "phf_simd_count", "phf_single_level_state_size", "phf_single_level_init",
+           "phf_single_level_advance", "phf_single_level_advance_queued", "phf_single_level_queue_status", "phf_single_level_log_target",
+           "phf_debug_math", "phf_debug_philox", "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance",
+           "phf_hierarchical_set_kernel_policy", "phf_hierarchical_log_target", "phf_predictive_scratch_bytes", "phf_predictive_accumulate"]
 
 
 class PhfError(RuntimeError):
@@ -65,6 +65,9 @@ def load():
                                              vp, vp, i64, vp]
     lib.phf_single_level_advance_queued.argtypes = [C.POINTER(Points), C.POINTER(Problems), C.POINTER(MhConfig), i64, i64, vp,
                                                     vp, vp, i64, i32, vp, vp]
+    lib.phf_single_level_queue_status.argtypes = [vp, i64, vp]
+    lib.phf_hierarchical_set_kernel_policy.argtypes = [i32, i32]
+    lib.phf_simd_count.restype = C.c_int
     lib.phf_single_level_log_target.argtypes = [C.POINTER(Points), i32, i64, vp, vp, vp, vp, vp, vp]
     lib.phf_debug_math.argtypes = [i32, i64, vp, vp, vp]
     lib.phf_debug_philox.argtypes = [i64, vp, vp, vp]

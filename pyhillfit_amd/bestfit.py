@@ -270,10 +270,15 @@ def _hyper_start(best_fits, locs):
     return alpha_cur, beta_cur, mu_cur, s_cur, sigma_cur
 
 
-def hierarchical_first_iteration_batch(experiments_per_pair, locs, pool_map=None):
+def hierarchical_first_iteration_batch(experiments_per_pair, locs):
     """theta0 = [alpha, beta, mu, s, pIC50_1, Hill_1, ..., sigma] for every pair (PyHillFit.py:243-257,303-336): the
     per-experiment (pIC50, Hill) least-squares fits of ALL pairs run as one batch (700 fits for the Crumb set; they were
-    85 % of the start-point time as one Nelder-Mead each), the two small distribution fits per pair stay scalar."""
+    85 % of the start-point time as one Nelder-Mead each), and so do the two distribution fits per pair
+    (_hyper_start_batch; the scalar _hyper_start is their cross-check in the tests)."""
+    for k, exs in enumerate(experiments_per_pair):
+        if len(exs) == 0 or any(len(ex) == 0 for ex in exs):
+            # sqrt(SS / 0) would hand the chain a NaN start sigma without a word
+            raise ValueError("pair %d: %s" % (k, "no experiments" if len(exs) == 0 else "an experiment without points"))
     flat = [(ex[:, 0], ex[:, 1]) for exs in experiments_per_pair for ex in exs]
     p, hill, ss, n = _least_squares_batch(flat, 2, -2.0)           # pic50_hill_priors_lowers = (-2, 0), PyHillFit.py:218,253
     tables, k = [], 0

@@ -6,7 +6,7 @@ char* phf_error_buffer() {
   return buf;
 }
 
-long long phf_simd_count() {
+extern "C" int phf_simd_count(void) {
   static int cached[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 1024; }

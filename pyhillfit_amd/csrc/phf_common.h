@@ -24,7 +24,6 @@ inline int phf_check_launch(const char* what) {
   return PHF_ERR_HIP;
 }
 
-// SIMDs of the current device (4 per compute unit on CDNA: 1 024 on MI355X), looked up once per device; defined in phf_capi.hip
-long long phf_simd_count();
+// phf_simd_count() (public header): SIMDs of the current device, looked up once per device; defined in phf_capi.hip
 
 #endif  // PHF_COMMON_H

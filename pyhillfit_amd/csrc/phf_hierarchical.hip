@@ -826,26 +826,31 @@ int current_device() {
 //   - bigger launches run the one-lane kernel: a lone wavefront already issues an instruction every ~2.2 ns, the rate at which
 //     the fp64 pipe retires them, so two wavefronts per SIMD gain nothing and the two-lane split costs ~18 % more vector
 //     instructions per chain (rotations and draws computed twice, cross-lane moves).
-// PHF_HIER_LANES=1|2 in the environment forces one, PHF_HIER_WPS=1|2 the register build of the two-lane kernel (read at every
-// launch: the bit-identity test switches them between launches).
+// phf_hierarchical_set_kernel_policy(lanes, wps) forces one / the register build of the two-lane kernel (tests, A/B timing); the
+// environment variables PHF_HIER_LANES / PHF_HIER_WPS = 1|2 give the initial values and are read once per process.
 constexpr int kMinNe2 = 3, kMaxNe2 = 6;                           // the two-lane kernel is compiled for the Crumb set's Ne = 3..6
 
 int env_1_or_2(const char* name) {
   const char* e = getenv(name);
   return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
 }
-int hier_lanes_override() { return env_1_or_2("PHF_HIER_LANES"); }
-int hier_wps_override() { return env_1_or_2("PHF_HIER_WPS"); }   // which build of the two-lane kernel (tests, A/B timing)
+struct HierPolicy { int lanes, wps; };
+HierPolicy& hier_policy() {                                       // first use reads the environment; later changes through the ABI only
+  static HierPolicy p{env_1_or_2("PHF_HIER_LANES"), env_1_or_2("PHF_HIER_WPS")};
+  return p;
+}
+int hier_lanes_override() { return hier_policy().lanes; }
+int hier_wps_override() { return hier_policy().wps; }
 
 template <typename K>
-void allow_big_lds(K kernel, bool* configured) {                  // the attribute is per function AND per device
+int allow_big_lds(K kernel, bool* configured) {                   // the attribute is per function AND per device
   const int dev = current_device();
   if (!configured[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      (void)hipGetLastError();
-    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return phf_check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) for a hierarchical kernel");
     configured[dev] = true;
   }
+  return PHF_OK;
 }
 
 template <int NE>
@@ -854,7 +859,7 @@ int launch_advance1(const HierArgs& a, hipStream_t stream) {
   if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
   const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
   static bool configured[kMaxDevices] = {};
-  allow_big_lds(&hier_advance_kernel<NE>, configured);
+  if (int rc = allow_big_lds(&hier_advance_kernel<NE>, configured)) return rc;
   hipLaunchKernelGGL((hier_advance_kernel<NE>), grid, block, lds, stream, a);
   return phf_check_launch("phf_hierarchical_advance");
 }
@@ -862,7 +867,7 @@ int launch_advance1(const HierArgs& a, hipStream_t stream) {
 template <int NE, int WPS>
 int launch_advance2_wps(const HierArgs& a, size_t lds, hipStream_t stream) {
   static bool configured[kMaxDevices] = {};
-  allow_big_lds(&hier_advance2_kernel<NE, WPS>, configured);
+  if (int rc = allow_big_lds(&hier_advance2_kernel<NE, WPS>, configured)) return rc;
   const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
   hipLaunchKernelGGL((hier_advance2_kernel<NE, WPS>), grid, block, lds, stream, a);
   return phf_check_launch("phf_hierarchical_advance (two lanes per chain)");
@@ -918,14 +923,7 @@ int launch_wave_advance(const HierArgs& a, hipStream_t stream, bool* launched) {
   const int64_t blocks = (int64_t)a.prob.num_problems * a.prob.chains_per_problem;
   if (blocks > 0x7fffffffLL) return PHF_OK;
   static bool configured[kMaxDevices] = {};
-  const int dev = current_device();
-  if (!configured[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hier_wave_advance_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    configured[dev] = true;
-  }
+  if (int rc = allow_big_lds(&hier_wave_advance_kernel, configured)) return rc;
   hipLaunchKernelGGL(hier_wave_advance_kernel, dim3((unsigned)blocks), dim3(kBlock), w.bytes(), stream, a);
   *launched = true;
   return phf_check_launch("phf_hierarchical_advance (wave per chain)");
@@ -969,6 +967,12 @@ int phf_hierarchical_state_size(int n_expts) {
   if (n_expts < 1 || n_expts > PHF_HIER_MAX_EXPTS) return phf_fail(PHF_ERR_UNSUPPORTED, "hierarchical sampler supports 1..64 experiments per pair");
   const int d = 5 + 2 * n_expts;
   return 2 * d + d * (d + 1) / 2 + 3;
+}
+
+int phf_hierarchical_set_kernel_policy(int lanes, int wps) {
+  if (lanes < 0 || lanes > 2 || wps < 0 || wps > 2) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "kernel policy: lanes and wps must be 0 (automatic), 1 or 2");
+  hier_policy() = HierPolicy{lanes, wps};
+  return PHF_OK;
 }
 
 int phf_hierarchical_init(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,

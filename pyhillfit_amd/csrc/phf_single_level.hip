@@ -19,6 +19,8 @@
 namespace {
 
 constexpr int kBlock = 64;
+constexpr int kQueuePoison = 0x40000000;     // task counter value that makes every wavefront of a queued launch leave
+constexpr int kQueueMaxRounds = 16;          // beyond this many rounds of the chip's wavefront slots the tail of a launch is negligible
 
 template <int MODEL> struct Dim { static constexpr int d = (MODEL == 1) ? 2 : 3; };
 
@@ -304,8 +306,17 @@ __global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceAr
         int polls = 0;
         while (__hip_atomic_load(a.queue + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
           __builtin_amdgcn_s_sleep(16);
-          if (++polls > (1 << 24)) {                             // cannot happen in a correct run: drain instead of hanging
-            if (threadIdx.x == 0) __hip_atomic_store(a.queue, 0x40000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // cannot happen in a correct run: give up after ~2^24 sleeps — or as soon as another wavefront has — and DRAIN instead of
+          // hanging: poison the task counter, raise the sticky fault word (never cleared by the library; the host reads it through
+          // phf_single_level_queue_status) and leave WITHOUT advancing this block
+          ++polls;
+          const bool gave_up = polls > (1 << 24) ||
+                               ((polls & 1023) == 0 && __hip_atomic_load(a.queue + 1 + nblocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+          if (gave_up) {
+            if (threadIdx.x == 0) {
+              __hip_atomic_store(a.queue + 1 + nblocks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(a.queue, kQueuePoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return;
           }
         }
@@ -316,10 +327,11 @@ __global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceAr
     }
     run_block<MODEL, MOMENTS, WPS>(a, s_pts, b, t0, t1);
     if (!queued) break;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // this block's state (and rows) are in HBM ...
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // every lane: its part of this block's state (and rows) is in HBM ...
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                             // ... all lanes' parts (a barrier, so the hand-over does not lean on the
+                                                                 // block being ONE lock-step wavefront), and s_pts is free to be restaged ...
     if (threadIdx.x == 0) __hip_atomic_store(a.queue + 1 + b, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the word that says so
-    __syncthreads();                                             // s_pts is restaged by the next task
   }
 }
 
@@ -498,7 +510,7 @@ static int advance_impl(const phf_points* pts, const phf_problems* prob, const p
     const int64_t slots = 2 * phf_simd_count();
     const int64_t nquanta = (t_end - t_begin + quantum - 1) / quantum;
     if (nquanta * nblocks > 0x3fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many tasks for one queued launch");
-    if (!lone && nquanta >= 2 && nblocks > slots) {
+    if (!lone && nquanta >= 2 && nblocks > slots && nblocks <= kQueueMaxRounds * slots) {
       if (hipMemsetAsync(queue, 0, (size_t)(1 + nblocks) * sizeof(int32_t), s) != hipSuccess) return phf_check_launch("phf_single_level_advance_queued (memset)");
       a.queue = queue; a.quantum = quantum;
       grid_blocks = slots;
@@ -528,6 +540,18 @@ int phf_single_level_advance_queued(const phf_points* pts, const phf_problems* p
                                     int64_t moments_after, int32_t quantum, int32_t* queue, void* stream) {
   if (quantum <= 0 || !queue) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "queued advance needs a positive quantum and a queue workspace");
   return advance_impl(pts, prob, cfg, t_begin, t_end, state, rows, moments, moments_after, quantum, queue, stream);
+}
+
+int phf_single_level_queue_status(const int32_t* queue, int64_t num_blocks, void* stream) {
+  if (!queue || num_blocks <= 0) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_single_level_queue_status");
+  int32_t fault = 0;
+  if (hipMemcpyAsync(&fault, queue + 1 + num_blocks, sizeof(fault), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return phf_check_launch("phf_single_level_queue_status");
+  if (fault != 0)
+    return phf_fail(PHF_ERR_DRAINED, "a queued single-level launch drained (a wavefront's wait for its block's previous quantum did not end): "
+                                     "states, rows and moments written since are stale");
+  return PHF_OK;
 }
 
 int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, const int32_t* pair_index,

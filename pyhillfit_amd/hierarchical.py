@@ -101,6 +101,14 @@ def _bind(lib):
     lib._phf_hier_bound = True
 
 
+def set_kernel_policy(lanes=0, wps=0):
+    """Which kernel runs Ne = 3..6 groups (phf_hierarchical_set_kernel_policy): lanes per chain 1 | 2, register build of the two-lane
+    kernel 1 | 2 (wavefronts per SIMD), 0 = decided from the launch size.  Every choice gives the same numbers bit for bit; used by
+    the bit-identity tests and for A/B timing.  (PHF_HIER_LANES / PHF_HIER_WPS in the environment set the process's initial values.)"""
+    lib = _lib.load(); _bind(lib)
+    _lib.check(lib.phf_hierarchical_set_kernel_policy(int(lanes), int(wps)), "phf_hierarchical_set_kernel_policy")
+
+
 def log_target_batch(packed, pair_index, theta, prior=None, device="cuda"):
     """log_target_distribution (PyHillFit.py:173-193) of M parameter vectors theta[M][dim] on the GPU."""
     lib = _lib.load(); _bind(lib)
@@ -256,7 +264,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     # all start points first, in one sweep over the worker pool (the file-writer processes start after it)
     # (the least-squares fits of every experiment of every pair as ONE batch in this process, the two small distribution fits
     # per pair over the pool)
-    fits = bestfit.hierarchical_first_iteration_batch([m[2] for _, members in ordered for m in members], locs, pool_map=writers.map)
+    fits = bestfit.hierarchical_first_iteration_batch([m[2] for _, members in ordered for m in members], locs)
     for ne, members in ordered:
         packed = PackedHierPoints([m[2] for m in members])
         theta0 = np.array(fits[:len(members)]); fits = fits[len(members):]

@@ -69,6 +69,13 @@ def log_target_batch(packed, model, pair_index, temperature, theta, device="cuda
     return lik.cpu().numpy(), pri.cpu().numpy()
 
 
+def raise_if_drained(queue):
+    """queue: the int32 workspace of phf_single_level_advance_queued ([2 + blocks], last word = sticky fault flag) or None"""
+    if queue is not None and int(queue[-1].item()) != 0:
+        raise _lib.PhfError("a queued single-level launch drained (a wavefront's wait for its block's previous quantum did not end): "
+                            "chains, moments and state written since are stale — discard them")
+
+
 class SingleLevelSampler(object):
     """Q problems x C chains of the adaptive-Metropolis sampler, advanced in lock-step on one GPU.
 
@@ -118,6 +125,7 @@ class SingleLevelSampler(object):
         # 0 = always the plain launch.  The workspace is one int per block + 1.
         self.queue_quanta = int(queue_quanta)
         self._queue = None
+        self.nblocks = self.Q * ((self.C + 63) // 64)
         self.S = self.lib.phf_single_level_state_size(self.model)
         self.state = torch.zeros((self.S, self.Q * self.C), dtype=torch.float64, device=dev)
         self.moments = None
@@ -177,14 +185,14 @@ class SingleLevelSampler(object):
                     raise ValueError("out must be contiguous with shape %s" % (shape,))
                 rows = out
         n = int(n_iterations)
-        nblocks = self.Q * ((self.C + 63) // 64)
-        # (beyond ~16 rounds the tail of a launch is negligible anyway: the 107 520-block ladder launch gains nothing)
-        if self.queue_quanta > 1 and n >= 100 * self.queue_quanta and 2048 < nblocks <= 32768:
-            # quanta of a whole number of thinning periods, at least 100 iterations each (the state goes through HBM between them)
+        if self.queue_quanta > 1 and n >= 100 * self.queue_quanta:
+            # quanta of a whole number of thinning periods, at least 100 iterations each (the state goes through HBM between them).
+            # Whether the launch really runs as a queue is the library's decision (it knows the chip: phf_simd_count()): only launches
+            # of 1..16 rounds of the chip's wavefront slots do, anything else falls back to the plain launch there.
             quantum = -(-n // self.queue_quanta)
             quantum = max(100, -(-quantum // self.thinning) * self.thinning)
             if self._queue is None:
-                self._queue = torch.zeros(1 + nblocks, dtype=torch.int32, device=self.device)
+                self._queue = torch.zeros(2 + self.nblocks, dtype=torch.int32, device=self.device)   # last word: sticky fault flag
             _lib.check(self.lib.phf_single_level_advance_queued(C.byref(self.points.struct), C.byref(self.prob), C.byref(cfg),
                                                                 self.t, t_end, _ptr(self.state), _ptr(rows), _ptr(self.moments),
                                                                 self.moments_after, quantum, _ptr(self._queue), _stream_ptr(self.device)),
@@ -196,6 +204,13 @@ class SingleLevelSampler(object):
                        "phf_single_level_advance")
         self.t = t_end
         return rows
+
+    def check_queue(self):
+        """A queued launch whose wavefronts gave up waiting for each other drains and leaves stale chains behind a PHF_OK (the
+        launch is asynchronous).  Called wherever the host synchronises anyway — state_dict, posterior_moments,
+        mean_log_likelihood_t1, acceptance, the end of run() — it reads the workspace's sticky fault word (a stream-ordered
+        device-to-host copy, like phf_single_level_queue_status) and raises PhfError instead of handing such results on."""
+        raise_if_drained(self._queue)
 
     def run(self, iterations, segment=None):
         """Whole chain like the reference keeps it: [iterations/thinning + 1][Q][d+1][C], row 0 = start point."""
@@ -213,6 +228,7 @@ class SingleLevelSampler(object):
             nr = self.rows_between(self.t, self.t + k)
             self.advance(k, out=chain[r:r + nr])
             done += k; r += nr
+        self.check_queue()
         return chain
 
     # -- views of the state ---------------------------------------------------------------------------------
@@ -227,12 +243,14 @@ class SingleLevelSampler(object):
 
     def acceptance(self):
         """running acceptance rate (PyHillFit.py:839) per chain"""
+        self.check_queue()
         return self.state[2 * self.d + 2 + self.d * (self.d + 1) // 2].view(self.Q, self.C) / max(self.t, 1)
 
     def posterior_moments(self):
         """(mean, variance, n) per chain from the on-device accumulators: [d+1][Q][C]"""
         if self.moments is None:
             raise _lib.PhfError("enable_moments() was not called")
+        self.check_queue()
         n = self.t // self.thinning - self.moments_after // self.thinning
         k = self.d + 1
         s1 = self.moments[:k].view(k, self.Q, self.C); s2 = self.moments[k:2 * k].view(k, self.Q, self.C)
@@ -245,11 +263,13 @@ class SingleLevelSampler(object):
         compute_log_py_approxn of python/compute_bayes_factors.py:11-27, accumulated inside the sampler kernel"""
         if self.moments is None:
             raise _lib.PhfError("enable_moments() was not called")
+        self.check_queue()
         n = self.t // self.thinning - self.moments_after // self.thinning
         return self.moments[2 * (self.d + 1)].view(self.Q, self.C) / n
 
     def state_dict(self):
         """checkpoint: everything needed to continue bit-identically"""
+        self.check_queue()
         return {"state": self.state.clone(), "t": self.t, "moments": None if self.moments is None else self.moments.clone(),
                 "moments_after": self.moments_after, "seed": self.seed}
 

@@ -1,0 +1,128 @@
+"""G10: long-run posteriors of the reference's own HIERARCHICAL sampler — every column of the chain.
+
+The hierarchical Metropolis loop of the reference (python/PyHillFit.py:431-511, target :173-193) is inlined in
+run_hierarchical; golden G9 lifts its statements for a few thousand iterations to pin the state machine draw by draw.  Here
+the same lifted statements run at the reference's own length (500 000 iterations, thinning 5, the first quarter of the saved
+rows dropped as its readers do, construct_hierarchical_cdfs.py:84-86) with the plain numpy generator, several seeds per
+pair (the reference does not seed this loop: `seed = 1` at :225 is never used), on one pair of every Ne in the Crumb set plus
+two weakly informative pairs.  Stored per seed and pooled: mean, sd and batch-means standard error of ALL dim+1 columns
+(alpha, beta, mu, s, pIC50_i, Hill_i, sigma, log-target) — the pin for "the distribution the kernel samples", which the
+reference's stored chaste/samples (500 draws of (alpha, mu)) could only give for two marginals.
+
+The start point is the one the product's command line would use (pyhillfit_amd.bestfit, host numpy) and is stored in the
+fixture so that the GPU test starts its chains at the same place.
+
+TEST INFRASTRUCTURE, generator side only (needs /root/reference; 18 runs of 3-6 minutes spread over worker processes).
+    python tests/golden/make_golden_posteriors_hier.py [--iterations 500000] [--seeds 3] [--workers 7]
+"""
+import argparse
+import contextlib
+import io
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+import numpy.random as npr
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+PAIRS = [("Amiodarone", "hERG"),          # Ne = 3: 4+4+4 points, informative
+         ("Amiodarone", "Kv4.3"),         # Ne = 4: 4+4+4+3
+         ("Dofetilide", "hERG"),          # Ne = 5: 5+5+4+2+2
+         ("Amitriptyline", "Kv4.3"),      # Ne = 6: 4+4+4+4+2+1 (one response out of range)
+         ("Sertindole", "Kir2.1"),        # Ne = 3, weakly informative: 11 of 12 responses are exactly 0
+         ("Cibenzoline", "Kv4.3")]        # Ne = 6, weakly informative: 4+4+4+1+1+1, 10 of 15 zero
+
+NB = 25                                   # batches for the batch-means standard error
+
+
+class Args(object):
+    pass
+
+
+def _run(job):
+    import _ref_loader as R
+    import make_golden as G
+    import scipy.stats as st
+    d, c, seed, iterations, thinning, first_iteration = job
+    dr = R.load_doseresponse()
+    dr.setup(os.path.join(G.REF_DATA, "crumb_data.csv"))
+    pair = G.concat_pair(dr, d, c)
+    shapes, scales, locs, _ = G.elkins_prior_params()
+    glb = {"np": np, "sys": sys, "st": st, "pic50_prior": [-2.], "dr": dr}
+    R.lift_functions("PyHillFit.py", ["log_data_likelihood", "log_hill_i_log_logistic_likelihood", "log_pic50_i_logistic_likelihood",
+                                      "log_target_distribution"], glb)
+    args = Args()
+    args.iterations = R.Py2Int(iterations); args.thinning = R.Py2Int(thinning)
+    glb.update({"npr": npr, "time": time, "args": args, "experiments": pair["experiments"], "shapes": shapes, "scales": scales,
+                "locs": locs, "first_iteration": np.array(first_iteration, dtype=float)})
+    npr.seed(seed)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+        lines = R.lift_statements("PyHillFit.py", "run_hierarchical", [
+            (lambda t: t.startswith("first_cov ="), lambda t: t.startswith("while t <= total_iterations")),
+        ], glb)
+    chain = np.array(glb["chain"])
+    keep = chain[int(glb["burn"]):]                       # the first quarter of the saved rows dropped
+    k = keep.shape[0] // NB
+    bm = keep[:NB * k].reshape(NB, k, -1).mean(axis=1)
+    return {"drug": d, "channel": c, "seed": seed, "rows": int(keep.shape[0]), "acceptance": float(glb["acceptance"]),
+            "loga": float(glb["loga"]), "mean": keep.mean(axis=0).tolist(), "sd": keep.std(axis=0, ddof=1).tolist(),
+            "batch_means_se": (bm.std(axis=0, ddof=1) / np.sqrt(NB)).tolist(), "q05": np.quantile(keep, 0.05, axis=0).tolist(),
+            "q50": np.quantile(keep, 0.5, axis=0).tolist(), "q95": np.quantile(keep, 0.95, axis=0).tolist(),
+            "reference_lines": lines, "seconds": round(time.time() - t0, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=500000)
+    ap.add_argument("--thinning", type=int, default=5)
+    ap.add_argument("--seeds", type=int, default=3)
+    ap.add_argument("--workers", type=int, default=7)
+    a = ap.parse_args()
+    import _ref_loader as R
+    import make_golden as G
+    from pyhillfit_amd import bestfit
+    dr = R.load_doseresponse(); dr.setup(os.path.join(G.REF_DATA, "crumb_data.csv"))
+    _, _, locs, _ = G.elkins_prior_params()
+    starts = {}
+    for d, c in PAIRS:
+        pair = G.concat_pair(dr, d, c)
+        starts[(d, c)] = np.asarray(bestfit.hierarchical_first_iteration(pair["experiments"], locs), dtype=float)
+    jobs = [(d, c, 101 + s, a.iterations, a.thinning, starts[(d, c)].tolist()) for s in range(a.seeds) for d, c in PAIRS]
+    jobs.sort(key=lambda j: -len(j[5]))                   # longest (largest Ne) first
+    t0 = time.time()
+    runs = []
+    with mp.get_context("fork").Pool(a.workers) as pool:
+        for r in pool.imap_unordered(_run, jobs):
+            runs.append(r)
+            print("  G10 %-14s %-12s seed %d: acceptance %.3f, %d rows, %.0f s (%.0f s elapsed)"
+                  % (r["drug"], r["channel"], r["seed"], r["acceptance"], r["rows"], r["seconds"], time.time() - t0), flush=True)
+    out = []
+    for d, c in PAIRS:
+        mine = sorted([r for r in runs if (r["drug"], r["channel"]) == (d, c)], key=lambda r: r["seed"])
+        means = np.array([r["mean"] for r in mine]); sds = np.array([r["sd"] for r in mine]); ses = np.array([r["batch_means_se"] for r in mine])
+        n = len(mine)
+        # pooled over the seeds (equal run lengths): the standard error of the pooled mean from the within-run batch means, and —
+        # the honest one when chains mix slowly — from the scatter of the seeds' means themselves
+        pooled = {"mean": means.mean(axis=0).tolist(),
+                  "sd": np.sqrt((sds ** 2).mean(axis=0) + means.var(axis=0)).tolist(),
+                  "se_batch_means": (np.sqrt((ses ** 2).sum(axis=0)) / n).tolist(),
+                  "se_between_seeds": (means.std(axis=0, ddof=1) / np.sqrt(n)).tolist() if n > 1 else None}
+        out.append({"drug": d, "channel": c, "Ne": (len(starts[(d, c)]) - 5) // 2, "dim": len(starts[(d, c)]),
+                    "first_iteration": starts[(d, c)].tolist(), "iterations": a.iterations, "thinning": a.thinning,
+                    "burn": "first quarter of the saved rows", "columns": "alpha, beta, mu, s, (pIC50_i, Hill_i) x Ne, sigma, log-target",
+                    "pooled": pooled, "runs": mine})
+    with open(os.path.join(HERE, "g10_hier_posteriors.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("G10 written: %d pairs x %d seeds in %.0f s" % (len(PAIRS), a.seeds, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""G5d: the reference's own sampler re-run with SEVERAL seeds for the (pair, model, temperature) cases where one 200 000-iteration
+chain is not enough to say what the posterior mean is.
+
+G5c holds ONE reference chain per pair (PyHillTemp.do_mcmc, seed 1).  Five pairs sit at 0.7-1.2x the tolerance "1 % + 4
+batch-means standard errors" against the GPU's 256 pooled chains, in every GPU run the same ones: weakly informative pairs
+whose pIC50 posterior is the prior's exponential tail cut by the data (sd ~ 2-2.7), which a single adaptive chain explores in
+rare long excursions — its batch-means standard error underestimates the error of its mean.  Eight independent reference chains
+per case settle it: stored per seed and pooled (mean of the seeds' means; standard error from the scatter BETWEEN the seeds,
+which needs no mixing assumption).  The prior-only rung (t = 0) of the tempered ladder is included for the same reason: at this
+run length the reference itself averages pIC50 to ~1.9 where the analytic prior mean is 2.
+
+TEST INFRASTRUCTURE, generator side only (needs /root/reference; 48 runs of ~45 s over worker processes).
+    python tests/golden/make_golden_posteriors_reseed.py [--seeds 8] [--workers 4]
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+CASES = [("Ranolazine", "Nav1.5-peak", 2, 1.0), ("Nilotinib", "KvLQT1/mink", 2, 1.0), ("Sertindole", "Cav1.2", 2, 1.0),
+         ("Sotalol", "Kv4.3", 2, 1.0), ("Amitriptyline", "Kir2.1", 2, 1.0),
+         ("Amiodarone", "hERG", 2, 0.0)]                 # prior-only rung: analytic answer known, reached slowly
+
+_dr = None
+
+
+def _worker(job):
+    global _dr
+    import _ref_loader as R
+    import make_golden as G
+    if _dr is None:
+        _dr = R.load_doseresponse()
+        _dr.setup(os.path.join(G.REF_DATA, "crumb_data.csv"))
+    d, c, model, t, seed, iterations = job
+    pair = G.concat_pair(_dr, d, c)
+    t0 = time.time()
+    chain, _ = G.run_do_mcmc(_dr, pair, model, t, iterations, 5, 4, seed, False)
+    nb = 20
+    k = chain.shape[0] // nb
+    bm = chain[:nb * k].reshape(nb, k, -1).mean(axis=1)
+    return {"drug": d, "channel": c, "model": model, "temperature": t, "seed": seed, "rows": int(chain.shape[0]),
+            "mean": chain.mean(axis=0).tolist(), "sd": chain.std(axis=0, ddof=1).tolist(),
+            "batch_means_se": (bm.std(axis=0, ddof=1) / np.sqrt(nb)).tolist(), "seconds": round(time.time() - t0, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=200000)
+    ap.add_argument("--seeds", type=int, default=8)
+    ap.add_argument("--workers", type=int, default=4)
+    a = ap.parse_args()
+    jobs = [(d, c, m, t, seed, a.iterations) for (d, c, m, t) in CASES for seed in range(1, a.seeds + 1)]
+    t0 = time.time()
+    runs = []
+    with mp.get_context("fork").Pool(a.workers) as pool:
+        for r in pool.imap_unordered(_worker, jobs):
+            runs.append(r)
+            print("  G5d %-14s %-12s t=%g seed %d: mean %s (%.0f s elapsed)" % (r["drug"], r["channel"], r["temperature"], r["seed"],
+                                                                               np.round(r["mean"], 3).tolist(), time.time() - t0), flush=True)
+    out = []
+    for d, c, m, t in CASES:
+        mine = sorted([r for r in runs if (r["drug"], r["channel"], r["model"], r["temperature"]) == (d, c, m, t)], key=lambda r: r["seed"])
+        means = np.array([r["mean"] for r in mine]); sds = np.array([r["sd"] for r in mine])
+        n = len(mine)
+        out.append({"drug": d, "channel": c, "model": m, "temperature": t, "iterations": a.iterations, "thinning": 5, "burn_in_fraction": 4,
+                    "seeds": [r["seed"] for r in mine], "mean": means.mean(axis=0).tolist(),
+                    "sd": np.sqrt((sds ** 2).mean(axis=0) + means.var(axis=0)).tolist(),
+                    "se_between_seeds": (means.std(axis=0, ddof=1) / np.sqrt(n)).tolist(),
+                    "se_single_chain_batch_means": np.array([r["batch_means_se"] for r in mine]).mean(axis=0).tolist(),
+                    "runs": mine})
+    with open(os.path.join(HERE, "g5d_posteriors_reseeded.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("G5d written: %d cases x %d seeds in %.0f s" % (len(CASES), a.seeds, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

@@ -33,7 +33,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_state_sizes(lib):
-    assert lib.phf_version() == 3
+    assert lib.phf_version() == 4
+    assert lib.phf_simd_count() >= 4                      # without a GPU: the MI355X figure (1 024)
     assert lib.phf_single_level_state_size(1) == 11      # 2+1+2+3+1+1+1
     assert lib.phf_single_level_state_size(2) == 16      # 3+1+3+6+1+1+1
     assert lib.phf_single_level_state_size(3) < 0
@@ -62,6 +63,22 @@ def test_argument_validation_without_gpu(lib):
     assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -3
     with pytest.raises(_lib.PhfError):
         _lib.check(-1, "x")
+    assert lib.phf_single_level_queue_status(None, 10, None) == -1 and lib.phf_single_level_queue_status(1, 0, None) == -1
+    assert lib.phf_hierarchical_set_kernel_policy(3, 0) == -1 and lib.phf_hierarchical_set_kernel_policy(0, -1) == -1
+    assert lib.phf_hierarchical_set_kernel_policy(2, 1) == 0 and lib.phf_hierarchical_set_kernel_policy(0, 0) == 0
+
+
+def test_drained_queue_raises_on_the_host():
+    """sampler.raise_if_drained reads the workspace's last word: what SingleLevelSampler calls at its synchronisation points"""
+    import torch
+    from pyhillfit_amd import _lib
+    from pyhillfit_amd.sampler import raise_if_drained
+    q = torch.zeros(2 + 7, dtype=torch.int32)
+    q[0] = 0x40000000                                     # a poisoned task counter alone is history the next launch resets ...
+    raise_if_drained(None); raise_if_drained(q)
+    q[-1] = 1                                             # ... the sticky fault word is what says "stale results"
+    with pytest.raises(_lib.PhfError, match="drained"):
+        raise_if_drained(q)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

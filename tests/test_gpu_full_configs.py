@@ -128,12 +128,38 @@ def test_queued_launch_is_bit_identical_to_the_plain_launch(model, moments, gpu,
         if quanta:
             q_ = s._queue.cpu().numpy()
             nq = -(-2305 // max(100, -(-(-(-2305 // quanta)) // 5) * 5))
-            assert q_[0] >= 3360 * nq and q_[0] < 0x40000000 and np.all(q_[1:] == nq)      # every task pulled, every block through all its quanta
+            assert q_[0] >= 3360 * nq and q_[0] < 0x40000000 and np.all(q_[1:-1] == nq) and q_[-1] == 0   # every task pulled, every block through all its quanta, no fault
         got.append((rows, s.state.clone(), None if s.moments is None else s.moments.clone()))
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
     if moments:
         assert torch.equal(got[0][2], got[1][2])
     assert torch.isfinite(got[1][0]).all()
+
+
+def test_a_drained_queued_launch_is_an_error_not_stale_chains(gpu, dr):
+    """the sticky fault word of the queue workspace (set by a wavefront that gave up waiting, ABI 4) reaches the host as an error at
+    every point that hands results on: the word is written here by hand, as such a launch would leave it"""
+    import ctypes as C
+    from pyhillfit_amd import _lib
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    names = _all_names(dr)
+    packed = dr.pack_single_level(names)
+    Q = len(names)
+    s = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, 1024, thinning=5, seed=41, adapt_start=600, device=gpu, queue_quanta=4)
+    s.init([6.0, 0.8, 8.0])
+    s.enable_moments(after_iteration=0)
+    s.advance(800, save=False)
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
+    assert lib.phf_single_level_queue_status(C.c_void_p(s._queue.data_ptr()), s.nblocks, stream) == 0
+    s.acceptance(); s.posterior_moments(); s.state_dict()                  # a healthy queue: no raise
+    s._queue[-1] = 1
+    assert lib.phf_single_level_queue_status(C.c_void_p(s._queue.data_ptr()), s.nblocks, stream) == -4 and b"drained" in lib.phf_last_error()
+    s.advance(400, save=False)                                             # the library never clears the word ...
+    assert int(s._queue[-1].item()) == 1 and int(s._queue[0].item()) > 0   # ... while it does reset counter and progress words
+    for call in (s.acceptance, s.posterior_moments, s.mean_log_likelihood_t1, s.state_dict, lambda: s.run(100)):
+        with pytest.raises(_lib.PhfError, match="drained"):
+            call()
 
 
 def test_queued_launch_at_the_bench_shape(gpu, dr):
@@ -152,7 +178,7 @@ def test_queued_launch_at_the_bench_shape(gpu, dr):
             s.advance(2000, save=False)
         if quanta:
             q_ = s._queue.cpu().numpy()
-            assert q_[0] >= 13440 * 4 and q_[0] < 0x40000000 and np.all(q_[1:] == 4)
+            assert q_[0] >= 13440 * 4 and q_[0] < 0x40000000 and np.all(q_[1:-1] == 4) and q_[-1] == 0
         got.append((s.state.clone(), s.moments.clone()))
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
     acc = got[1][0][14].view(Q, 4096) / 6000.0                     # accepted count / iterations (state row 2d + 2 + d(d+1)/2)

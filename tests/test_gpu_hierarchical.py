@@ -87,11 +87,11 @@ def test_hier_chains_bit_identical_to_cpu_twin(names, gpu, oracle_pair):
                                    [("Amiodarone", "Nav1.5-peak"), ("Amiodarone", "Kv4.3")],   # Ne = 4: 4+4+4+1 and 4+4+4+3
                                    [("Moxifloxacin", "KvLQT1/mink"), ("Dofetilide", "hERG")],  # Ne = 5: 4 points each (straight-line) and 5+5+4+2+2
                                    [("Amitriptyline", "Kv4.3"), ("Cibenzoline", "Kv4.3")]])    # Ne = 6: 4+4+4+4+2+1 and 4+4+4+1+1+1
-def test_two_lanes_per_chain_kernel_is_bit_identical(names, gpu, oracle_pair, monkeypatch):
+def test_two_lanes_per_chain_kernel_is_bit_identical(names, gpu, oracle_pair):
     """hier_advance2_kernel<Ne, WPS> (two lanes share a chain: rows of the state, Philox blocks and the halves of the target split
     between them, 32 chains per wavefront; WPS 1: 512 registers, every table resident — the build small launches run; WPS 2: 256
     registers, tables and prior through LDS, two wavefronts per SIMD) against hier_advance_kernel<Ne> (one lane per chain) and
-    the twin: same chain, same final state, same moments, bit for bit; PHF_HIER_LANES / PHF_HIER_WPS force kernel and build"""
+    the twin: same chain, same final state, same moments, bit for bit; H.set_kernel_policy forces kernel and build"""
     from oracle import c_oracle as co
     from pyhillfit_amd import hierarchical as H
     from pyhillfit_amd.sampler import gamma_table
@@ -105,16 +105,14 @@ def test_two_lanes_per_chain_kernel_is_bit_identical(names, gpu, oracle_pair, mo
     C, T, thin, adapt = 200, 600, 5, 140              # 200 chains: a ragged last wavefront for both kernels (64 and 32 chains each)
     got = {}
     for wps in ("1", "2", "2/2"):
-        monkeypatch.setenv("PHF_HIER_LANES", wps[0])
-        monkeypatch.setenv("PHF_HIER_WPS", "2" if wps == "2/2" else "1")
+        H.set_kernel_policy(lanes=int(wps[0]), wps=2 if wps == "2/2" else 1)
         s = H.HierarchicalSampler(packed, [0, 1], C, thinning=thin, seed=31337, adapt_start=adapt, problem_ids=[4, 5], chain_id_base=64, device=gpu)
         s.init(theta0, cov_scale=0.01)
         s.enable_moments(after_iteration=adapt)
         chain = np.concatenate([s.advance(k).cpu().numpy() for k in (adapt + 7, T - adapt - 7)])
         mean, var, n = s.posterior_moments()
         got[wps] = (chain, s.state.cpu().numpy().reshape(s.S, 2, C), mean.cpu().numpy())
-    monkeypatch.delenv("PHF_HIER_LANES")
-    monkeypatch.delenv("PHF_HIER_WPS")
+    H.set_kernel_policy(0, 0)
     for other in ("2", "2/2"):
         assert all(np.array_equal(got["1"][i], got[other][i]) for i in range(3)), other
     chain, state, mean = got["2"]

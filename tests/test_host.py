@@ -218,6 +218,10 @@ def test_hierarchical_start_points_batched(dr):
             th_nm, ss_nm = bestfit._fit_pic50_hill(ex[:, 0], ex[:, 1])
             assert bestfit.sum_of_square_diffs([th[4 + 2 * i], th[5 + 2 * i]], ex[:, 0], ex[:, 1]) <= ss_nm + 1e-7 * (1 + ss_nm)
             assert th[4 + 2 * i] >= -2.0 and th[5 + 2 * i] > 0
+    with pytest.raises(ValueError, match="without points"):              # not a NaN start sigma
+        bestfit.hierarchical_first_iteration_batch([exs[0], [exs[1][0], np.zeros((0, 2))]], locs)
+    with pytest.raises(ValueError, match="no experiments"):
+        bestfit.hierarchical_first_iteration_batch([[]], locs)
 
 
 def test_bench_profile_facts_only_apply_to_the_measured_launch_shape():

@@ -24,13 +24,13 @@ for C, I in ((1024, 500), (64, 5000)):
         s.advance(2000, save=False)
         out = []
         for lanes in ("1", "2"):
-            os.environ["PHF_HIER_LANES"] = lanes
+            H.set_kernel_policy(lanes=int(lanes))
             s.advance(I, save=True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(3):
                 s.advance(I, save=True)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
             out.append(dt)
-        del os.environ["PHF_HIER_LANES"]
+        H.set_kernel_policy(0, 0)
         print("chains/pair %4d  Ne=%d pairs=%3d  %d iterations: one lane %.2f ms, two lanes %.2f ms  (x%.2f)  | %.2f / %.2f us per iteration"
               % (C, ne, s.Q, I, out[0] * 1e3, out[1] * 1e3, out[0] / out[1], out[0] / I * 1e6, out[1] / I * 1e6), flush=True)
