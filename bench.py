@@ -14,8 +14,11 @@ torchrun (the driver's way of starting it) RANK / LOCAL_RANK / WORLD_SIZE are re
 shards without a data-path collective (python/PyHillFit.py:978-1003 maps pairs over a process pool):
   weak scaling (default): every rank runs the full workload on its own range of Philox chain ids
                           (rank r owns chains [r C, (r+1) C) of every pair), value = all ranks' iterations / time;
-  --scaling strong:       the pairs of ONE workload are partitioned over the ranks by cost (distributed.shard_problems).
-RCCL is used outside the timed region only: rank 0 reads and packs the data and broadcasts it, the per-problem
+  strong scaling:         the (pair, 64-chain block) units of ONE full-size workload are partitioned over the ranks by cost
+                          (distributed.shard_blocks: 13 440 blocks -> 1 680 per GPU at 8), every chain keeping its Philox stream.
+With N > 1 BOTH are measured in the same run, one timed region each: `value` is the region --scaling names (weak by default),
+`strong_value` (or `weak_value`) the other.  With N = 1 the c3 run also times short regions of c2, c4 and c5 (`other_workloads`).
+RCCL is used outside the timed regions only: rank 0 reads and packs the data and broadcasts it, the per-problem
 acceptance summaries are gathered to rank 0.  Timing: barrier + synchronize on both sides, MAX over ranks.
 Rank 0 prints ONE JSON line."""
 import argparse
@@ -38,7 +41,9 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 64 fp64 FMA lanes x 2 x 2.4 GHz (vecto
 FP64_VALU_MEASURED_TFLOPS = 58.3  # tools/microbench.hip: v_fma_f64 saturates at 2.25 ns per wave-instruction per SIMD
 
 DEFAULT_CHAINS = {"c2": 65536, "c3": 4096, "c4": 1024, "c5": 1024}
-DEFAULT_ITERS = {"c2": 2000, "c3": 2000, "c4": 500, "c5": 500}
+# c3: 8 000 iterations per step = one queued launch of 160 ms (4 quanta of 2 000), so that the driver's 20 timed steps last > 3 s
+DEFAULT_ITERS = {"c2": 2000, "c3": 8000, "c4": 500, "c5": 500}
+OTHER_STEPS = {"c2": (40, 10), "c4": (20, 6), "c5": (8, 4)}      # (timed steps, warm-up steps) of the short regions after the headline
 
 
 def profile_facts(workload, chains, iters, thinning):
@@ -119,13 +124,15 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10, help="untimed steps before the timed ones (the first launches of a process run ~10 %% slow while the clocks settle)")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
-    ap.add_argument("--iters-per-step", type=int, default=None, help="MH iterations per step (default: 2000 c2/c3, 500 c4/c5)")
+    ap.add_argument("--iters-per-step", type=int, default=None, help="MH iterations per step (default: 8000 c3, 2000 c2, 500 c4/c5)")
     ap.add_argument("--chains", type=int, default=None, help="chains per problem (default: 65536 c2, 4096 c3, 1024 c4/c5)")
     ap.add_argument("--thinning", type=int, default=5)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--moments", action="store_true", help="also accumulate posterior moments and <log L> on the device (what the CLIs and the thermodynamic-integration path run)")
     ap.add_argument("--queue-quanta", type=int, default=None, help="quanta per block of the work-queue launch (0: plain launch; default: the sampler's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="N = 1, c3: skip the short c2 / c4 / c5 regions after the headline")
+    ap.add_argument("--single-region", action="store_true", help="N > 1: only the region --scaling names (no second region of the other kind)")
     return ap.parse_args(argv)
 
 
@@ -156,32 +163,50 @@ def spawn_ranks(a):
 
 
 class HierarchicalBatch(object):
-    """c4: one sampler per group of pairs with equal numbers of experiments, one HIP stream each, inside a 'step'."""
+    """c4: one sampler per group of pairs with equal numbers of experiments, one HIP stream each, inside a 'step'.
+    units: None = every pair with chains [chain_id_base, chain_id_base + C); or this rank's (pair, 64-chain block) units
+    (distributed.shard_blocks over all 210 pairs) — each block then is a problem of 64 chains with its own chain offset."""
+    is_hier = True
+    kernel_name = "hier_advance_kernel<Ne=3,4> + hier_advance2_kernel<Ne=5,6> (one stream each)"
 
-    def __init__(self, dr, names, C, thinning, chain_id_base, dev, torch):
+    def __init__(self, dr, names, C, thinning, chain_id_base, dev, torch, units=None):
         from pyhillfit_amd import hierarchical as H
-        self.torch, self.dev, self.C = torch, dev, C
+        self.torch, self.dev = torch, dev
         groups = {}
-        for d_, c_ in names:
+        for p, (d_, c_) in enumerate(names):
             ne, _, ex = dr.load_crumb_data(d_, c_)
-            groups.setdefault(len(ex), []).append(ex)
+            groups.setdefault(len(ex), []).append((p, ex))
         shapes, scales, locs = H.prior_params()
         self.samplers = []
-        for ne, exs in sorted(groups.items(), reverse=True):
-            hs = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(len(exs))), C, thinning=thinning, seed=25,
-                                       chain_id_base=chain_id_base, device=dev)
-            hs.init(np.array([H.first_iteration(e, locs) for e in exs]), cov_scale=0.01)
+        for ne, members in sorted(groups.items(), reverse=True):
+            exs = [ex for _, ex in members]
+            start = np.array([H.first_iteration(e, locs) for e in exs])
+            if units is None:
+                hs = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(len(exs))), C, thinning=thinning, seed=25,
+                                           problem_ids=[p for p, _ in members], chain_id_base=chain_id_base, device=dev)
+                hs.init(start, cov_scale=0.01)
+            else:
+                local = {p: k for k, (p, _) in enumerate(members)}
+                mine = [(local[int(p)], int(b)) for p, b in units if int(p) in local]
+                if not mine:
+                    continue
+                hs = H.HierarchicalSampler(H.PackedHierPoints(exs), [k for k, _ in mine], 64, thinning=thinning, seed=25,
+                                           problem_ids=[members[k][0] for k, _ in mine], chain_offsets=[64 * b for _, b in mine], device=dev)
+                hs.init(start[[k for k, _ in mine]], cov_scale=0.01)
             self.samplers.append(hs)
         self.adapt_start = max(h.adapt_start for h in self.samplers)
-        self.bytes_per_iter = sum(h.Q * C * 8.0 * (h.d + 1) for h in self.samplers) / thinning
-        self.chains = sum(h.Q * C for h in self.samplers)
+        self.bytes_per_iter = sum(h.Q * h.C * 8.0 * (h.d + 1) for h in self.samplers) / thinning
+        self.chains = sum(h.Q * h.C for h in self.samplers)
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.samplers]
+
+    def enable_moments(self):
+        [h.enable_moments(after_iteration=0) for h in self.samplers]
 
     def reserve(self, n):
         [h.reserve(n) for h in self.samplers]
 
     def make_rows(self, I):
-        return [self.torch.empty((h.rows_between(0, I), h.Q, h.d + 1, self.C), dtype=self.torch.float64, device=self.dev)
+        return [self.torch.empty((h.rows_between(0, I), h.Q, h.d + 1, h.C), dtype=self.torch.float64, device=self.dev)
                 for h in self.samplers]
 
     def advance(self, I, out, join=True):
@@ -224,6 +249,173 @@ class HierarchicalBatch(object):
         return self.torch.cat([h.acceptance().mean(dim=1) for h in self.samplers])
 
 
+class SingleLevelBatch(object):
+    """c2 / c3 / c5: one SingleLevelSampler.  units as for HierarchicalBatch (indices into the problem list)."""
+    is_hier = False
+    kernel_name = "mh_advance_kernel<2>"
+
+    def __init__(self, packed, pair_index, temps, C, a, chain_id_base, dev, torch, tempered, units=None):
+        from pyhillfit_amd.sampler import SingleLevelSampler
+        self.torch, self.dev = torch, dev
+        kw = {} if a.queue_quanta is None else {"queue_quanta": a.queue_quanta}
+        if units is None:
+            s = SingleLevelSampler(packed, 2, pair_index, temps, C, thinning=a.thinning, seed=25, chain_id_base=chain_id_base,
+                                   reset_mean_at_adapt_start=tempered, device=dev, **kw)
+        else:
+            s = SingleLevelSampler(packed, 2, [pair_index[q] for q, _ in units], [temps[q] for q, _ in units], 64, thinning=a.thinning,
+                                   seed=25, problem_ids=[int(q) for q, _ in units], chain_offsets=[64 * int(b) for _, b in units],
+                                   reset_mean_at_adapt_start=tempered, device=dev, **kw)
+        if tempered:
+            s.init(np.ones(3), cov_identity=True, cov_scale=1.0)          # PyHillTemp.py:63,80 start
+        else:
+            s.init([6.0, 0.8, 8.0], cov_identity=False, cov_scale=0.05)   # PyHillFit.py:748-751 start
+        self.s = s
+        self.adapt_start = s.adapt_start
+        self.bytes_per_iter = float(s.Q) * s.C * 8 * (s.d + 1) / a.thinning   # SURVEY 8(d): 8(d+1)/thin B per iteration
+        self.chains = s.Q * s.C
+
+    def enable_moments(self):
+        self.s.enable_moments(after_iteration=0)
+
+    def reserve(self, n):
+        self.s.reserve(n)
+
+    def make_rows(self, I):
+        s = self.s
+        return self.torch.empty((s.rows_between(0, I), s.Q, s.d + 1, s.C), dtype=self.torch.float64, device=self.dev)
+
+    def advance(self, I, out, join=True):
+        self.s.advance(I, out=out)
+
+    def acceptance_summary(self):
+        return self.s.acceptance().mean(dim=1)
+
+
+def workload_label(workload, n_pairs, C, per):
+    if workload == "c2":
+        return "Amiodarone-hERG, non-hierarchical model 2 (pIC50, Hill, sigma), %d chains %s (BASELINE configs[1])" % (C, per)
+    if workload == "c3":
+        return "all %d Crumb drug x channel pairs, non-hierarchical model 2, %d chains each %s (BASELINE configs[2])" % (n_pairs, C, per)
+    if workload == "c5":
+        return "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains %s, model 2 (BASELINE configs[4])" % (n_pairs, C, per)
+    return ("hierarchical model, all %d Crumb pairs, %d chains each %s (BASELINE configs[3]); one stream per Ne group, "
+            "not joined between steps" % (n_pairs, C, per))
+
+
+def make_batch(workload, scaling, C, a, ctx):
+    """The batch of one rank.  weak: the full workload on this rank's own range of Philox chain ids.  strong: this rank's share of
+    the (problem, 64-chain block) units of ONE workload (distributed.shard_blocks: LPT on block cost) — or, when the chains per
+    problem are not whole blocks, of its pairs / chains."""
+    dr, D, torch, dev, rank, world = ctx["dr"], ctx["D"], ctx["torch"], ctx["dev"], ctx["rank"], ctx["world"]
+    all_names = [(d, c) for d in dr.drugs for c in dr.channels]
+    names = [("Amiodarone", "hERG")] if workload == "c2" else all_names
+    strong = scaling == "strong" and world > 1
+    chain_id_base = 0 if scaling == "strong" else rank * C
+    if workload == "c4":
+        units = None
+        if strong:
+            if C % 64:
+                raise SystemExit("bench.py: --scaling strong splits a batch by 64-chain blocks: --chains must be a multiple of 64")
+            costs = [len(dr.concatenate_experiments(*dr.load_crumb_data(d_, c_)[::2])[0]) + 20.0 * len(dr.load_crumb_data(d_, c_)[2]) for d_, c_ in names]
+            units = D.shard_blocks(costs, C // 64, world)[rank]
+        b = HierarchicalBatch(dr, names, C, a.thinning, chain_id_base, dev, torch, units=units)
+    else:
+        packed = dr.pack_single_level(names) if rank == 0 or ctx["backend_is_local"] else None
+        packed = D.broadcast_packed_points(packed, dev)               # RCCL: "scatter the dataset", a few tens of KB
+        if workload == "c5":
+            ladder = dr.temperature_ladder(31)                        # 32 rungs (BASELINE configs[4]); reference ladder has 41
+            pair_index = [p for p in range(len(names)) for _ in ladder]
+            temps = [float(t) for _ in names for t in ladder]
+        else:
+            pair_index, temps = list(range(len(names))), [1.0] * len(names)
+        units = None
+        if strong:
+            if C % 64:
+                raise SystemExit("bench.py: --scaling strong splits a batch by 64-chain blocks: --chains must be a multiple of 64")
+            cnt = packed.counts[np.asarray(pair_index)]
+            costs = 525.0 + 28.0 * cnt[:, 0] + 115.0 * (cnt[:, 1] + cnt[:, 2])     # instructions per iteration (sampler.py: launch_order)
+            units = D.shard_blocks(costs, C // 64, world)[rank]
+        b = SingleLevelBatch(packed, pair_index, temps, C, a, chain_id_base, dev, torch, workload == "c5", units=units)
+    b.label = workload_label(workload, len(names), C, "in all, split by 64-chain blocks over the GPUs" if scaling == "strong" else "per GPU")
+    if a.moments:
+        b.enable_moments()
+        b.label += " + on-device moments"
+    return b
+
+
+def timed_region(b, I, steps, warmup, ctx):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; time = MAX over ranks.
+    Returns (seconds, kernel ms per step from HIP events on the launch stream(s), chains of all ranks)."""
+    torch, dist, dev, world = ctx["torch"], ctx["dist"], ctx["dev"], ctx["world"]
+    b.reserve((warmup + steps) * I)
+    rows = b.make_rows(I)
+    for _ in range(warmup):
+        b.advance(I, out=rows)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for b_, e_ in ev:                                # events are created lazily at their first record: not inside the timed region
+        b_.record(); e_.record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    gc.collect(); gc.disable()                      # no collector pause between launches of the timed region
+    t0 = time.perf_counter()
+    if b.is_hier:                                   # four kernels per step on four streams, not joined between steps
+        b.mark("start")
+        for k in range(steps):
+            b.advance(I, out=rows, join=False)
+        b.mark("end")
+        b.join()
+    else:
+        for k in range(steps):
+            ev[k][0].record()
+            b.advance(I, out=rows)
+            ev[k][1].record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    gc.enable()
+    chains_total = float(b.chains)
+    if world > 1:
+        cdev = dev if ctx["backend"] == "nccl" else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ct = torch.tensor([chains_total], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+        chains_total = float(ct.item())
+    if b.is_hier:
+        kernel_ms = b.region_ms() / steps                            # HIP events on the groups' streams: longest stream / steps
+    else:
+        kernel_ms = float(np.mean([x.elapsed_time(y) for x, y in ev]))   # HIP events on the launch stream
+    for r_ in (rows if isinstance(rows, list) else [rows]):
+        assert torch.isfinite(r_[-1]).all() and torch.isfinite(r_[0]).all()
+    return dt, kernel_ms, chains_total
+
+
+def rooflines(workload, b, I, thinning, kernel_ms):
+    alg_bytes = b.bytes_per_iter * I
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    prof = profile_facts(workload, b.chains, I, thinning)
+    flop_per_iter = prof.get("flop_per_iteration")
+    tflops = None if flop_per_iter is None else float(b.chains) * I * flop_per_iter / (kernel_ms * 1e-3) / 1e12
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": prof.get("traffic_bytes_per_launch"), "kernel": b.kernel_name, "kernel_ms": kernel_ms,
+            "traffic_source": prof.get("source"), "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "fp64-VALU-bound scalar-per-chain arithmetic; the HBM fraction is reported as BASELINE asks, the binding roof is fp64_valu"}
+    fp64 = {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": None if tflops is None else tflops / FP64_VALU_PEAK_TFLOPS,
+            "measured_achievable_peak": FP64_VALU_MEASURED_TFLOPS, "flop_per_iteration": flop_per_iter, "flop_source": prof.get("source")}
+    return roof, fp64
+
+
+def release(torch):
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def main():
     a = parse_args()
     if a.gpus < 1:
@@ -254,143 +446,69 @@ def main():
 
     from pyhillfit_amd import distributed as D
     from pyhillfit_amd import doseresponse as dr
-    from pyhillfit_amd.sampler import SingleLevelSampler
     # ONE reader: rank 0 parses the data file, the table reaches the other ranks by broadcast (outside the timed region)
     D.setup_data_file(os.path.join(REPO, "data", "crumb_dataset.json"))
     dr.define_model(2)
-    all_names = [(d, c) for d in dr.drugs for c in dr.channels]
+    ctx = {"dr": dr, "D": D, "torch": torch, "dist": dist, "dev": dev, "rank": rank, "world": world, "backend": backend,
+           "backend_is_local": world == 1}
     C = a.chains or DEFAULT_CHAINS[a.workload]
     I = a.iters_per_step or DEFAULT_ITERS[a.workload]
-    kernel_name = "mh_advance_kernel<2>"
-    per = "per GPU" if a.scaling == "weak" else "in all"
-    if a.workload == "c2":
-        names = [("Amiodarone", "hERG")]
-        label = "Amiodarone-hERG, non-hierarchical model 2 (pIC50, Hill, sigma), %d chains %s (BASELINE configs[1])" % (C, per)
-    elif a.workload == "c3":
-        names = all_names
-        label = "all %d Crumb drug x channel pairs, non-hierarchical model 2, %d chains each %s (BASELINE configs[2])" % (len(names), C, per)
-    elif a.workload == "c5":
-        names = all_names
-        label = "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains %s, model 2 (BASELINE configs[4])" % (len(names), C, per)
-    else:
-        names = all_names
-        label = ("hierarchical model, all %d Crumb pairs, %d chains each %s (BASELINE configs[3]); one stream per Ne group, "
-                 "not joined between steps" % (len(names), C, per))
 
-    # the partition: weak = this rank's own chain-id range of every problem; strong = this rank's share of the pairs
-    chain_id_base = rank * C if a.scaling == "weak" else 0
-    if a.scaling == "strong" and world > 1:
-        if len(names) >= world:
-            costs = [len(dr.concatenate_experiments(*dr.load_crumb_data(d_, c_)[::2])[0]) for d_, c_ in names]
-            mine = D.shard_problems(costs, world)[rank]
-            names = [names[i] for i in mine]
-        else:                                                         # fewer pairs than GPUs (c2): split the chains
-            chain_id_base, C = D.shard_chains(C, rank, world)
-
-    if a.workload == "c4":
-        s = HierarchicalBatch(dr, names, C, a.thinning, chain_id_base, dev, torch)
-        kernel_name = "hier_advance_kernel<Ne=3,4> + hier_advance2_kernel<Ne=5,6> (one stream each)"
-        if a.moments:
-            [h.enable_moments(after_iteration=0) for h in s.samplers]
-    else:
-        packed = dr.pack_single_level(names) if rank == 0 or a.scaling == "strong" else None
-        if a.scaling == "weak":
-            packed = D.broadcast_packed_points(packed, dev)           # RCCL: "scatter the dataset", a few tens of KB
-        if a.workload == "c5":
-            ladder = dr.temperature_ladder(31)                           # 32 rungs (BASELINE configs[4]); reference ladder has 41
-            pair_index = [p for p in range(len(names)) for _ in ladder]
-            temps = [float(t) for _ in names for t in ladder]
-        else:
-            pair_index, temps = list(range(len(names))), [1.0] * len(names)
-        Q = len(pair_index)
-        s = SingleLevelSampler(packed, 2, pair_index, temps, C, thinning=a.thinning, seed=25, chain_id_base=chain_id_base,
-                               reset_mean_at_adapt_start=(a.workload == "c5"), device=dev,
-                               **({} if a.queue_quanta is None else {"queue_quanta": a.queue_quanta}))
-        if a.workload == "c5":
-            s.init(np.ones(3), cov_identity=True, cov_scale=1.0)          # PyHillTemp.py:63,80 start
-        else:
-            s.init([6.0, 0.8, 8.0], cov_identity=False, cov_scale=0.05)   # PyHillFit.py:748-751 start
-        s.bytes_per_iter = float(Q) * C * 8 * (s.d + 1) / a.thinning      # 8(d+1)/thin B per iteration
-        s.chains = Q * C
-        s.make_rows = lambda I: torch.empty((s.rows_between(0, I), Q, s.d + 1, C), dtype=torch.float64, device=dev)
-        s.acceptance_summary = lambda: s.acceptance().mean(dim=1)
-        if a.moments:
-            s.enable_moments(after_iteration=0)
-    s.reserve((a.warmup + a.steps) * I)
-    rows = s.make_rows(I)
-
-    for _ in range(a.warmup):
-        s.advance(I, out=rows)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    for b_, e_ in ev:                                # events are created lazily at their first record: not inside the timed region
-        b_.record(); e_.record()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    gc.collect(); gc.disable()                      # no collector pause between launches of the timed region
-    t0 = time.perf_counter()
-    if a.workload == "c4":                         # four kernels per step on four streams, not joined between steps
-        s.mark("start")
-        for k in range(a.steps):
-            s.advance(I, out=rows, join=False)
-        s.mark("end")
-        s.join()
-    else:
-        for k in range(a.steps):
-            ev[k][0].record()
-            s.advance(I, out=rows)
-            ev[k][1].record()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    gc.enable()
-    chains_total = float(s.chains)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ct = torch.tensor([chains_total], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
-        chains_total = float(ct.item())
-    if a.workload == "c4":
-        kernel_ms = s.region_ms() / a.steps                          # HIP events on the groups' streams: longest stream / steps
-    else:
-        kernel_ms = float(np.mean([b.elapsed_time(e) for b, e in ev]))   # HIP events on the launch stream
-    for r_ in (rows if isinstance(rows, list) else [rows]):
-        assert torch.isfinite(r_).all()
+    # ---- the headline region: the scaling asked for (weak by default) ----
+    b = make_batch(a.workload, a.scaling, C, a, ctx)
+    dt, kernel_ms, chains_total = timed_region(b, I, a.steps, a.warmup, ctx)
     # "gather samples/summaries" (RCCL, outside the timed region): per-problem mean acceptance of every rank to rank 0
-    acc = s.acceptance_summary().reshape(-1, 1)
+    acc = b.acceptance_summary().reshape(-1, 1)
     gathered = D.gather_rows(acc if backend == "nccl" or world == 1 else acc.cpu())
-
+    out = None
     if rank == 0:
         acc_all = np.concatenate(gathered)
-        value = chains_total * I * a.steps / dt
-        alg_bytes = s.bytes_per_iter * I
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        prof = profile_facts(a.workload, s.chains, I, a.thinning)
-        flop_per_iter = prof.get("flop_per_iteration")
-        tflops = None if flop_per_iter is None else float(s.chains) * I * flop_per_iter / (kernel_ms * 1e-3) / 1e12
+        roof, fp64 = rooflines(a.workload, b, I, a.thinning, kernel_ms)
         out = {
-            "metric": "MCMC samples/sec (whole node)", "value": value, "unit": "MH samples/s", "n_gpus": world,
+            "metric": "MCMC samples/sec (whole node)", "value": chains_total * I * a.steps / dt, "unit": "MH samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "real Crumb dose-response rows (data/crumb_dataset.json), synthetic chain batch",
-            "config": {"workload": label + (" + on-device moments" if a.moments else ""), "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": s.chains,
+            "config": {"workload": b.label, "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": b.chains,
                        "chains_all_gpus": chains_total,
-                       "adaptation": "on (steps start after iteration %d > adapt_start %d)" % (a.warmup * I, s.adapt_start),
+                       "adaptation": "on (steps start after iteration %d > adapt_start %d)" % (a.warmup * I, b.adapt_start),
                        "mean_acceptance": float(acc_all.mean()), "problems_reporting": int(acc_all.shape[0])},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": prof.get("traffic_bytes_per_launch"), "kernel": kernel_name, "kernel_ms": kernel_ms,
-                         "traffic_source": prof.get("source"),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "fp64-VALU-bound scalar-per-chain arithmetic; the HBM fraction is reported as BASELINE asks, the binding roof is fp64_valu"},
-            "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": None if tflops is None else tflops / FP64_VALU_PEAK_TFLOPS,
-                          "measured_achievable_peak": FP64_VALU_MEASURED_TFLOPS, "flop_per_iteration": flop_per_iter,
-                          "flop_source": prof.get("source")},
+            "roofline": roof, "fp64_valu": fp64,
         }
+    del b
+    release(torch)
+
+    # ---- N > 1: a second timed region in the same run with the OTHER kind of scaling.  The metric is "the full Crumb set at
+    # 1/2/4/8 GPUs": `value` keeps the per-GPU work fixed (weak), `strong_value` splits ONE full-size batch over the GPUs by
+    # (pair, 64-chain block) units.  (N = 1: the two coincide.) ----
+    if world > 1 and not a.single_region:
+        other = "strong" if a.scaling == "weak" else "weak"
+        b2 = make_batch(a.workload, other, C, a, ctx)
+        dt2, kms2, chains2 = timed_region(b2, I, a.steps, a.warmup, ctx)
+        if rank == 0:
+            out[other + "_value"] = chains2 * I * a.steps / dt2
+            out[other + "_region"] = {"scaling": other, "ms_per_step": dt2 / a.steps * 1e3, "kernel_ms_rank0": kms2, "chains_all_gpus": chains2,
+                                      "chains_rank0": b2.chains, "workload": b2.label}
+        del b2
+        release(torch)
+
+    # ---- N = 1: the other BASELINE configurations, short regions of the same protocol, in the same JSON line ----
+    if world == 1 and a.workload == "c3" and a.chains is None and a.iters_per_step is None and not a.no_other_workloads:
+        others = {}
+        for w in ("c2", "c4", "c5"):
+            Cw, Iw = DEFAULT_CHAINS[w], DEFAULT_ITERS[w]
+            bw = make_batch(w, "weak", Cw, a, ctx)
+            steps_w, warm_w = OTHER_STEPS[w]
+            dtw, kmsw, chw = timed_region(bw, Iw, steps_w, warm_w, ctx)
+            roof, fp64 = rooflines(w, bw, Iw, a.thinning, kmsw)
+            others[w] = {"value": chw * Iw * steps_w / dtw, "unit": "MH samples/s", "ms_per_step": dtw / steps_w * 1e3, "kernel_ms": kmsw,
+                         "steps": steps_w, "warmup": warm_w, "iterations_per_step": Iw, "chains": bw.chains, "workload": bw.label,
+                         "roofline_frac": roof["frac"], "fp64_frac": fp64["frac"], "kernel": bw.kernel_name,
+                         "mean_acceptance": float(bw.acceptance_summary().mean().item())}
+            del bw
+            release(torch)
+        out["other_workloads"] = others
+
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

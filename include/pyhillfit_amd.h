@@ -79,6 +79,10 @@ typedef struct phf_problems {
                                     state); what does is the tail of a launch whose problems differ in cost: pairs have 2..8 entries,
                                     an iteration 550..1 500 instructions, and most expensive first (what the reference's pool gets by
                                     luck or not) took 6.5 % off the full-Crumb-set launch.  NULL = 0, 1, 2, ... */
+  const uint32_t* chain_offset;  /* device [Q] or NULL (ABI 4): global number of problem q's local chain 0 is chain_id_base +
+                                    chain_offset[q].  Lets a launch hold ANY subset of a batch's (problem, 64-chain block) units — a
+                                    rank's share when a batch is split over GPUs by blocks rather than by whole pairs
+                                    (pyhillfit_amd/distributed.py:shard_blocks) — with every chain keeping its Philox stream. */
 } phf_problems;
 
 /* Adaptive-Metropolis schedule: python/PyHillFit.py:787-848 / python/PyHillTemp.py:76-123. */

@@ -12,9 +12,10 @@ pair (burn-in removed exactly like PyHillFit.py:861-864); with --save-all-chains
 device, go to `<...>_summary.json`.  The CMA-ES start point is replaced by a deterministic least-squares fit
 (bestfit.py); figures are not produced (plotting is outside the sampling step).
 
-Multi-GPU: launch with torchrun (one rank per GPU); pairs are partitioned over the ranks, each rank writes the
-files of its pairs, rank 0 broadcasts the packed data set first and gathers the summaries at the end (RCCL).
-`-c/--num-cores` is accepted for command-line compatibility (the reference used it for its process pool)."""
+Multi-GPU: `-c/--num-cores N` — the reference's pool size (python/PyHillFit.py:40,997-1003) — starts min(N, visible GPUs) ranks,
+one per GPU (this process runs `torch.distributed.run` as a child before it touches a GPU and passes the exit code on); or
+launch under torchrun yourself.  Pairs are partitioned over the ranks by cost, each rank writes the files of its pairs, rank 0
+reads the data file and broadcasts it first and gathers the summaries at the end (RCCL)."""
 import argparse
 import itertools as it
 import json
@@ -36,7 +37,7 @@ def build_parser():
     parser.add_argument("-b", "--burn-in-fraction", type=int, help="given N saved MCMC iterations, discard the first N/b as burn-in", default=4)
     parser.add_argument("-a", "--all", action='store_true', help='run MCMC on all drugs and channels', default=False)
     parser.add_argument('-ppp', '--plot-parameter-paths', action='store_true', help='accepted, ignored (no figures)', default=False)
-    parser.add_argument("-c", "--num-cores", type=int, help="accepted for compatibility; GPUs are selected by torchrun ranks", default=1)
+    parser.add_argument("-c", "--num-cores", type=int, help="number of cores to parallelise drug/channel combinations: here GPUs — N > 1 starts min(N, visible GPUs) ranks, one per GPU", default=1)
     parser.add_argument("-Ne", "--num-expts", type=int, help="how many experiments to fit to", default=0)
     parser.add_argument("--num-APs", type=int, help="how many (alpha,mu) samples to take for AP simulations", default=500)
     parser.add_argument("--hierarchical", action='store_true', help="run hierarchical MCMC algorithm", default=False)
@@ -184,6 +185,9 @@ def main(argv=None):
         parser.print_help()
         sys.exit(1)
     args = parser.parse_args(argv)
+    n = phfdist.ranks_for_cores(args.num_cores)                        # -c N: the reference's pool (PyHillFit.py:997-1003) -> N ranks
+    if n:
+        sys.exit(phfdist.spawn_ranks("pyhillfit_amd.PyHillFit", sys.argv[1:] if argv is None else argv, n))
     rank, local_rank, world = phfdist.init()
     try:
         return _run(args, rank, local_rank, world)

@@ -8,7 +8,8 @@ t_i = (i/n)^c, n = 40, c = 3 (:151, doseresponse.py:27-28) through a process poo
 (times --num-chains chains, times all selected pairs) advance in one batch of HIP kernel launches; each rung's
 chain 0 is written, burn-in removed, headerless, to the reference's temperature_<t> chain file (:165-169), where
 python/compute_bayes_factors.py expects it.  Start point ones(d), identity covariance, mean reset at 1000*d
-(:63,80,114-115).  `--rungs N` changes n (BASELINE config 5 uses 32 rungs = --rungs 31)."""
+(:63,80,114-115).  `--rungs N` changes n (BASELINE config 5 uses 32 rungs = --rungs 31).  `-nc N` — the reference's pool size —
+starts min(N, visible GPUs) ranks, one per GPU, which share the (pair, rung) units; or launch under torchrun."""
 import argparse
 import json
 import sys
@@ -28,7 +29,7 @@ def build_parser():
     parser.add_argument("-t", "--thinning", type=int, help="save every t-th iteration", default=5)
     parser.add_argument("-b", "--burn-in-fraction", type=int, help="discard the first N/b saved rows as burn-in", default=4)
     parser.add_argument("-a", "--all", action='store_true', default=False, help="accepted, unused (as in the reference)")
-    parser.add_argument("-nc", "--num-cores", type=int, default=1, help="accepted for compatibility")
+    parser.add_argument("-nc", "--num-cores", type=int, default=1, help="the reference's pool size over the rungs (PyHillTemp.py:25,155-159): here GPUs — N > 1 starts min(N, visible GPUs) ranks that share the (pair, rung) units")
     parser.add_argument("-Ne", "--num_expts", type=int, default=0, help="accepted, unused (as in the reference)")
     parser.add_argument("--num-APs", type=int, default=500, help="accepted, unused")
     parser.add_argument("--single", action='store_true', default=True)
@@ -182,6 +183,9 @@ def main(argv=None):
         parser.print_help()
         sys.exit(1)
     args = parser.parse_args(argv)
+    n = phfdist.ranks_for_cores(args.num_cores)                         # -nc N: the reference's pool over the rungs (:155-159) -> N ranks
+    if n:
+        sys.exit(phfdist.spawn_ranks("pyhillfit_amd.PyHillTemp", sys.argv[1:] if argv is None else argv, n))
     rank, local_rank, world = phfdist.init()
     try:
         device = args.device or "cuda:%d" % local_rank

@@ -73,7 +73,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #define PHF_LSET(e, v) sL[(e) * kBlock] = (v)
   const int C = a.prob.chains_per_problem;
   const uint32_t pid = a.prob.problem_id[q];
-  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
+  const uint32_t cid = a.prob.chain_id_base + (a.prob.chain_offset ? a.prob.chain_offset[q] : 0u) + (uint32_t)c;
   const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
   const size_t nchains = (size_t)a.prob.num_problems * C;
   const size_t g = (size_t)q * C + c;
@@ -277,7 +277,7 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
 #define PHF_HAS_ROW(a_) (!(ODD && (a_) == A - 1) || h == 0)
   const int C = a.prob.chains_per_problem;
   const uint32_t pid = a.prob.problem_id[q];
-  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
+  const uint32_t cid = a.prob.chain_id_base + (a.prob.chain_offset ? a.prob.chain_offset[q] : 0u) + (uint32_t)c;
   const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
   const size_t nchains = (size_t)a.prob.num_problems * C;
   const size_t g = (size_t)q * C + c;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
   const int q = a.prob.launch_order ? a.prob.launch_order[slot] : slot;
   const int pair = a.prob.pair_index[q];
   const uint32_t pid = a.prob.problem_id[q];
-  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
+  const uint32_t cid = a.prob.chain_id_base + (a.prob.chain_offset ? a.prob.chain_offset[q] : 0u) + (uint32_t)c;
   const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
   const size_t nch = (size_t)a.prob.num_problems * C;
   const size_t g = (size_t)q * C + c;

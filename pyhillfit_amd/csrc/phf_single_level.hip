@@ -95,7 +95,7 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   const double n_other_points = a.pts.extra[2 * pair], ss_within = a.pts.extra[2 * pair + 1];
   const double temperature = a.prob.temperature[q];
   const uint32_t pid = a.prob.problem_id[q];
-  const uint32_t cid = a.prob.chain_id_base + (uint32_t)c;
+  const uint32_t cid = a.prob.chain_id_base + (a.prob.chain_offset ? a.prob.chain_offset[q] : 0u) + (uint32_t)c;
   const uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
   const size_t nchains = (size_t)a.prob.num_problems * C;
   const size_t g = (size_t)q * C + c;

@@ -18,6 +18,37 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def ranks_for_cores(num_cores):
+    """How many ranks a command line's `-c/--num-cores N` (PyHillFit.py:40) / `-nc N` (PyHillTemp.py:25) starts: the reference
+    sizes its process pool with that flag (python/PyHillFit.py:997-1003: min(N, cpu_count - 1) workers; PyHillTemp.py:155-159);
+    here a worker is a GPU, so N ranks, at most one per visible GPU.  0 = do not start anything (N <= 1, or this process is
+    already a rank of a torchrun world).  PHF_DIST_BACKEND=gloo lifts the GPU cap (rehearsal / CPU-only steps such as -bfo)."""
+    if int(num_cores) <= 1 or "WORLD_SIZE" in os.environ:
+        return 0
+    if os.environ.get("PHF_DIST_BACKEND") == "gloo":
+        return int(num_cores)
+    import torch
+    n = min(int(num_cores), torch.cuda.device_count())     # counting devices does not initialise the GPU
+    return n if n > 1 else 0
+
+
+def spawn_ranks(module, argv, n):
+    """Start `python -m torch.distributed.run --nproc-per-node n -m <module> <argv>` as a CHILD process — this process has made no
+    GPU call yet, and it is a child, never an exec — and return its exit code (as bench.py --gpus N does)."""
+    import socket
+    import subprocess
+    import sys
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", module] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    return subprocess.call(cmd, env=env)
+
+
 def init(backend=None):
     """Initialise the default process group from the torchrun environment (no-op for a single process)."""
     import torch
@@ -25,7 +56,7 @@ def init(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("PHF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -61,6 +92,28 @@ def shard_problems(costs, world):
         r = int(np.argmin(load))
         parts[r].append(int(q)); load[r] += costs[q]
     return [np.array(sorted(p), dtype=np.int64) for p in parts]
+
+
+def shard_blocks(costs, blocks_per_problem, world):
+    """Partition the (problem, 64-chain block) UNITS of a batch over ranks, balancing cost: longest-processing-time greedy over
+    the units (every block of a problem costs what the problem costs per chain), deterministic.  The reference's unit of
+    distribution is a whole pair (python/PyHillFit.py:978-1003: pool.map_async(run, pairs)); with thousands of chains per pair a
+    pair is many wavefronts, and splitting by blocks keeps every rank's share within one block of the others' — 13 440 blocks of
+    the full Crumb set over 8 GPUs are 1 680 each — where whole pairs leave 26 or 27 pairs of unequal cost per rank.
+    Returns, per rank, an int64 array [n_units][2] of (problem index, block index), sorted; a unit keeps its chains' Philox
+    streams through phf_problems.chain_offset = 64 * block (sampler `chain_offsets`)."""
+    import heapq
+    costs = np.asarray(costs, dtype=np.float64)
+    bpp = np.broadcast_to(np.asarray(blocks_per_problem, dtype=np.int64), costs.shape)
+    order = np.argsort(-costs, kind="stable")
+    heap = [(0.0, r) for r in range(world)]
+    parts = [[] for _ in range(world)]
+    for q in order:
+        for b in range(int(bpp[q])):
+            load, r = heapq.heappop(heap)
+            parts[r].append((int(q), b))
+            heapq.heappush(heap, (load + float(costs[q]), r))
+    return [np.array(sorted(p), dtype=np.int64).reshape(-1, 2) for p in parts]
 
 
 def shard_chains(num_chains, rank, world):

@@ -131,7 +131,7 @@ class HierarchicalSampler(object):
     """Q pairs (all with Ne experiments) x C chains of the hierarchical adaptive-Metropolis sampler on one GPU."""
 
     def __init__(self, points, pair_index, chains_per_problem, thinning=5, seed=25, adapt_start=None, prior=None,
-                 problem_ids=None, chain_id_base=0, device="cuda"):
+                 problem_ids=None, chain_id_base=0, chain_offsets=None, device="cuda"):
         self.lib = _lib.load(); _bind(self.lib)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -151,8 +151,11 @@ class HierarchicalSampler(object):
         # pairs with more points first (the cost of an iteration grows with the points; include/pyhillfit_amd.h: launch_order)
         npts = self.points.packed.expt_start[np.asarray(pair_index, dtype=np.int64), -1]
         self.launch_order = torch.tensor(np.argsort(-npts, kind="stable").astype(np.int32), device=dev)
+        # chain_offsets[q]: global number of problem q's chain 0 (on top of chain_id_base) — a shard made of (pair, 64-chain block) units
+        self.chain_offsets = None if chain_offsets is None else torch.tensor(np.asarray(chain_offsets, dtype=np.int64), device=dev).to(torch.int32)
         self.prob = _lib.Problems(self.Q, self.C, self.pair_index.data_ptr(), self.temperature.data_ptr(),
-                                  self.problem_ids.data_ptr(), int(chain_id_base) & 0xFFFFFFFF, 0, self.launch_order.data_ptr())
+                                  self.problem_ids.data_ptr(), int(chain_id_base) & 0xFFFFFFFF, 0, self.launch_order.data_ptr(),
+                                  None if self.chain_offsets is None else self.chain_offsets.data_ptr())
         self.S = self.lib.phf_hierarchical_state_size(self.n_expts)
         if self.S < 0:
             raise _lib.PhfError(self.lib.phf_last_error().decode())

@@ -84,7 +84,7 @@ class SingleLevelSampler(object):
 
     def __init__(self, points, model, pair_index, temperature, chains_per_problem, thinning=5, seed=25,
                  adapt_start=None, reset_mean_at_adapt_start=False, problem_ids=None, chain_id_base=0, device="cuda",
-                 launch_order="cost", queue_quanta=4):
+                 launch_order="cost", queue_quanta=4, chain_offsets=None):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -117,9 +117,13 @@ class SingleLevelSampler(object):
             if sorted(order.tolist()) != list(range(self.Q)):
                 raise ValueError("launch_order must be a permutation of the problems")
             self.launch_order = torch.tensor(order, device=dev)
+        # chain_offsets[q]: global number of problem q's chain 0 (on top of chain_id_base) — a shard made of (pair, 64-chain block)
+        # units (distributed.shard_blocks) lists each block as a problem of 64 chains and keeps every chain's Philox stream
+        self.chain_offsets = None if chain_offsets is None else torch.tensor(np.asarray(chain_offsets, dtype=np.int64), device=dev).to(torch.int32)
         self.prob = _lib.Problems(self.Q, self.C, self.pair_index.data_ptr(), self.temperature.data_ptr(),
                                   self.problem_ids.data_ptr(), int(chain_id_base) & 0xFFFFFFFF, 0,
-                                  self.launch_order.data_ptr() if self.launch_order is not None else None)
+                                  self.launch_order.data_ptr() if self.launch_order is not None else None,
+                                  None if self.chain_offsets is None else self.chain_offsets.data_ptr())
         # Launches of a few rounds of the chip run as a work queue of `queue_quanta` quanta per block (phf_single_level_advance_queued:
         # same results, shorter tail: the 210 pairs x 4 096 chains launch 44.2 ms plain, 42.4 with 4 quanta, 42.8 with 8, 44.2 with 16);
         # 0 = always the plain launch.  The workspace is one int per block + 1.

@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu(lib):
     rc = lib.phf_single_level_advance(None, None, None, 0, 10, None, None, None, 0, None)
     assert rc == -1 and b"null" in lib.phf_last_error()
     pts = _lib.Points(1, 16, 1, 1, 1, 1, 1, 1)
-    prob = _lib.Problems(1, 64, 1, 1, 1, 0, 0, None)
+    prob = _lib.Problems(1, 64, 1, 1, 1, 0, 0, None, None)
     cfg = _lib.MhConfig(5, 5, 3000, 0, 0, 25, None)
     assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
     cfg.model = 2; cfg.thinning = 0

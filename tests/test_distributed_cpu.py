@@ -27,6 +27,36 @@ def test_shard_problems_is_a_balanced_partition(g4_pairs):
     assert spans == [(0, 3), (3, 3), (6, 2), (8, 2)]
 
 
+def test_shard_blocks_covers_every_pair_block_once_and_balances(g4_pairs):
+    """strong scaling of one batch: (pair, 64-chain block) units by LPT — every unit on exactly one rank, block counts within one
+    of each other, cost within one unit; the Philox ids a rank hands its kernels (problem id = pair, chain offset = 64 x block)
+    are the one-rank run's"""
+    from pyhillfit_amd import distributed as pd
+    costs = np.array([525.0 + 30.0 * p["n_total"] for p in g4_pairs.values()])
+    P, B = len(costs), 64                                            # the full Crumb set at 4 096 chains per pair: 13 440 blocks
+    everything = {(q, b) for q in range(P) for b in range(B)}
+    for world in (1, 2, 3, 4, 8):
+        parts = pd.shard_blocks(costs, B, world)
+        assert len(parts) == world and sum(len(p) for p in parts) == P * B
+        seen = set()
+        for p in parts:
+            units = set(map(tuple, p.tolist()))
+            assert len(units) == len(p) and not (units & seen)
+            seen |= units
+        assert seen == everything
+        sizes = [len(p) for p in parts]
+        assert max(sizes) - min(sizes) <= 1 + (world == 3), sizes     # 1 680 each at 8 ranks
+        loads = [float(costs[p[:, 0]].sum()) for p in parts]
+        assert max(loads) - min(loads) <= costs.max(), loads
+        # global chain ids of a rank's units: chain_offset 64 b + lane — disjoint over ranks, complete over the batch
+        ids = np.concatenate([(p[:, 0] * (B * 64) + p[:, 1] * 64)[:, None] + np.arange(64)[None, :] for p in parts]).ravel()
+        assert np.array_equal(np.sort(ids), np.arange(P * B * 64))
+    # ragged: different block counts per problem (a ladder of few-chain rungs next to a big pair), more ranks than some problems' blocks
+    parts = pd.shard_blocks([3.0, 1.0, 2.0], [1, 5, 2], 4)
+    assert sorted(u for p in parts for u in map(tuple, p.tolist())) == [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (2, 0), (2, 1)]
+    assert sorted(len(p) for p in parts) == [1, 2, 2, 3] and parts[0].tolist()[0] == [0, 0]
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -141,3 +171,36 @@ def test_tempered_pair_rung_units_gathered_and_assembled_world_size_2(tmp_path):
         from pyhillfit_amd import doseresponse as dr
         dr.setup(os.path.join(REPO, "data", "crumb_dataset.json")); dr.define_model(2)
         T.assemble_thermodynamic_integration(np.zeros((3, 8)), [("Amiodarone", "hERG")], lad, 2, {})
+
+
+def test_num_cores_flag_starts_ranks_through_the_cli_entry_point(tmp_path):
+    """`PyHillFit.py ... -c 2` (the reference's pool size, python/PyHillFit.py:40,997-1003) starts two ranks as a child torchrun
+    and passes the exit code on.  On the CPU: gloo, and the one step of the command line that needs no GPU (-bfo: best fits only,
+    python/PyHillFit.py:739-746) — both ranks go through broadcast, partition and gather, together they write every pair's file."""
+    import subprocess
+    import sys
+    from pyhillfit_amd import distributed as pd
+    from pyhillfit_amd import doseresponse as dr
+    assert pd.ranks_for_cores(1) == 0 and pd.ranks_for_cores(0) == 0
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    csv = str(tmp_path / "crumb_data.csv")
+    dr.table.to_csv(csv)
+    out = str(tmp_path / "output")
+    env = dict(os.environ, PHF_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(REPO, "python", "PyHillFit.py"), "--data-file", csv, "-m", "2", "-a", "-bfo", "-c", "2",
+           "--output-root", out, "--write-workers", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "gathered summaries from 2 ranks" in r.stdout
+    import glob
+    assert len(glob.glob(os.path.join(out, "crumb_data", "single-level", "*", "*", "model_2", "temperature_1", "figures", "*_best_fit_params.txt"))) == 210
+    # a failing rank's exit code comes back through the parent (a data file that does not exist)
+    bad = subprocess.run(cmd[:3] + [str(tmp_path / "missing.csv")] + cmd[4:], env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
+    # inside a torchrun world the flag starts nothing
+    os.environ["WORLD_SIZE"] = "2"
+    try:
+        assert pd.ranks_for_cores(8) == 0
+    finally:
+        del os.environ["WORLD_SIZE"]

@@ -185,3 +185,50 @@ def test_bench_line_keeps_the_contract(workload):
     # whole-job throughput = chains x iterations x steps / time
     chains = d["config"]["chains_per_gpu"]
     assert d["value"] == pytest.approx(chains * 400 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)
+    assert "other_workloads" not in d                       # only the default-size headline run carries the other configurations
+
+
+def test_bench_default_line_carries_the_other_configurations():
+    """the driver's command (N = 1, defaults): the headline keys are c3's, and `other_workloads` holds driver-timed short regions of
+    c2, c4 and c5 — value, ms_per_step, kernel_ms and the two roofline fractions each"""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["chains_per_gpu"] == 210 * 4096 and d["steps"] == 3
+    assert d["value"] == pytest.approx(210 * 4096 * d["config"]["iterations_per_step"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
+    assert d["ms_per_step"] * d["steps"] > 300              # a timed region of the default size is no blink
+    ow = d["other_workloads"]
+    assert sorted(ow) == ["c2", "c4", "c5"]
+    for w, chains in (("c2", 65536), ("c4", 210 * 1024), ("c5", 32 * 210 * 1024)):
+        e = ow[w]
+        assert e["chains"] == chains and e["value"] == pytest.approx(chains * e["iterations_per_step"] * e["steps"] / (e["ms_per_step"] * e["steps"] * 1e-3), rel=1e-6)
+        assert 0 < e["kernel_ms"] <= e["ms_per_step"] * 1.05 and 0 < e["roofline_frac"] < 1 and 0.05 < e["mean_acceptance"] < 0.6
+        assert e["value"] > 1e9
+
+
+def test_bench_two_ranks_report_weak_and_strong_scaling():
+    """`bench.py --gpus 2` rehearsed on the one GPU (gloo; RCCL refuses two ranks on a device): ONE JSON line with `value` (weak:
+    every rank its own full batch) AND `strong_value` (one batch split by (pair, 64-chain block) units, distributed.shard_blocks)"""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--chains", "256",
+           "--iters-per-step", "400", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PHF_BENCH_BACKEND="gloo"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["chains_all_gpus"] == 2 * 210 * 256
+    assert d["value"] == pytest.approx(2 * 210 * 256 * 400 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)
+    sr = d["strong_region"]
+    assert sr["chains_all_gpus"] == 210 * 256 and abs(sr["chains_rank0"] - 210 * 128) <= 64          # 840 blocks: 420 per rank
+    assert d["strong_value"] == pytest.approx(210 * 256 * 400 * 2 / (sr["ms_per_step"] * 2e-3), rel=1e-6) and d["strong_value"] > 0

@@ -211,6 +211,16 @@ def test_c3_full_width_shard_invariance_and_checkpoint(gpu, dr):
         s = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, C // 2, chain_id_base=h * (C // 2), **kw)
         s.init([6.0, 0.8, 8.0])
         assert torch.equal(s.run(T), a[..., h * (C // 2):(h + 1) * (C // 2)])
+    # strong scaling's partition: (pair, 64-chain block) units by LPT over 8 'ranks' (distributed.shard_blocks: 1 680 blocks each);
+    # a rank lists its blocks as problems of 64 chains (problem id = the pair, chain offset = 64 x block): same chains, bit for bit
+    parts = D.shard_blocks(525.0 + 28.0 * packed.counts[:, 0] + 115.0 * (packed.counts[:, 1] + packed.counts[:, 2]), C // 64, 8)
+    assert [len(u) for u in parts] == [1680] * 8
+    blocks = a.view(a.shape[0], Q, 4, C // 64, 64)                  # [9][210][4][64 blocks][64 chains]
+    for units in (parts[0], parts[5]):
+        s = SingleLevelSampler(packed, 2, units[:, 0].tolist(), [1.0] * len(units), 64, problem_ids=units[:, 0], chain_offsets=64 * units[:, 1], **kw)
+        s.init([6.0, 0.8, 8.0])
+        u = torch.as_tensor(units, device=a.device)
+        assert torch.equal(s.run(T), blocks[:, u[:, 0], :, u[:, 1], :].permute(1, 0, 2, 3).contiguous())
     r = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, C, **kw)
     r.init([6.0, 0.8, 8.0])
     first = r.advance(25)
@@ -243,6 +253,14 @@ def test_c4_full_width_shard_invariance_and_checkpoint(gpu, dr):
             s = H.HierarchicalSampler(packed, list(range(len(exs))), C // 8, chain_id_base=r * (C // 8), **kw)
             s.init(theta0, cov_scale=0.01)
             assert torch.equal(s.advance(T), a[..., r * (C // 8):(r + 1) * (C // 8)])
+        # a strong-scaling rank's share: (pair, 64-chain block) units as problems of 64 chains with chain offsets
+        from pyhillfit_amd import distributed as D
+        units = D.shard_blocks(packed.expt_start[:, -1].astype(float), C // 64, 8)[3]
+        s = H.HierarchicalSampler(packed, units[:, 0].tolist(), 64, problem_ids=units[:, 0], chain_offsets=64 * units[:, 1], **kw)
+        s.init(theta0[units[:, 0]], cov_scale=0.01)
+        u = torch.as_tensor(units, device=a.device)
+        blocks = a.view(a.shape[0], len(exs), a.shape[2], C // 64, 64)
+        assert torch.equal(s.advance(T), blocks[:, u[:, 0], :, u[:, 1], :].permute(1, 0, 2, 3).contiguous())
         one = H.HierarchicalSampler(packed, list(range(len(exs))), C, **kw)
         one.init(theta0, cov_scale=0.01)
         assert torch.equal(one.advance(T), a) and torch.equal(one.state, full.state)
