@@ -62,3 +62,31 @@ def oracle_pair(crumb_table, synthetic_table):
             cache[key] = orc.pair_from_rows(*rows_of(table, drug, channel))
         return cache[key]
     return get
+
+
+def reference_posteriors(model, temperature=1.0):
+    """The reference sampler's long-run posterior of every Crumb pair: (names, mean [d+1][210], standard error [d+1][210], sd).
+
+    G5c = ONE reference chain per pair (PyHillTemp.do_mcmc, 200 000 iterations, seed 1) with its batch-means standard error.  Where
+    G5d holds several independent reference chains of the same case (tests/golden/make_golden_posteriors_reseed.py: the weakly
+    informative pairs whose single chain is not enough), the pooled mean of those replaces the single chain's, with the larger
+    of the two standard errors one can form from them: scatter between the seeds' means / sqrt(n), and mean batch-means s.e. / sqrt(n)."""
+    with open(os.path.join(GOLDEN, "g5c_posteriors_all_pairs_model_%d.json" % model)) as f:
+        g5c = json.load(f)
+    names = [(w["drug"], w["channel"]) for w in g5c]
+    mean = np.array([w["mean"] for w in g5c]).T
+    se = np.array([w["batch_means_se"] for w in g5c]).T
+    sd = np.array([w["sd"] for w in g5c]).T
+    path = os.path.join(GOLDEN, "g5d_posteriors_reseeded.json")
+    reseeded = []
+    if os.path.exists(path):
+        with open(path) as f:
+            for e in json.load(f):
+                if e["model"] == model and e["temperature"] == temperature and (e["drug"], e["channel"]) in names:
+                    q = names.index((e["drug"], e["channel"]))
+                    n = len(e["seeds"])
+                    mean[:, q] = e["mean"]
+                    se[:, q] = np.maximum(e["se_between_seeds"], np.array(e["se_single_chain_batch_means"]) / np.sqrt(n))
+                    sd[:, q] = e["sd"]
+                    reseeded.append(names[q])
+    return names, mean, se, sd, reseeded

@@ -27,6 +27,9 @@ sys.path.insert(0, HERE)
 CASES = [("Ranolazine", "Nav1.5-peak", 2, 1.0), ("Nilotinib", "KvLQT1/mink", 2, 1.0), ("Sertindole", "Cav1.2", 2, 1.0),
          ("Sotalol", "Kv4.3", 2, 1.0), ("Amitriptyline", "Kir2.1", 2, 1.0),
          ("Amiodarone", "hERG", 2, 0.0)]                 # prior-only rung: analytic answer known, reached slowly
+# more seeds where eight left the question open: the GPU's pooled pIC50 of Amitriptyline-Kir2.1 (-0.2386) lay below all eight
+# reference chains (-0.185 ... -0.235): chance, or a difference of 1 % of the posterior's sd?
+MORE_SEEDS = {("Amitriptyline", "Kir2.1", 2, 1.0): 32}
 
 _dr = None
 
@@ -55,10 +58,17 @@ def main():
     ap.add_argument("--iterations", type=int, default=200000)
     ap.add_argument("--seeds", type=int, default=8)
     ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--fresh", action="store_true", help="recompute every run instead of adding the missing ones to the fixture")
     a = ap.parse_args()
-    jobs = [(d, c, m, t, seed, a.iterations) for (d, c, m, t) in CASES for seed in range(1, a.seeds + 1)]
-    t0 = time.time()
+    out_path = os.path.join(HERE, "g5d_posteriors_reseeded.json")
     runs = []
+    if os.path.exists(out_path) and not a.fresh:          # runs already made are kept: only the missing (case, seed) are computed
+        with open(out_path) as f:
+            runs = [r for e in json.load(f) if e["iterations"] == a.iterations for r in e["runs"]]
+    have = {(r["drug"], r["channel"], r["model"], r["temperature"], r["seed"]) for r in runs}
+    jobs = [(d, c, m, t, seed, a.iterations) for (d, c, m, t) in CASES for seed in range(1, max(a.seeds, MORE_SEEDS.get((d, c, m, t), 0)) + 1)
+            if (d, c, m, t, seed) not in have]
+    t0 = time.time()
     with mp.get_context("fork").Pool(a.workers) as pool:
         for r in pool.imap_unordered(_worker, jobs):
             runs.append(r)
@@ -75,7 +85,7 @@ def main():
                     "se_between_seeds": (means.std(axis=0, ddof=1) / np.sqrt(n)).tolist(),
                     "se_single_chain_batch_means": np.array([r["batch_means_se"] for r in mine]).mean(axis=0).tolist(),
                     "runs": mine})
-    with open(os.path.join(HERE, "g5d_posteriors_reseeded.json"), "w") as f:
+    with open(out_path, "w") as f:
         json.dump(out, f, indent=1)
     print("G5d written: %d cases x %d seeds in %.0f s" % (len(CASES), a.seeds, time.time() - t0))
 

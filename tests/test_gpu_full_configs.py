@@ -273,9 +273,10 @@ def test_c5_full_ladder_all_pairs(gpu, dr):
     """BASELINE configs[4]: 32 rungs t_i = (i/31)^3 (python/PyHillTemp.py:151 with n = 31) x 210 pairs x 1 024 chains =
     6.9 M chains, PyHillTemp's start (ones, identity covariance, mean reset), 200 000 iterations like the reference's runs
     behind golden G5c, moments on the device:
-      * rung t = 0 samples the prior alone (doseresponse.py:230-231): pooled over its 210 x 1 024 chains the means are the
-        analytic (2, 5, 7.49975) and the sds (5, 2.887, 3.354);
-      * rung t = 1 reproduces the reference sampler's posterior means of every pair (G5c: PyHillTemp.do_mcmc on all 210 pairs);
+      * rung t = 0 samples the prior alone (doseresponse.py:230-231): pooled over its 210 x 1 024 chains the means are those of
+        the reference's own t = 0 runs of this length (G5d) — for Hill and sigma also the analytic (5, 7.49975) — and the sds the
+        analytic (5, 2.887, 3.354);
+      * rung t = 1 reproduces the reference sampler's posterior means of EVERY pair and column (G5c, G5d: PyHillTemp.do_mcmc);
       * per pair, <log L(theta; t=1)> under the tempered posteriors rises along the ladder (its t-derivative is a variance):
         what python/compute_bayes_factors.py integrates."""
     from pyhillfit_amd.sampler import SingleLevelSampler
@@ -302,18 +303,25 @@ def test_c5_full_ladder_all_pairs(gpu, dr):
     prior_mean = m0.mean(dim=1).cpu().numpy()
     prior_sd = torch.sqrt(var[:3, :, 0, :].reshape(3, -1).mean(dim=1) + m0.var(dim=1)).cpu().numpy()
     print("C5 t=0 rung: pooled mean", prior_mean, "sd", prior_sd)
-    # the exponential pIC50 tail (mean 5 beyond -3) is explored slowly by a random walk started at 1: at this run length the
-    # REFERENCE's own t = 0 chain gives 1.89 for the analytic 2; Hill and sigma are at their analytic values
-    assert np.all(np.abs(prior_mean - [2.0, 5.0, 7.49975]) <= [0.12, 0.03, 0.05]), prior_mean
+    # the exponential pIC50 tail (mean 5 beyond -3) is explored slowly by a random walk started at 1: at THIS run length the
+    # reference's own sampler averages pIC50 to 1.893 +- 0.013 (golden G5d: eight seeds of PyHillTemp.do_mcmc at t = 0), not to the
+    # analytic 2 — so the rung is held to the reference run (1 % + 4 of its standard errors); Hill and sigma also to their analytic
+    # values.  (test_prior_only_rung_known_answer runs twice as long and pins all three to the analytic prior.)
+    with open(os.path.join(GOLDEN, "g5d_posteriors_reseeded.json")) as f:
+        ref0 = [e for e in json.load(f) if e["temperature"] == 0.0 and e["model"] == 2][0]
+    r_mean, r_se = np.array(ref0["mean"][:3]), np.maximum(ref0["se_between_seeds"][:3], np.array(ref0["se_single_chain_batch_means"][:3]) / np.sqrt(len(ref0["seeds"])))
+    assert np.all(np.abs(prior_mean - r_mean) <= 0.01 * np.abs(r_mean) + 4 * r_se), (prior_mean, r_mean, r_se)
+    assert np.all(np.abs(prior_mean[1:] - [5.0, 7.49975]) <= [0.03, 0.05]), prior_mean
     assert np.all(np.abs(prior_sd - [5.0, 10 / np.sqrt(12), np.sqrt(5) * 1.49975]) <= [0.35, 0.03, 0.06]), prior_sd
-    # t = 1: the reference sampler's posteriors, all pairs
+    # t = 1: the reference sampler's posteriors, all pairs, every (pair, column) within 1 % + 4 standard errors
+    from conftest import reference_posteriors
+    names_ref, want, se, _, _ = reference_posteriors(2)
+    assert names_ref == names
     pooled = mean[:, :, R - 1, :].mean(dim=2).cpu().numpy()        # [4][P]
-    want = np.array([w["mean"] for w in g5c]).T
-    se = np.array([w["batch_means_se"] for w in g5c]).T
     ratio = np.abs(pooled - want) / (0.01 * np.abs(want) + 4 * se)
     worst = np.unravel_index(np.argmax(ratio), ratio.shape)
-    print("C5 t=1 rung vs G5c: within tolerance %.4f, worst %.2f at %s column %d" % (np.mean(ratio < 1), ratio.max(), names[worst[1]], worst[0]))
-    assert np.mean(ratio < 1) >= 0.99 and ratio.max() < 2.0, (np.mean(ratio < 1), ratio.max(), names[worst[1]], worst[0])
+    print("C5 t=1 rung vs G5c+G5d: worst %.2f at %s column %d" % (ratio.max(), names[worst[1]], worst[0]))
+    assert ratio.max() < 1.0, (ratio.max(), names[worst[1]], worst[0], pooled[worst], want[worst], se[worst])
     # <log L> along the ladder
     ll = s.mean_log_likelihood_t1().view(P, R, C)
     e = ll.mean(dim=2).cpu().numpy()                               # [P][R]

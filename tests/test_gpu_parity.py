@@ -345,16 +345,15 @@ def test_posteriors_of_other_pair_shapes_match_reference(gpu, dr):
 def test_every_crumb_pair_posterior_within_one_percent_of_reference(model, gpu, dr):
     """BASELINE's correctness target on the full data set (config 3): G5c = the reference's own sampler (PyHillTemp.do_mcmc,
     200 000 iterations, tests/golden/make_golden_posteriors_all.py) run on every one of the 210 pairs, for both models; here
-    256 chains per pair, same length and start, pooled on the device.  Tolerance per (pair, column): 1 % of the reference
-    mean + 4 batch-means standard errors of the reference's single chain."""
+    256 chains per pair, same length and start, pooled on the device.  Tolerance per (pair, column), with NO entry allowed outside:
+    1 % of the reference mean + 4 standard errors of the reference — the batch-means s.e. of its single chain, or, for the five
+    weakly informative pairs whose single chain proved too short to say what the mean is (golden G5d: eight and more independent
+    reference chains each; Ranolazine-Nav1.5-peak's seed-1 chain sits 3.5 of the others' standard errors from their mean), the
+    pooled mean and the s.e. of the reseeded runs (conftest.reference_posteriors)."""
+    from conftest import reference_posteriors
     from pyhillfit_amd.sampler import SingleLevelSampler
-    path = os.path.join(GOLDEN, "g5c_posteriors_all_pairs_model_%d.json" % model)
-    if not os.path.exists(path):
-        pytest.skip("fixture not generated (tests/golden/make_golden_posteriors_all.py --model %d)" % model)
-    with open(path) as f:
-        g5c = json.load(f)
-    assert len(g5c) == 210
-    names = [(w["drug"], w["channel"]) for w in g5c]
+    names, want, se, want_sd, reseeded = reference_posteriors(model)
+    assert len(names) == 210 and (model == 1 or len(reseeded) == 5)
     packed = dr.pack_single_level(names)
     s = SingleLevelSampler(packed, model, list(range(len(names))), [1.0] * len(names), 256, thinning=5, seed=5,
                            reset_mean_at_adapt_start=True, device=gpu)
@@ -364,20 +363,19 @@ def test_every_crumb_pair_posterior_within_one_percent_of_reference(model, gpu, 
     mean, var, n = s.posterior_moments()
     pooled = mean.mean(dim=2).cpu().numpy()                          # [d+1][210]
     pooled_sd = torch.sqrt(var.mean(dim=2) + mean.var(dim=2)).cpu().numpy()
-    want = np.array([w["mean"] for w in g5c]).T
-    se = np.array([w["batch_means_se"] for w in g5c]).T
     ratio = np.abs(pooled - want) / (0.01 * np.abs(want) + 4 * se)
     worst = np.unravel_index(np.argmax(ratio), ratio.shape)
-    print("G5c: fraction within tolerance %.4f, worst ratio %.2f at %s column %d" % (np.mean(ratio < 1), ratio.max(), names[worst[1]], worst[0]))
+    print("G5c+G5d: worst ratio %.2f at %s column %d; fraction below 0.5: %.4f" % (ratio.max(), names[worst[1]], worst[0], np.mean(ratio < 0.5)))
     order = np.dstack(np.unravel_index(np.argsort(-ratio, axis=None), ratio.shape))[0][:25]
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)                # scratch record of the entries closest to the tolerance
     with open(os.path.join(REPO, "gpurun_out", "g5c_worst_model_%d.json" % model), "w") as f:
         json.dump([{"drug": names[q][0], "channel": names[q][1], "column": int(k), "ratio": float(ratio[k, q]), "gpu": float(pooled[k, q]),
                     "reference": float(want[k, q]), "reference_se": float(se[k, q]), "gpu_sd": float(pooled_sd[k, q])} for k, q in order], f, indent=1)
-    assert np.mean(ratio < 1) >= 0.99 and ratio.max() < 2.0, (np.mean(ratio < 1), ratio.max(), names[worst[1]], worst[0])
+    # EVERY (pair, column): within 1 % of the reference's mean + 4 of its standard errors — no fraction allowed to fail
+    assert ratio.max() < 1.0, (ratio.max(), names[worst[1]], worst[0], pooled[worst], want[worst], se[worst])
     # posterior widths: the reference's single 200k chain estimates an sd poorly where the posterior has a long thin tail
     # (Hill of weakly informative pairs), so the bulk is checked tightly and the extremes loosely
-    sd_ratio = pooled_sd[:s.d] / np.array([w["sd"][:s.d] for w in g5c]).T
+    sd_ratio = pooled_sd[:s.d] / want_sd[:s.d]
     lo, hi = np.unravel_index(np.argmin(sd_ratio), sd_ratio.shape), np.unravel_index(np.argmax(sd_ratio), sd_ratio.shape)
     info = (sd_ratio.min(), names[lo[1]], lo[0], sd_ratio.max(), names[hi[1]], hi[0], np.mean((sd_ratio > 0.8) & (sd_ratio < 1.25)))
     assert np.mean((sd_ratio > 0.8) & (sd_ratio < 1.25)) >= 0.97, info
@@ -427,6 +425,9 @@ def test_thermodynamic_integration_against_the_reference_pipeline(gpu, dr):
             log_py = s.mean_log_likelihood_t1().mean(dim=1).cpu().numpy()                    # pooled over the chains of a rung
             want, se = np.array(ref["log_py"]), np.array(ref["batch_means_se"])
             ratio = np.abs(log_py - want) / (0.01 * np.abs(want) + 4 * se)
+            print("G6 %s-%s model %d: per-rung ratios: max %.2f at rung %d, %d of %d above 1: %s" % (
+                entry["drug"], entry["channel"], model, ratio.max(), int(ratio.argmax()), int((ratio >= 1).sum()), len(ratio),
+                [(int(k), round(float(ratio[k]), 2), round(float(log_py[k]), 3), round(float(want[k]), 3), round(float(se[k]), 4)) for k in np.argsort(-ratio)[:4]]))
             assert ratio.max() < 1.5 and np.mean(ratio < 1) >= 0.9, (entry["drug"], model, ratio.max(), int(ratio.argmax()))
             E[model] = float(dr.trapezium_rule(temps, log_py))
             w = np.zeros(len(temps)); w[1:] += 0.5 * np.diff(temps); w[:-1] += 0.5 * np.diff(temps)   # trapezium weights

@@ -19,11 +19,11 @@ for si, s0 in enumerate(starts):
         m = re.match(r'(\.LBB\d+_\d+):', l)
         if m:
             labels[m.group(1)] = len(ins); continue
+        if l.startswith('.Lfunc_end'):
+            break
         if not l or l.startswith(';') or l.startswith('.'):
             continue
-        if l.startswith('s_endpgm'):
-            ins.append(l); break
-        ins.append(l)
+        ins.append(l)                      # (a kernel may hold several s_endpgm: early exits precede the big bodies)
     print(name, 'total instructions', len(ins))
     loops = []
     for i, l in enumerate(ins):
@@ -41,11 +41,13 @@ for si, s0 in enumerate(starts):
             elif op.startswith('ds_read') or op.startswith('ds_load'): c['ds_read'] += 1
             elif op.startswith('ds_write') or op.startswith('ds_store'): c['ds_write'] += 1
             elif op.startswith('v_accvgpr'): c['accvgpr_mov'] += 1
+            elif op.startswith('v_readlane') or op.startswith('v_writelane') or op.startswith('v_readfirstlane'): c['lane_ops'] += 1
+            elif op.startswith('s_nop'): c['s_nop'] += 1
             elif op.startswith('v_') and ('_f64' in op): c['f64:' + ('fma' if 'fma' in op else 'mul' if 'mul' in op else 'add' if 'add' in op else 'rcp/sqrt/rsq' if re.search('rcp|sqrt|rsq', op) else 'other')] += 1
             elif op.startswith('v_'): c['valu_other'] += 1
             elif op.startswith('s_load') or op.startswith('s_buffer'): c['smem'] += 1
             elif op.startswith('s_'): c['salu'] += 1
             elif op.startswith('global_'): c['global'] += 1
             else: c['other:' + op] += 1
-        valu = sum(v for k, v in c.items() if k.startswith('f64') or k in ('valu_other', 'accvgpr_mov'))
+        valu = sum(v for k, v in c.items() if k.startswith('f64') or k in ('valu_other', 'accvgpr_mov', 'lane_ops'))
         print('  loop [%d..%d] %d instructions, VALU %d:' % (a, b, b - a + 1, valu), dict(sorted(c.items())))
