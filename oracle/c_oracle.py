@@ -212,6 +212,16 @@ class PackedHierPair:
         return out
 
 
+def hier_state_covariance(st, dim):
+    """the adapted covariance a hierarchical chain's state carries: cov = L diag(d) L' with the packed lower triangle of the state
+    holding the unit lower L and, in its diagonal slots, d (pyhillfit_amd/csrc/phf_hierarchical.hip: PHF_LDL_COLUMN)"""
+    tri = np.zeros((dim, dim))
+    tri[np.tril_indices(dim)] = np.asarray(st)[2 * dim + 1:2 * dim + 1 + dim * (dim + 1) // 2]
+    dvec = np.diag(tri).copy()
+    np.fill_diagonal(tri, 1.0)
+    return (tri * dvec[None, :]) @ tri.T
+
+
 def predictive_accumulate(rows, chains_used, hill_x, pic50_x, chunk, sums=None):
     """twin of phf_predictive_accumulate: rows [num_rows][Q][row_stride][C] -> sums [Q][4][G] (added to `sums`)."""
     rows = np.ascontiguousarray(rows, dtype=np.float64)

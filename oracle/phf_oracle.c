@@ -186,20 +186,22 @@ double phfo_hier_log_target(const phfo_hier_problem* pb, const double* th) {
   return phf_hier_log_target_any(pb->n_expts, pb->expt_start, pb->ln_conc, pb->response, th, 1, &pb->prior, phf_k_exp, phf_k_log);
 }
 
-/* state: th[d], lt, mean[d], L[d(d+1)/2] (factor of the adapted covariance), loga, n_accepted */
+/* state: th[d], lt, mean[d], L[d(d+1)/2] (the adapted covariance as L diag(d) L': unit lower L packed row-major, d_i in the
+ * diagonal slots), loga, n_accepted */
 void phfo_hier_init_state(const phfo_hier_problem* pb, double cov_scale, const double* theta0, double* st) {
   const int d = 5 + 2 * pb->n_expts;
   double* th = st; double* lt = st + d; double* mean = st + d + 1; double* L = mean + d;
   for (int i = 0; i < d; ++i) { th[i] = theta0[i]; mean[i] = theta0[i]; }   /* PyHillFit.py:433,442 */
-  for (int i = 0; i < d; ++i)                                               /* factor of diag(0.01 |theta0|), :431 */
-    for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = (i != j) ? 0.0 : phf_sqrt(cov_scale * __builtin_fabs(theta0[i]));
+  for (int i = 0; i < d; ++i)                                               /* diag(0.01 |theta0|), :431: L = I, d = the diagonal */
+    for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = (i != j) ? 0.0 : cov_scale * __builtin_fabs(theta0[i]);
   *lt = phfo_hier_log_target(pb, th);                                       /* :447 */
   L[d * (d + 1) / 2] = 0.0;
   L[d * (d + 1) / 2 + 1] = 0.0;
 }
 
 /* The hierarchical loop (PyHillFit.py:484-511).  The covariance recursion cov <- (1-g) cov + g v v' (:498-499) is
- * carried on the Cholesky factor: scale by sqrt(1-g), then a rank-one update with sqrt(g) v by Givens rotations. */
+ * carried on the factors cov = L diag(d) L' (L unit lower): d scales by 1-g, then the rank-one update of Gill, Golub, Murray &
+ * Saunders (1974, method C1) with weight g and vector v, column by column. */
 void phfo_hier_advance(const phfo_hier_problem* pb, const phfo_run* run, double* st, double* out_rows,
                        const double* star_replay, const double* u_replay) {
   const int d = 5 + 2 * pb->n_expts;
@@ -216,10 +218,14 @@ void phfo_hier_advance(const phfo_hier_problem* pb, const phfo_run* run, double*
       log_u = phf_log(u_replay[t - run->t_begin - 1]);
     } else {
       log_u = phf_hier_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, phf_k_log, z, 1);
-      for (int i = 0; i < d; ++i) {                                        /* :485 */
-        double yv = L[i * (i + 1) / 2 + i] * z[i];
-        for (int k = i - 1; k >= 0; --k) yv = phf_fma(L[i * (i + 1) / 2 + k], z[k], yv);
-        star[i] = phf_fma(sc, yv, th[i]);
+      for (int i = 0; i < d; ++i) {                                        /* u = sqrt(d) z */
+        const double di = L[i * (i + 1) / 2 + i];
+        z[i] = ((di > 0.0) ? phf_sqrt(di) : 0.0) * z[i];
+      }
+      for (int i = 0; i < d; ++i) {                                        /* :485: theta* = theta + e^(loga/2) L u */
+        double yv = 0.0;                                                   /* ascending k from +0, u_i last */
+        for (int k = 0; k < i; ++k) yv = phf_fma(L[i * (i + 1) / 2 + k], z[k], yv);
+        star[i] = phf_fma(sc, yv + z[i], th[i]);
       }
     }
     const double lt_star = phfo_hier_log_target(pb, star);                 /* :486 */
@@ -229,21 +235,23 @@ void phfo_hier_advance(const phfo_hier_problem* pb, const phfo_run* run, double*
     if (t > run->adapt_start) {                                            /* :495-501 */
       const double g = run->gamma[t - run->adapt_start];
       const double omg = 1.0 - g;
-      const double sqa = phf_sqrt(omg), sqg = phf_sqrt(g);
-      for (int i = 0; i < d; ++i) w[i] = sqg * (th[i] - mean[i]);
+      for (int i = 0; i < d; ++i) w[i] = th[i] - mean[i];
       for (int i = 0; i < d; ++i) mean[i] = phf_fma(g, th[i], omg * mean[i]);
       *loga = phf_fma(g, (double)acc - 0.25, *loga);
+      double alpha = g;
       for (int k = 0; k < d; ++k) {
-        const double tkk = sqa * L[k * (k + 1) / 2 + k];
-        const double r = phf_sqrt(phf_fma(tkk, tkk, w[k] * w[k]));
-        const double inv = (r > 0.0) ? 1.0 / r : 0.0;
-        const double cs = (r > 0.0) ? tkk * inv : 1.0;
-        const double sn = w[k] * inv;
-        L[k * (k + 1) / 2 + k] = r;
+        const double p = w[k];
+        const double dk = omg * L[k * (k + 1) / 2 + k];
+        const double ap = alpha * p;
+        const double dn = phf_fma(ap, p, dk);
+        const double inv = (dn > 0.0) ? 1.0 / dn : 0.0;
+        const double beta = ap * inv;
+        alpha = (dn > 0.0) ? (alpha * dk) * inv : alpha;
+        L[k * (k + 1) / 2 + k] = dn;
         for (int i = k + 1; i < d; ++i) {
-          const double tik = sqa * L[i * (i + 1) / 2 + k];
-          L[i * (i + 1) / 2 + k] = phf_fma(cs, tik, sn * w[i]);
-          w[i] = phf_fma(cs, w[i], -(sn * tik));
+          const double lik = L[i * (i + 1) / 2 + k];
+          w[i] = phf_fma(-p, lik, w[i]);
+          L[i * (i + 1) / 2 + k] = phf_fma(beta, w[i], lik);
         }
       }
       sc = phf_exp_fast(0.5 * *loga);

@@ -23,6 +23,27 @@ constexpr int kBlock = 64;
 // *p += v without reading it back: global_atomic_add_f64, no return value, nothing to wait for
 __device__ __forceinline__ void phf_accumulate(double* p, double v) { (void)unsafeAtomicAdd(p, v); }
 
+// The adapted covariance is carried as cov = L diag(d) L' — L unit lower triangular, stored as the packed lower triangle with d_k in
+// the diagonal slot — and the reference's recursion cov <- (1-g) cov + g v v' (python/PyHillFit.py:498-499) is applied to the
+// factors: D scales by (1-g), then the rank-one update of Gill, Golub, Murray & Saunders (1974, method C1), column by column:
+//     p = w_k;  dk = (1-g) d_k;  dn = dk + alpha p^2;  beta = alpha p / dn;  alpha <- alpha dk / dn   (alpha starts at g, w at v)
+//     for the rows i > k:   w_i <- w_i - p L_ik;   L_ik <- L_ik + beta w_i
+// Two fused multiply-adds per element and ONE short dependent chain per column (multiply, fma, reciprocal, multiply) — against
+// five operations per element and a square root AND a reciprocal in every column's chain for the Givens sweep of a Cholesky
+// factor that rounds 1 and 2 carried: with that sweep cut out the one-lane Ne = 3 kernel ran 23 % faster although the sweep was
+// 13.5 % of its instructions (a lone wavefront exposes every dependent latency).  No square root is needed to UPDATE; the proposal
+// takes sqrt(d_k) of the eleven diagonals at the start of an iteration, where they overlap the draws.  dn = 0 (a direction that
+// has no variance and gets none: d_k = 0 and p = 0) leaves the column and alpha as they are.
+#define PHF_LDL_COLUMN(omg_, alpha_, p_, d_, dn_, beta_)                  \
+  do {                                                                   \
+    const double dk_ = (omg_) * (d_);                                    \
+    const double ap_ = (alpha_) * (p_);                                  \
+    (dn_) = phf_fma(ap_, (p_), dk_);                                     \
+    const double inv_ = ((dn_) > 0.0) ? phf_rcp(dn_) : 0.0;              \
+    (beta_) = ap_ * inv_;                                                \
+    (alpha_) = ((dn_) > 0.0) ? ((alpha_) * dk_) * inv_ : (alpha_);       \
+  } while (0)
+
 struct HierArgs {
   phf_hier_points pts;
   phf_problems prob;
@@ -105,17 +126,30 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   double* out = a.rows ? a.rows + ((size_t)q * (D + 1)) * C + c : nullptr;
   const size_t row_stride = (size_t)a.prob.num_problems * (D + 1) * C;
 
+  // y = L sqrt(D) z of the NEXT proposal, element by element:  y_i = (sum over k < i, ascending, of L_ik u_k, from +0) + u_i  with
+  // u_k = sqrt(d_k) z_k.  Read from LDS here (the first iteration of a launch, and every iteration before the adaptation
+  // starts); once adapting, the update sweep below produces it from the elements it has in registers anyway.
+#define PHF_PLAIN_LU(zz, yy)                                                                              \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < D; ++i) (zz)[i] = phf_sqrt_nonneg(PHF_LGET(i * (i + 1) / 2 + i)) * (zz)[i]; \
+    _Pragma("unroll") for (int i = 0; i < D; ++i) {                                                       \
+      double v_ = 0.0;                                                                                    \
+      _Pragma("unroll") for (int k = 0; k < i; ++k) v_ = phf_fma(PHF_LGET(i * (i + 1) / 2 + k), (zz)[k], v_); \
+      (yy)[i] = v_ + (zz)[i];                                                                             \
+    }                                                                                                     \
+  } while (0)
+  double y[D];
+  double log_u;
+  {
+    double z0[D];
+    log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(a.t_begin + 1), seed_lo, seed_hi, k_log, k_sc, 1, z0, 1);
+    PHF_PLAIN_LU(z0, y);
+  }
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
-    // ---- proposal theta* = theta + e^(loga/2) L z   (PyHillFit.py:485) ----
-    double z[D], star[D];
-    const double log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)t, seed_lo, seed_hi, k_log, k_sc, 1, z, 1);
+    // ---- proposal theta* = theta + e^(loga/2) L sqrt(D) z   (PyHillFit.py:485) ----
+    double star[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      double v = PHF_LGET(i * (i + 1) / 2 + i) * z[i];
-#pragma unroll
-      for (int k = i - 1; k >= 0; --k) v = phf_fma(PHF_LGET(i * (i + 1) / 2 + k), z[k], v);
-      star[i] = phf_fma(sc, v, th[i]);
-    }
+    for (int i = 0; i < D; ++i) star[i] = phf_fma(sc, y[i], th[i]);
     // ---- target, accept (:486-492) ----
     const double lt_star = phf_hier_log_target_n(NE, FIXED_N, s_es, s_lc, s_y, star, 1, &a.prior, k_exp, k_log);
     const bool acc = log_u < lt_star - lt;
@@ -125,34 +159,44 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
       lt = lt_star;
     }
     nacc += acc ? 1.0 : 0.0;
-    // ---- adaptation (:495-501): cov <- (1-g) cov + g v v' applied to the factor as a rank-one update ----
+    // ---- the draws of iteration t + 1 (a function of (chain, t + 1) alone): independent work next to the sweep's dependent chains ----
+    double zn[D];
+    log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, k_sc, 1, zn, 1);
+    // ---- adaptation (:495-501): cov <- (1-g) cov + g v v' applied to the L D L' factors as a rank-one update (PHF_LDL_COLUMN),
+    // and the next proposal's y = L' sqrt(D') z' accumulated from the new elements while they are in registers.  Before the
+    // adaptation starts the sweep runs with g = 0 — an exact no-op on mean, loga, d and L (x + 0 y) that still delivers y — so
+    // that the iteration is one straight-line body ----
     if (t > a.cfg.adapt_start) {
       const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
       const double omg = 1.0 - gs;
-      const double sqa = phf_sqrt_pos(omg), sqg = phf_sqrt_pos(gs);
       double w[D];
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        w[i] = sqg * (th[i] - mean[i]);
+        w[i] = th[i] - mean[i];
         mean[i] = phf_fma(gs, th[i], omg * mean[i]);
+        y[i] = 0.0;
       }
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
+      double alpha = gs;
 #pragma unroll
-      for (int k = 0; k < D; ++k) {                        // Givens sweep down column k
-        const double tkk = sqa * PHF_LGET(k * (k + 1) / 2 + k);
-        const double r = phf_sqrt_nonneg(phf_fma(tkk, tkk, w[k] * w[k]));
-        const double inv = (r > 0.0) ? phf_rcp(r) : 0.0;
-        const double cs = (r > 0.0) ? tkk * inv : 1.0;
-        const double sn = w[k] * inv;
-        PHF_LSET(k * (k + 1) / 2 + k, r);
+      for (int k = 0; k < D; ++k) {
+        double dn, beta;
+        PHF_LDL_COLUMN(omg, alpha, w[k], PHF_LGET(k * (k + 1) / 2 + k), dn, beta);
+        PHF_LSET(k * (k + 1) / 2 + k, dn);
+        zn[k] = phf_sqrt_nonneg(dn) * zn[k];               // u_k of the next proposal
 #pragma unroll
         for (int i = k + 1; i < D; ++i) {
-          const double tik = sqa * PHF_LGET(i * (i + 1) / 2 + k);
-          PHF_LSET(i * (i + 1) / 2 + k, phf_fma(cs, tik, sn * w[i]));
-          w[i] = phf_fma(cs, w[i], -(sn * tik));
+          const double lik = PHF_LGET(i * (i + 1) / 2 + k);
+          w[i] = phf_fma(-w[k], lik, w[i]);
+          const double nl = phf_fma(beta, w[i], lik);
+          PHF_LSET(i * (i + 1) / 2 + k, nl);
+          y[i] = phf_fma(nl, zn[k], y[i]);
         }
+        y[k] = y[k] + zn[k];
       }
       sc = phf_exp_fast_k(0.5 * loga, k_exp);
+    } else {
+      PHF_PLAIN_LU(zn, y);
     }
     // ---- thinning + sample store (:502-503) ----
     if (--until_save == 0) {
@@ -187,6 +231,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   for (int e = 0; e < TRI; ++e) PHF_SP(2 * D + 1 + e) = PHF_LGET(e);
   PHF_SP(2 * D + 1 + TRI) = loga;
   PHF_SP(2 * D + 2 + TRI) = nacc;
+#undef PHF_PLAIN_LU
 #undef PHF_LGET
 #undef PHF_LSET
 #undef PHF_SP
@@ -357,18 +402,42 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
         }
       }
     }
-    // ---- proposal theta* = theta + e^(loga/2) L z, own rows (PyHillFit.py:485); then every lane gets the whole vector ----
+    // ---- proposal theta* = theta + e^(loga/2) L sqrt(D) z, own rows (PyHillFit.py:485); then every lane gets the whole vector ----
     double star[D];
     {
+      // u = sqrt(d) z: each lane takes the square root of ITS rows' diagonals (one instruction stream: A square roots, not D)
+      double u_o[A], u[D];
+#pragma unroll
+      for (int a_ = 0; a_ < A; ++a_) {
+        u_o[a_] = 0.0;
+        if (PHF_HAS_ROW(a_)) {
+          const double d_e = PHF_L2(a_, 2 * a_);                                 // lane 0: its diagonal d; lane 1: an off-diagonal
+          double d_own = d_e;
+          if (2 * a_ + 1 < D) { const double d_o = PHF_L2D(a_); d_own = h ? d_o : d_e; }
+          const double z_own = (2 * a_ + 1 < D) ? (h ? z[2 * a_ + 1] : z[2 * a_]) : z[2 * a_];
+          u_o[a_] = phf_sqrt_nonneg(d_own) * z_own;
+        }
+      }
+#pragma unroll
+      for (int a_ = 0; a_ < A; ++a_) {
+        u[2 * a_] = PHF_FROM_LANE(0, u_o[a_]);
+        if (2 * a_ + 1 < D) u[2 * a_ + 1] = PHF_FROM_LANE(1, u_o[a_]);
+      }
       double star_o[A];
 #pragma unroll
       for (int a_ = 0; a_ < A; ++a_) {
         star_o[a_] = 0.0;
         if (PHF_HAS_ROW(a_)) {
-          double v = -0.0;                                 // fma(L, z, -0) == L * z bit for bit: lane 0's row starts one column later
-          if (2 * a_ + 1 < D) { if (h) v = PHF_L2D(a_) * z[2 * a_ + 1]; }
+          // row i = 2a+h: v = (sum over k < i, ascending, of L_ik u_k, from +0) + u_i.  Slot (a, 2a) is lane 1's element (2a+1, 2a)
+          // but lane 0's DIAGONAL: lane 0 multiplies u_2a by zero there (fma(0, u, v) == v; a zero's sign cannot reach theta*)
+          double v = 0.0;
 #pragma unroll
-          for (int k = 2 * a_; k >= 0; --k) v = phf_fma(PHF_L2(a_, k), z[k], v);
+          for (int k = 0; k < 2 * a_; ++k) v = phf_fma(PHF_L2(a_, k), u[k], v);
+          {
+            const double e = PHF_L2(a_, 2 * a_);
+            v = phf_fma(h ? e : 0.0, u[2 * a_], v);
+          }
+          v = v + u_o[a_];
           star_o[a_] = phf_fma(sc, v, th[a_]);
         }
       }
@@ -389,45 +458,44 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
       lt = lt_star;
     }
     nacc += acc ? 1.0 : 0.0;
-    // ---- adaptation (:495-501): rank-one update of the factor; a column's rotation by both lanes, own rows rotated ----
+    // ---- adaptation (:495-501): rank-one update of L D L' (PHF_LDL_COLUMN); a column's (dn, beta, alpha) by both lanes from the
+    // owner's p and d, every lane then updates its own rows ----
     if (t > a.cfg.adapt_start) {
       const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
       const double omg = 1.0 - gs;
-      const double sqa = phf_sqrt_pos(omg), sqg = phf_sqrt_pos(gs);
       double w[A];
 #pragma unroll
       for (int a_ = 0; a_ < A; ++a_) {
-        w[a_] = sqg * (th[a_] - mean[a_]);
+        w[a_] = th[a_] - mean[a_];
         mean[a_] = phf_fma(gs, th[a_], omg * mean[a_]);
       }
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
+      double alpha = gs;
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         const int m = k >> 1;
         const bool even = (k & 1) == 0;                    // owner of the diagonal: lane 0 (even k: row 2m) or lane 1 (row 2m+1)
-        const bool below = even && (k + 1 < D);            // even k: lane 1's element of pair-row m is L[k+1][k], a row to rotate
-        double t_own = 0.0;
-        if (even) { if (below || h == 0) t_own = sqa * PHF_L2(m, k); }
-        else { if (h) t_own = sqa * PHF_L2D(m); }
-        const double tkk = PHF_FROM_LANE(even ? 0 : 1, t_own);
-        const double wk = PHF_FROM_LANE(even ? 0 : 1, w[m]);
-        const double r = phf_sqrt_nonneg(phf_fma(tkk, tkk, wk * wk));
-        const double inv = (r > 0.0) ? phf_rcp(r) : 0.0;
-        const double cs = (r > 0.0) ? tkk * inv : 1.0;
-        const double sn = wk * inv;
+        const bool below = even && (k + 1 < D);            // even k: lane 1's element of pair-row m is L[k+1][k], a row to update
+        double e_own = 0.0;                                // slot (m, k): lane 0's d_k (even k) / lane 1's L[k+1][k]; or lane 1's d_k (odd k)
+        if (even) { if (below || h == 0) e_own = PHF_L2(m, k); }
+        else { if (h) e_own = PHF_L2D(m); }
+        const double dcur = PHF_FROM_LANE(even ? 0 : 1, e_own);
+        const double pk = PHF_FROM_LANE(even ? 0 : 1, w[m]);
+        double dn, beta;
+        PHF_LDL_COLUMN(omg, alpha, pk, dcur, dn, beta);
         if (below) {
-          const double nl = phf_fma(cs, t_own, sn * w[m]);
-          const double nw = phf_fma(cs, w[m], -(sn * t_own));
-          PHF_L2(m, k) = h ? nl : r;
+          const double nw = phf_fma(-pk, e_own, w[m]);
+          const double nl = phf_fma(beta, nw, e_own);
+          PHF_L2(m, k) = h ? nl : dn;
           w[m] = nw;                                       // lane 0's w[m] is not read again
-        } else if (even) { if (h == 0) PHF_L2(m, k) = r; }
-        else { if (h) PHF_L2D(m) = r; }
+        } else if (even) { if (h == 0) PHF_L2(m, k) = dn; }
+        else { if (h) PHF_L2D(m) = dn; }
 #pragma unroll
         for (int a_ = m + 1; a_ < A; ++a_) {
           if (PHF_HAS_ROW(a_)) {
-            const double tik = sqa * PHF_L2(a_, k);
-            PHF_L2(a_, k) = phf_fma(cs, tik, sn * w[a_]);
-            w[a_] = phf_fma(cs, w[a_], -(sn * tik));
+            const double lik = PHF_L2(a_, k);
+            w[a_] = phf_fma(-pk, lik, w[a_]);
+            PHF_L2(a_, k) = phf_fma(beta, w[a_], lik);
           }
         }
       }
@@ -540,8 +608,8 @@ __global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
-    for (int j = 0; j <= i; ++j)   // factor of diag(cov_scale |theta0|)  (PyHillFit.py:431)
-      sp[(size_t)(2 * D + 1 + i * (i + 1) / 2 + j) * nchains] = (i != j) ? 0.0 : phf_sqrt(a.cov_scale * __builtin_fabs(th[i]));
+    for (int j = 0; j <= i; ++j)   // L D L' factors of diag(cov_scale |theta0|)  (PyHillFit.py:431): L = I, d on the diagonal slots
+      sp[(size_t)(2 * D + 1 + i * (i + 1) / 2 + j) * nchains] = (i != j) ? 0.0 : a.cov_scale * __builtin_fabs(th[i]);
   sp[(size_t)(2 * D + 1 + TRI) * nchains] = 0.0;
   sp[(size_t)(2 * D + 2 + TRI) * nchains] = 0.0;
   if (a.row0) {
@@ -657,12 +725,14 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
     const phf_logred lu = phf_log_reduce(u);
     const double log_u = phf_log_from_recip(u, lu, phf_rcp(2.0 + lu.f), k_log);
     __syncthreads();
-    // ---- proposal theta* = theta + e^(loga/2) L z: rows lane, lane+64, ... ----
+    // ---- proposal theta* = theta + e^(loga/2) L sqrt(D) z: u = sqrt(d) z in place, then rows lane, lane+64, ... ----
+    for (int i = lane; i < D; i += kBlock) s_z[i] = phf_sqrt_nonneg(sLm[i * (i + 1) / 2 + i]) * s_z[i];
+    __syncthreads();
     for (int i = lane; i < D; i += kBlock) {
       const double* row = sLm + i * (i + 1) / 2;
-      double v = row[i] * s_z[i];
-      for (int k = i - 1; k >= 0; --k) v = phf_fma(row[k], s_z[k], v);
-      s_star[i] = phf_fma(sc, v, s_th[i]);
+      double v = 0.0;
+      for (int k = 0; k < i; ++k) v = phf_fma(row[k], s_z[k], v);
+      s_star[i] = phf_fma(sc, v + s_z[i], s_th[i]);
     }
     __syncthreads();
     // ---- target: one experiment per lane, sums in experiment order ----
@@ -687,33 +757,30 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
     }
     nacc += acc ? 1.0 : 0.0;
     __syncthreads();
-    // ---- adaptation: rank-one update of the factor, column by column; rows of a column in parallel ----
+    // ---- adaptation: rank-one update of L D L' (PHF_LDL_COLUMN), column by column; rows of a column in parallel ----
     if (t > a.cfg.adapt_start) {
       const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
       const double omg = 1.0 - gs;
-      const double sqa = phf_sqrt_pos(omg), sqg = phf_sqrt_pos(gs);
       double* s_w = s_z;
       for (int i = lane; i < D; i += kBlock) {
         const double thi = s_th[i], mi = s_mean[i];
-        s_w[i] = sqg * (thi - mi);
+        s_w[i] = thi - mi;
         s_mean[i] = phf_fma(gs, thi, omg * mi);
       }
       loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
       __syncthreads();
+      double alpha = gs;                                          // the same chain in every lane
       for (int k = 0; k < D; ++k) {
-        const double wk = s_w[k];
-        const double tkk = sqa * sLm[k * (k + 1) / 2 + k];
-        const double r = phf_sqrt_nonneg(phf_fma(tkk, tkk, wk * wk));
-        const double inv = (r > 0.0) ? phf_rcp(r) : 0.0;
-        const double cs = (r > 0.0) ? tkk * inv : 1.0;
-        const double sn = wk * inv;
-        __syncthreads();                                          // everybody has read L_kk and w_k
-        if (lane == 0) sLm[k * (k + 1) / 2 + k] = r;
+        const double pk = s_w[k];
+        double dn, beta;
+        PHF_LDL_COLUMN(omg, alpha, pk, sLm[k * (k + 1) / 2 + k], dn, beta);
+        __syncthreads();                                          // everybody has read d_k and w_k
+        if (lane == 0) sLm[k * (k + 1) / 2 + k] = dn;
         for (int i = k + 1 + lane; i < D; i += kBlock) {
-          const double tik = sqa * sLm[i * (i + 1) / 2 + k];
-          const double wi = s_w[i];
-          sLm[i * (i + 1) / 2 + k] = phf_fma(cs, tik, sn * wi);
-          s_w[i] = phf_fma(cs, wi, -(sn * tik));
+          const double lik = sLm[i * (i + 1) / 2 + k];
+          const double wi = phf_fma(-pk, lik, s_w[i]);
+          s_w[i] = wi;
+          sLm[i * (i + 1) / 2 + k] = phf_fma(beta, wi, lik);
         }
         __syncthreads();                                          // w_{k+1} is final before the next column reads it
       }
@@ -766,7 +833,7 @@ __global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a)
     const double v = a.theta0[(size_t)i * nch + g];
     sp[(size_t)i * nch] = v; sp[(size_t)(D + 1 + i) * nch] = v;
     for (int j = 0; j <= i; ++j)
-      sp[(size_t)(2 * D + 1 + i * (i + 1) / 2 + j) * nch] = (i != j) ? 0.0 : phf_sqrt(a.cov_scale * __builtin_fabs(v));
+      sp[(size_t)(2 * D + 1 + i * (i + 1) / 2 + j) * nch] = (i != j) ? 0.0 : a.cov_scale * __builtin_fabs(v);
   }
   PHF_KFETCH_V(k_exp, phf_k_exp, 10);
   PHF_KFETCH_V(k_log, phf_k_log, 7);

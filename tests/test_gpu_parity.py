@@ -428,7 +428,7 @@ def test_thermodynamic_integration_against_the_reference_pipeline(gpu, dr):
             print("G6 %s-%s model %d: per-rung ratios: max %.2f at rung %d, %d of %d above 1: %s" % (
                 entry["drug"], entry["channel"], model, ratio.max(), int(ratio.argmax()), int((ratio >= 1).sum()), len(ratio),
                 [(int(k), round(float(ratio[k]), 2), round(float(log_py[k]), 3), round(float(want[k]), 3), round(float(se[k]), 4)) for k in np.argsort(-ratio)[:4]]))
-            assert ratio.max() < 1.5 and np.mean(ratio < 1) >= 0.9, (entry["drug"], model, ratio.max(), int(ratio.argmax()))
+            assert ratio.max() < 1.0, (entry["drug"], model, ratio.max(), int(ratio.argmax()))         # every rung (observed: <= 0.69)
             E[model] = float(dr.trapezium_rule(temps, log_py))
             w = np.zeros(len(temps)); w[1:] += 0.5 * np.diff(temps); w[:-1] += 0.5 * np.diff(temps)   # trapezium weights
             se_E = float(np.sqrt(np.sum((w * se) ** 2)))

@@ -173,8 +173,8 @@ def test_hierarchical_target_across_the_tail_cut_against_the_independent_oracle(
 
 
 def test_hierarchical_factor_update_is_the_reference_covariance_recursion(oracle_pair):
-    """the twin carries the Cholesky factor and applies cov <- (1-g) cov + g v v' (PyHillFit.py:498-499) as a rank-one
-    update: L L' must equal the covariance obtained by iterating the reference formula on the same accepted states"""
+    """the twin carries the covariance as L diag(d) L' and applies cov <- (1-g) cov + g v v' (PyHillFit.py:498-499) as a rank-one
+    update of the factors: L D L' must equal the covariance obtained by iterating the reference formula on the same accepted states"""
     p = oracle_pair("Amiodarone", "hERG")
     shapes, scales, locs = orc.hierarchical_prior_params()
     pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
@@ -194,8 +194,7 @@ def test_hierarchical_factor_update_is_the_reference_covariance_recursion(oracle
             v = (th - mean)[None, :]
             cov = (1 - gs) * cov + gs * np.dot(v.T, v)
             mean = (1 - gs) * mean + gs * th
-    L = np.zeros((d, d)); L[np.tril_indices(d)] = st[2 * d + 1:2 * d + 1 + d * (d + 1) // 2]
-    np.testing.assert_allclose(L @ L.T, cov, rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(co.hier_state_covariance(st, d), cov, rtol=1e-9, atol=1e-14)
     np.testing.assert_allclose(st[d + 1:2 * d + 1], mean, rtol=1e-12)
     assert 0.05 < st[-1] / T < 0.7 and (np.diff(chain[:, 0]) != 0).sum() > 200
 
@@ -277,8 +276,8 @@ def test_single_level_loop_replays_reference_statements(run, oracle_pair):
 
 @pytest.mark.parametrize("run", ["hier_amio", "hier_amit"])
 def test_hierarchical_loop_replays_reference_statements(run, oracle_pair):
-    """python/PyHillFit.py:431-511 from the reference's own statements (Ne = 3 and 6): same accept sequence and chain; the factor the
-    twin carries squares to the reference's final covariance"""
+    """python/PyHillFit.py:431-511 from the reference's own statements (Ne = 3 and 6): same accept sequence and chain; the factors the
+    twin carries (L, d) multiply out to the reference's final covariance"""
     g, meta = _g9()
     m = next(r for r in meta["hierarchical"] if r["name"] == run)
     p = oracle_pair(m["drug"], m["channel"])
@@ -295,7 +294,6 @@ def test_hierarchical_loop_replays_reference_statements(run, oracle_pair):
     _close(chain[:, :d], want[:, :d], 0)
     _close(chain[:, d], want[:, d], 1e-11)
     final = g[run + "_final"]
-    L = np.zeros((d, d)); L[np.tril_indices(d)] = st[2 * d + 1:2 * d + 1 + d * (d + 1) // 2]
-    np.testing.assert_allclose(L @ L.T, final[:d * d].reshape(d, d), rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(co.hier_state_covariance(st, d), final[:d * d].reshape(d, d), rtol=1e-8, atol=1e-13)
     np.testing.assert_allclose(st[d + 1:2 * d + 1], final[d * d:d * d + d], rtol=1e-12)
     assert st[2 * d + 1 + d * (d + 1) // 2] == pytest.approx(final[-2], rel=1e-11)

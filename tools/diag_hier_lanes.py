@@ -15,7 +15,8 @@ for d in dr.drugs:
         ne, _, ex = dr.load_crumb_data(d, c)
         groups.setdefault(len(ex), []).append(ex)
 only = [int(x) for x in os.environ.get("PHF_DIAG_NE", "3,4,5,6").split(",")]
-for C, I in ((1024, 500), (64, 5000)):
+shapes = [int(x) for x in os.environ.get("PHF_DIAG_SHAPES", "1024,64").split(",")]
+for C, I in [(c_, 500 if c_ >= 512 else 5000) for c_ in shapes]:
     for ne, exs in sorted(groups.items()):
         if ne not in only:
             continue
