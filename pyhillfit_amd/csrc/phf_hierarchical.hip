@@ -159,7 +159,12 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
       lt = lt_star;
     }
     nacc += acc ? 1.0 : 0.0;
-    // ---- the draws of iteration t + 1 (a function of (chain, t + 1) alone): independent work next to the sweep's dependent chains ----
+    // ---- the factors for the sweep, read from LDS HERE — ahead of the draws, whose ~700 instructions cover the LDS latency a lone
+    // wavefront would otherwise wait out element by element inside the sweep (same box: Ne = 3 group 13.80 -> 13.62 ms, Ne = 4 6.37 ->
+    // 6.17, C4 19.11 -> 18.86) — and the draws of iteration t + 1 (a function of (chain, t + 1) alone) ----
+    double Lr[TRI];
+#pragma unroll
+    for (int e = 0; e < TRI; ++e) Lr[e] = PHF_LGET(e);
     double zn[D];
     log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, k_sc, 1, zn, 1);
     // ---- adaptation (:495-501): cov <- (1-g) cov + g v v' applied to the L D L' factors as a rank-one update (PHF_LDL_COLUMN),
@@ -181,12 +186,12 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         double dn, beta;
-        PHF_LDL_COLUMN(omg, alpha, w[k], PHF_LGET(k * (k + 1) / 2 + k), dn, beta);
+        PHF_LDL_COLUMN(omg, alpha, w[k], Lr[k * (k + 1) / 2 + k], dn, beta);
         PHF_LSET(k * (k + 1) / 2 + k, dn);
         zn[k] = phf_sqrt_nonneg(dn) * zn[k];               // u_k of the next proposal
 #pragma unroll
         for (int i = k + 1; i < D; ++i) {
-          const double lik = PHF_LGET(i * (i + 1) / 2 + k);
+          const double lik = Lr[i * (i + 1) / 2 + k];
           w[i] = phf_fma(-w[k], lik, w[i]);
           const double nl = phf_fma(beta, w[i], lik);
           PHF_LSET(i * (i + 1) / 2 + k, nl);

@@ -20,7 +20,7 @@ if want c5; then step bench_c5 400 python bench.py --workload c5 --steps 5 --war
 if want two_ranks; then PHF_BENCH_BACKEND=gloo step bench_2rank 500 python bench.py --gpus 2 --steps 5 --warmup 3 --chains 2048 --no-cpu-baseline; fi
 cd /tmp && export TMPDIR=/tmp
 if want rocprof; then
-  step rocprof 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -- python $R/bench.py --steps 5 --warmup 5 --no-cpu-baseline
+  step rocprof 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -- python $R/bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-other-workloads
   for W in ${PHF_ROCPROF_EXTRA:-}; do step rocprof_$W 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$W -- python $R/bench.py --workload $W --steps 3 --warmup 4 --no-cpu-baseline; done
 fi
 if want pmc; then
@@ -30,7 +30,7 @@ if want pmc; then
              "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES SQ_INST_CYCLES_VMEM" \
              "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
     i=$((i+1))
-    step pmc_${W}_$i 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${W}_$i -- python $R/bench.py --workload $W --steps 3 --warmup 2 --no-cpu-baseline
+    step pmc_${W}_$i 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${W}_$i -- python $R/bench.py --workload $W --steps 3 --warmup 2 --no-cpu-baseline --no-other-workloads
   done
   (cd $R && rm -f gpurun_out/pmc_${W}_summary.txt && python tools/pmc_summary.py gpurun_out/pmc_${W}_[0-9]*/ > gpurun_out/pmc_${W}_summary.txt 2>&1; tail -n 20 gpurun_out/pmc_${W}_summary.txt)
  done
