@@ -24,6 +24,27 @@ inline int phf_check_launch(const char* what) {
   return PHF_ERR_HIP;
 }
 
+// The kernels advance moments with hardware fp64 atomics (global_atomic_add_f64 without return) and hand blocks of a queued launch
+// over with agent-scope release / acquire: both are only guaranteed on ordinary (coarse-grained) device memory.  A buffer that is
+// host-pinned, managed, or no HIP allocation at all is refused here instead of giving silently wrong sums (include/pyhillfit_amd.h,
+// "MEMORY KIND").  NULL passes: optional buffers are checked for NULL by their callers.
+inline int phf_require_device_memory(const void* p, const char* what) {
+  if (!p) return PHF_OK;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    std::snprintf(phf_error_buffer(), kPhfErrorBufferSize, "%s: not a HIP allocation (device memory from hipMalloc is required)", what);
+    return PHF_ERR_INVALID_ARGUMENT;
+  }
+  if (attr.type != hipMemoryTypeDevice) {
+    std::snprintf(phf_error_buffer(), kPhfErrorBufferSize,
+                  "%s: must be ordinary device memory (hipMalloc), not host-pinned or managed memory: fp64 atomics and "
+                  "release/acquire hand-overs are not guaranteed there", what);
+    return PHF_ERR_INVALID_ARGUMENT;
+  }
+  return PHF_OK;
+}
+
 // phf_simd_count() (public header): SIMDs of the current device, looked up once per device; defined in phf_capi.hip
 
 #endif  // PHF_COMMON_H

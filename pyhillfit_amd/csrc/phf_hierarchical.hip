@@ -1068,6 +1068,8 @@ int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* pro
   if (t_begin < 0 || t_end < t_begin || t_end > 0xffffffffLL) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad iteration range");
   if (t_end > cfg->adapt_start && !cfg->gamma) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "gamma table required once adapting");
   if (t_end == t_begin) return PHF_OK;
+  if (int rc = phf_require_device_memory(state, "state")) return rc;
+  if (int rc = phf_require_device_memory(moments, "moments")) return rc;
   HierArgs a{};
   a.pts = *pts; a.prob = *prob; a.prior = *prior; a.cfg = *cfg; a.t_begin = t_begin; a.t_end = t_end; a.state = state; a.rows = rows;
   a.moments = moments; a.moments_after = moments_after;

@@ -498,6 +498,9 @@ static int advance_impl(const phf_points* pts, const phf_problems* prob, const p
   // gamma[0] is read (and multiplied by zero) on every iteration before the adaptation starts: the table is always needed
   if (!cfg->gamma) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "gamma table required (gamma[0] is read even before adaptation starts)");
   if (t_end == t_begin) return PHF_OK;
+  if (int rc = phf_require_device_memory(state, "state")) return rc;
+  if (int rc = phf_require_device_memory(moments, "moments")) return rc;
+  if (int rc = phf_require_device_memory(queue, "queue workspace")) return rc;
   AdvanceArgs a{*pts, *prob, *cfg, t_begin, t_end, state, rows, moments, moments_after, 0, nullptr, 0};
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
   const int64_t nblocks = (int64_t)a.blocks_per_problem * prob->num_problems;

@@ -162,6 +162,35 @@ def test_a_drained_queued_launch_is_an_error_not_stale_chains(gpu, dr):
             call()
 
 
+def test_state_and_moments_must_be_device_memory(gpu, dr):
+    """the ABI's memory-kind rule (include/pyhillfit_amd.h): a host-pinned state or moments buffer is refused with an error code —
+    fp64 atomics and the queued launch's release/acquire hand-overs are not guaranteed there — instead of sampling into it"""
+    import ctypes as C
+    from pyhillfit_amd import _lib
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    packed = dr.pack_single_level([("Amiodarone", "hERG")])
+    s = SingleLevelSampler(packed, 2, [0], [1.0], 64, thinning=5, seed=1, device=gpu)
+    s.init([6.0, 0.8, 8.0])
+    good = s.state
+    s.state = torch.zeros(good.shape, dtype=torch.float64).pin_memory()
+    with pytest.raises(_lib.PhfError, match="device memory"):
+        s.advance(10, save=False)
+    s.state = good
+    s.enable_moments(0)
+    s.moments = torch.zeros(s.moments.shape, dtype=torch.float64).pin_memory()
+    with pytest.raises(_lib.PhfError, match="moments"):
+        s.advance(10, save=False)
+    s.moments = None
+    assert s.advance(10).shape == (2, 1, 4, 64)                    # and the sampler is still usable
+    ex = dr.load_crumb_data("Amiodarone", "hERG")[2]
+    hs = H.HierarchicalSampler(H.PackedHierPoints([ex]), [0], 64, device=gpu)
+    hs.init(np.concatenate([[1., 5., 6., .3], np.tile([6.0, 0.8], 3), [8.0]])[None])
+    hs.state = torch.zeros(hs.state.shape, dtype=torch.float64).pin_memory()
+    with pytest.raises(_lib.PhfError, match="device memory"):
+        hs.advance(10, save=False)
+
+
 def test_queued_launch_at_the_bench_shape(gpu, dr):
     """the C3 launch exactly as bench.py runs it — 210 pairs x 4 096 chains = 13 440 blocks over 2 048 persistent wavefronts, 2 000
     iterations in 4 quanta, three launches back to back — ends in the same state and moments as the plain launches"""
