@@ -246,6 +246,20 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
   const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
   const int n_pts = fixed_n ? n_expts * fixed_n : expt_start[n_expts];
   const int nl = 9 + n_expts, n0 = (nl + 1) / 2;
+  /* fixed_n > 0 (straight-line bodies): this half's points are read HERE, a few hundred instructions ahead of their use, so that a
+   * wavefront that has its SIMD to itself does not wait out the LDS latency pair by pair inside the point loop */
+  double plc[32], py[32];                                         /* [experiment][point of the half]: fixed_n <= 8 in kernels with Ne <= 8 */
+  if (fixed_n) {
+    PHF_UNROLL
+    for (int i = 0; i < n_expts; ++i) {
+      PHF_UNROLL
+      for (int p = 0; p < fixed_n / 2; ++p) {
+        const int j = i * fixed_n + (h ? 1 : 0) * (fixed_n / 2) + p;
+        plc[i * (fixed_n / 2) + p] = lc[j];
+        py[i * (fixed_n / 2) + p] = y[j];
+      }
+    }
+  }
   /* ---- this half's share of the first batch of logarithms, 1/sigma and 1/s: one division ---- */
   double ga[10 + PHF_HIER_CAP], gw[10 + PHF_HIER_CAP];            /* arguments and weights of all 9 + Ne (cheap), then the pick */
   double xl[5];
@@ -338,11 +352,13 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
     PHF_UNROLL
     for (int p = 0; p < npairs; ++p, j += 2) {                               /* two points at a time */
       const phf_ktab ke = k_exp;
-      const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
-      const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke, 0);
+      const double lc0 = fixed_n ? plc[i * (fixed_n / 2) + 2 * p] : lc[j], lc1 = fixed_n ? plc[i * (fixed_n / 2) + 2 * p + 1] : lc[j + 1];
+      const double y0 = fixed_n ? py[i * (fixed_n / 2) + 2 * p] : y[j], y1 = fixed_n ? py[i * (fixed_n / 2) + 2 * p + 1] : y[j + 1];
+      const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc0 - ln_ic50), 40.0), ke, 0);
+      const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc1 - ln_ic50), 40.0), ke, 0);
       const double inv = phf_rcp(d0 * d1);
       const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
-      const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
+      const double r0 = y0 - pred0, r1 = y1 - pred1;
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
       mass *= phf_trunc_mass_x2_ke(pred0, pred1, inv_s, k_exp, ke_given, have_ke, skip_tails);
     }
