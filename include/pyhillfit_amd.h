@@ -200,11 +200,13 @@ typedef struct phf_hier_prior {
 } phf_hier_prior;
 #endif
 
-/* doubles of per-chain state: theta[dim], log-target, mean[dim], L[dim(dim+1)/2] (lower Cholesky factor of the
- * adapted covariance, packed row-major), loga, accepted-count.  The factor is carried instead of the covariance:
- * the reference's update cov <- (1-g) cov + g v v' (PyHillFit.py:498-499) is applied to it as a rank-one
- * update, which is the same matrix in exact arithmetic and needs one pass over dim(dim+1)/2 numbers per iteration
- * instead of an O(dim^3) refactorisation.                                                                     */
+/* doubles of per-chain state: theta[dim], log-target, mean[dim], F[dim(dim+1)/2], loga, accepted-count.
+ * F holds the adapted covariance as cov = L diag(d) L' — L unit lower triangular — in ONE packed lower triangle (row-major):
+ * slot (i, j < i) = L_ij, slot (i, i) = d_i.  The factors are carried instead of the covariance: the reference's update
+ * cov <- (1-g) cov + g v v' (PyHillFit.py:498-499) is applied to them as d <- (1-g) d followed by a rank-one update (Gill, Golub,
+ * Murray & Saunders 1974, method C1), which is the same matrix in exact arithmetic and needs one pass over dim(dim+1)/2 numbers
+ * per iteration — two fused multiply-adds per element, no square root — instead of an O(dim^3) refactorisation; the proposal
+ * (PyHillFit.py:485) is theta + e^(loga/2) L sqrt(d) z.  (ABI <= 3 carried a Cholesky factor in the same slots.)          */
 int phf_hierarchical_state_size(int n_expts);
 
 /* Start chains: theta = mean = theta0, cov = diag(cov_scale*|theta0|) (PyHillFit.py:431, cov_scale 0.01), loga = 0.

@@ -2,8 +2,8 @@
 //
 // One lane = one Markov chain of dimension dim = 5 + 2 Ne (11..17 for the Crumb set); a wavefront advances 64
 // chains of the same (drug, channel) pair in lock-step.  The kernel is compiled per Ne so that theta, mean and the
-// proposal live in registers with static indices.  What does not fit in registers is the proposal factor: the
-// lower Cholesky factor L of the adapted covariance (dim(dim+1)/2 = 66..153 doubles per chain) lives in LDS as
+// proposal live in registers with static indices.  What does not fit in registers is the adapted covariance: its factors
+// cov = L diag(d) L' (PHF_LDL_COLUMN below; dim(dim+1)/2 = 66..153 doubles per chain) live in LDS as
 // L[element][lane] (stride 64 doubles: every ds_read/ds_write is conflict-free, 34..78 KB per wavefront) for the
 // whole launch, so that its two passes per iteration (y = L z, and the rank-one adaptation update) cost no HBM
 // traffic at all.  HBM sees the state once per launch and the thinned samples.
@@ -61,8 +61,8 @@ struct HierArgs {
   double* row0;
 };
 
-// One lane per chain: the whole factor in LDS ([tri][64] doubles, 34..78 KB per wavefront: at most 4 wavefronts per CU, one per
-// SIMD) and all 512 registers for the iteration.
+// One lane per chain: the factors (unit lower L, d in the diagonal slots) in LDS ([tri][64] doubles, 34..78 KB per wavefront: at most
+// 4 wavefronts per CU, one per SIMD) and all 512 registers for the iteration.
 template <int NE>
 struct Lds {
   static constexpr int dim = 5 + 2 * NE;
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(kBlock, 1) void hier_advance_kernel(const HierArgs 
 //               registers, half the LDS (A^2 slots of 64 doubles: 18 KB per wavefront at Ne = 3 — eight wavefronts per CU);
 //   the draws   Philox block b is evaluated by lane b mod 2 (normals 4b..4b+3, or the accept uniform), broadcast by DPP;
 //   the target  lane h computes half h of the log target (phf_hier_model.h), one cross-lane addition joins the halves;
-//   the factor  y = L z and the Givens sweep row by row: a column's rotation (one square root, one reciprocal) is computed by
-//               both lanes from the owner's diagonal element, every lane then rotates its own rows.
+//   the factor  y = L sqrt(d) z and the rank-one update row by row: a column's coefficients (dn, beta, alpha: one reciprocal) are
+//               computed by both lanes from the owner's p and d, every lane then updates its own rows.
 // Every number is produced by the same operations in the same order as in the one-lane kernel and the twin (rows of a column
 // are independent; the halves of the target are defined per half): chains, states and moments are bit-identical.
 //
@@ -654,7 +654,7 @@ __device__ __forceinline__ double gen_target(const HierArgs& a, int ne, int pair
 // ---------------------------------------------------------------------------------------------------------------
 // One WAVEFRONT per chain, for pairs with many experiments (dim = 5 + 2 Ne up to 133): the chain's factor (dim(dim+1)/2
 // doubles: 44.5 KB at dim 105), theta, mean, proposal and normals live in LDS; the 64 lanes take one experiment each in
-// the target (phf_hier_experiment_terms) and the rows lane, lane+64, ... of the factor in the proposal and in the Givens
+// the target (phf_hier_experiment_terms) and the rows lane, lane+64, ... of the factor in the proposal and in the update
 // sweep.  Every element is computed by the same operations in the same order as in the twin (the per-experiment sums are
 // added in experiment order by every lane), so results are bit-identical.  (A first version kept the state in HBM, 16 chains
 // per block: 1.2 ms per iteration at dim 105 against tens of us here.  It was unreachable once this kernel covered every
