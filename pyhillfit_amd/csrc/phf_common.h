@@ -26,15 +26,14 @@ inline int phf_check_launch(const char* what) {
 
 // The kernels advance moments with hardware fp64 atomics (global_atomic_add_f64 without return) and hand blocks of a queued launch
 // over with agent-scope release / acquire: both are only guaranteed on ordinary (coarse-grained) device memory.  A buffer that is
-// host-pinned, managed, or no HIP allocation at all is refused here instead of giving silently wrong sums (include/pyhillfit_amd.h,
+// host-pinned or managed is refused here instead of giving silently wrong sums (include/pyhillfit_amd.h,
 // "MEMORY KIND").  NULL passes: optional buffers are checked for NULL by their callers.
 inline int phf_require_device_memory(const void* p, const char* what) {
   if (!p) return PHF_OK;
   hipPointerAttribute_t attr;
   if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-    (void)hipGetLastError();
-    std::snprintf(phf_error_buffer(), kPhfErrorBufferSize, "%s: not a HIP allocation (device memory from hipMalloc is required)", what);
-    return PHF_ERR_INVALID_ARGUMENT;
+    (void)hipGetLastError();       // the runtime cannot classify the address (e.g. a range mapped through the virtual-memory API):
+    return PHF_OK;                 // nothing is known against it
   }
   if (attr.type != hipMemoryTypeDevice) {
     std::snprintf(phf_error_buffer(), kPhfErrorBufferSize,
