@@ -217,9 +217,11 @@ PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl
  * `h` is a literal at the call site (twin, one-lane kernels: the selects below fold away) or the lane's parity (two-lane
  * kernel: each select is a v_cndmask pair; only ARGUMENTS and WEIGHTS are selected, never results of expensive work).
  * n_expts must be a compile-time constant at the call site when theta lives in registers.
- * fixed_n > 0: every experiment has exactly fixed_n points (a literal: the point loops unroll, an iteration of the sampler is
- * straight-line code; 147 of the 210 Crumb pairs are 3 experiments x 4 points); 0: experiment i's points are
- * expt_start[i] .. expt_start[i+1]-1.  Same operations in the same order either way.                                      */
+ * fixed_n > 0: a SHAPE CODE, PHF_HIER_SHAPE(per, last) — every experiment has exactly `per` points (a multiple of 4), except that
+ * the last one has `last` (1..3) if that is not 0 — all literals: the point loops unroll, an iteration of the sampler is
+ * straight-line code (147 of the 210 Crumb pairs are 3 experiments x 4 points, 32 more are 4 + 4 + 4 + 1); 0: experiment i's
+ * points are expt_start[i] .. expt_start[i+1]-1.  Same operations in the same order either way.                            */
+#define PHF_HIER_SHAPE(per, last) ((per) | ((last) << 4))
 #define PHF_PICK(h, x0, x1) ((h) ? (x1) : (x0))
 /* a value the optimiser must treat as computed here: keeps a pick between two ARRAY ELEMENTS a select of two registers (left to
  * itself hipcc turns it into one load with a selected index, which puts the whole array in scratch memory)               */
@@ -244,20 +246,25 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
                                    phf_ktab ke_given, int have_ke, int skip_tails) {
   const int dim = 5 + 2 * n_expts;
   const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
-  const int n_pts = fixed_n ? n_expts * fixed_n : expt_start[n_expts];
+  /* fixed_n is a SHAPE CODE (PHF_HIER_SHAPE): low 4 bits = points of every experiment (a multiple of 4), the bits above = points of the
+   * LAST experiment if it differs (1..3; then h must be a literal: the halves' shares of that experiment are unequal) */
+  const int fper = fixed_n & 15, flast = fixed_n >> 4;
+#define PHF_NI_(i_) ((flast && (i_) == n_expts - 1) ? flast : fper)                       /* points of experiment i_ */
+#define PHF_NF_(i_) ((2 * ((PHF_NI_(i_) + 2) / 4) < PHF_NI_(i_)) ? 2 * ((PHF_NI_(i_) + 2) / 4) : PHF_NI_(i_))   /* of them, half 0's */
+  const int n_pts = fixed_n ? (n_expts - 1) * fper + PHF_NI_(n_expts - 1) : expt_start[n_expts];
   const int nl = 9 + n_expts, n0 = (nl + 1) / 2;
-  /* fixed_n > 0 (straight-line bodies): this half's points are read HERE, a few hundred instructions ahead of their use, so that a
+  /* fixed shapes (straight-line bodies): this half's points are read HERE, a few hundred instructions ahead of their use, so that a
    * wavefront that has its SIMD to itself does not wait out the LDS latency pair by pair inside the point loop */
-  double plc[32], py[32];                                         /* [experiment][point of the half]: fixed_n <= 8 in kernels with Ne <= 8 */
+  double plc[32], py[32];                                         /* this half's points, experiment after experiment */
   if (fixed_n) {
+    int off = 0;
     PHF_UNROLL
     for (int i = 0; i < n_expts; ++i) {
+      const int cnt = flast ? (h ? PHF_NI_(i) - PHF_NF_(i) : PHF_NF_(i)) : fper / 2;       /* equal halves when every experiment has fper points */
+      const int j0 = i * fper + (h ? 1 : 0) * PHF_NF_(i);
       PHF_UNROLL
-      for (int p = 0; p < fixed_n / 2; ++p) {
-        const int j = i * fixed_n + (h ? 1 : 0) * (fixed_n / 2) + p;
-        plc[i * (fixed_n / 2) + p] = lc[j];
-        py[i * (fixed_n / 2) + p] = y[j];
-      }
+      for (int p = 0; p < cnt; ++p) { plc[off + p] = lc[j0 + p]; py[off + p] = y[j0 + p]; }
+      off += cnt;
     }
   }
   /* ---- this half's share of the first batch of logarithms, 1/sigma and 1/s: one division ---- */
@@ -337,23 +344,25 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
   }
   /* ---- this half's points (:117-125) ---- */
   double sse = 0.0, mass = 1.0;                                    /* mass: product of the truncation masses Phi(b) - Phi(a) of this half's points */
+  int poff = 0;                                                    /* fixed shapes: where experiment i's points start in plc / py */
   PHF_UNROLL
   for (int i = 0; i < n_expts; ++i) {
     const double pic50 = th[(4 + 2 * i) * ts], hill = th[(5 + 2 * i) * ts];
     const double ln_ic50 = PHF_LN10 * (6.0 - pic50);
-    /* this half's points of experiment i: [j, jend).  fixed_n (a multiple of 4): fixed_n / 2 each, trip counts known */
-    const int sb = fixed_n ? i * fixed_n : expt_start[i];
-    const int se = fixed_n ? (i + 1) * fixed_n : expt_start[i + 1];
-    const int nf = fixed_n ? fixed_n / 2 : 2 * ((se - sb + 2) / 4);
+    /* this half's points of experiment i: [j, jend).  Fixed shapes: the counts are literals, the points already in plc / py */
+    const int sb = fixed_n ? i * fper : expt_start[i];
+    const int se = fixed_n ? sb + PHF_NI_(i) : expt_start[i + 1];
+    const int nf = fixed_n ? PHF_NF_(i) : 2 * ((se - sb + 2) / 4);
     const int cut = sb + ((nf < se - sb) ? nf : se - sb);
     int j = sb + (h ? 1 : 0) * (cut - sb);                                   /* affine in the lane parity: one per-lane base, immediate offsets */
-    const int jend = fixed_n ? j + fixed_n / 2 : PHF_PICK(h, cut, se);
-    const int npairs = fixed_n ? fixed_n / 4 : (jend - j) / 2;
+    const int fcnt = flast ? (h ? PHF_NI_(i) - PHF_NF_(i) : PHF_NF_(i)) : fper / 2;
+    const int jend = fixed_n ? j + fcnt : PHF_PICK(h, cut, se);
+    const int npairs = fixed_n ? fcnt / 2 : (jend - j) / 2;
     PHF_UNROLL
     for (int p = 0; p < npairs; ++p, j += 2) {                               /* two points at a time */
       const phf_ktab ke = k_exp;
-      const double lc0 = fixed_n ? plc[i * (fixed_n / 2) + 2 * p] : lc[j], lc1 = fixed_n ? plc[i * (fixed_n / 2) + 2 * p + 1] : lc[j + 1];
-      const double y0 = fixed_n ? py[i * (fixed_n / 2) + 2 * p] : y[j], y1 = fixed_n ? py[i * (fixed_n / 2) + 2 * p + 1] : y[j + 1];
+      const double lc0 = fixed_n ? plc[poff + 2 * p] : lc[j], lc1 = fixed_n ? plc[poff + 2 * p + 1] : lc[j + 1];
+      const double y0 = fixed_n ? py[poff + 2 * p] : y[j], y1 = fixed_n ? py[poff + 2 * p + 1] : y[j + 1];
       const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc0 - ln_ic50), 40.0), ke, 0);
       const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc1 - ln_ic50), 40.0), ke, 0);
       const double inv = phf_rcp(d0 * d1);
@@ -362,14 +371,18 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
       mass *= phf_trunc_mass_x2_ke(pred0, pred1, inv_s, k_exp, ke_given, have_ke, skip_tails);
     }
-    if (!fixed_n && j < jend) {                                              /* at most one left */
-      const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
+    if (fixed_n ? (fcnt & 1) : (j < jend)) {                                 /* at most one left */
+      const double lcs = fixed_n ? plc[poff + fcnt - 1] : lc[j], ys = fixed_n ? py[poff + fcnt - 1] : y[j];
+      const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lcs - ln_ic50), 40.0), k_exp, 1));
       const double pred = phf_fma(-100.0, w, 100.0);
-      const double r = y[j] - pred;
+      const double r = ys - pred;
       sse = phf_fma(r, r, sse);
       mass *= phf_trunc_mass_ke(pred, inv_s, k_exp, ke_given, have_ke, skip_tails);
     }
+    poff += fcnt;
   }
+#undef PHF_NI_
+#undef PHF_NF_
   /* sum_j ln(Phi(b_j) - Phi(a_j)) as ONE logarithm of the product: every mass is in (0, 1], a half has a handful of points, so the
    * product cannot overflow and underflows only where sigma ~ 1e27 — there the half is -inf (a proposal to reject), never +inf */
   const phf_logred lm = phf_log_reduce(mass);

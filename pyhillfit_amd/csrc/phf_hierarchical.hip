@@ -256,11 +256,18 @@ __global__ __launch_bounds__(kBlock, 1) void hier_advance_kernel(const HierArgs 
   stage<NE>(a.pts, pair, s_lc, s_y, s_es);
   if (c >= a.prob.chains_per_problem) return;
   // 4 points in every experiment (147 of the 210 Crumb pairs: 3 experiments x 4 doses)?  scalar loads: a uniform branch
-  bool four_each = true;
+  bool four_each = true, four_then_one = NE == 4;          // ... or 4 + 4 + 4 + 1 (32 of the 41 pairs with four experiments)
 #pragma unroll
-  for (int i = 1; i <= NE; ++i) four_each = four_each && (a.pts.expt_start[(size_t)pair * (NE + 1) + i] == 4 * i);
-  if (four_each) hier_advance_body<NE, 4>(a, s_mem, s_lc, s_y, s_es, q, c);
-  else hier_advance_body<NE, 0>(a, s_mem, s_lc, s_y, s_es, q, c);
+  for (int i = 1; i <= NE; ++i) {
+    const int e = a.pts.expt_start[(size_t)pair * (NE + 1) + i];
+    four_each = four_each && (e == 4 * i);
+    four_then_one = four_then_one && (e == (i < NE ? 4 * i : 4 * (NE - 1) + 1));
+  }
+  if (four_each) { hier_advance_body<NE, PHF_HIER_SHAPE(4, 0)>(a, s_mem, s_lc, s_y, s_es, q, c); return; }
+  if constexpr (NE == 4) {
+    if (four_then_one) { hier_advance_body<NE, PHF_HIER_SHAPE(4, 1)>(a, s_mem, s_lc, s_y, s_es, q, c); return; }
+  }
+  hier_advance_body<NE, 0>(a, s_mem, s_lc, s_y, s_es, q, c);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
