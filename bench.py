@@ -194,6 +194,8 @@ class HierarchicalBatch(object):
                                            problem_ids=[members[k][0] for k, _ in mine], chain_offsets=[64 * b for _, b in mine], device=dev)
                 hs.init(start[[k for k, _ in mine]], cov_scale=0.01)
             self.samplers.append(hs)
+        if not self.samplers:
+            raise SystemExit("bench.py: this rank's share of the batch is empty (more ranks than (pair, 64-chain block) units)")
         self.adapt_start = max(h.adapt_start for h in self.samplers)
         self.bytes_per_iter = sum(h.Q * h.C * 8.0 * (h.d + 1) for h in self.samplers) / thinning
         self.chains = sum(h.Q * h.C for h in self.samplers)
@@ -258,6 +260,8 @@ class SingleLevelBatch(object):
         from pyhillfit_amd.sampler import SingleLevelSampler
         self.torch, self.dev = torch, dev
         kw = {} if a.queue_quanta is None else {"queue_quanta": a.queue_quanta}
+        if units is not None and len(units) == 0:
+            raise SystemExit("bench.py: this rank's share of the batch is empty (more ranks than (pair, 64-chain block) units)")
         if units is None:
             s = SingleLevelSampler(packed, 2, pair_index, temps, C, thinning=a.thinning, seed=25, chain_id_base=chain_id_base,
                                    reset_mean_at_adapt_start=tempered, device=dev, **kw)
