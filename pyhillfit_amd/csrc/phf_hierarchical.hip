@@ -33,7 +33,8 @@ __device__ __forceinline__ void phf_accumulate(double* p, double v) { (void)unsa
 // factor that rounds 1 and 2 carried: with that sweep cut out the one-lane Ne = 3 kernel ran 23 % faster although the sweep was
 // 13.5 % of its instructions (a lone wavefront exposes every dependent latency).  No square root is needed to UPDATE; the proposal
 // takes sqrt(d_k) of the eleven diagonals at the start of an iteration, where they overlap the draws.  dn = 0 (a direction that
-// has no variance and gets none: d_k = 0 and p = 0) leaves the column and alpha as they are.
+// has no variance and gets none: d_k = 0 and p = 0 — a start point with a component exactly 0 freezes that component in the
+// reference too, PyHillFit.py:431,498-499) leaves the column and alpha as they are.
 #define PHF_LDL_COLUMN(omg_, alpha_, p_, d_, dn_, beta_)                  \
   do {                                                                   \
     const double dk_ = (omg_) * (d_);                                    \

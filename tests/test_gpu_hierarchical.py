@@ -135,6 +135,39 @@ def test_two_lanes_per_chain_kernel_is_bit_identical(names, gpu, oracle_pair):
             assert np.array_equal(state[:, q, c], st), (q, c)
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_zero_variance_direction_behaves_like_the_twin(lanes, gpu, oracle_pair):
+    """a start point with a component exactly 0: the initial covariance 0.01 diag|theta0| (PyHillFit.py:431) has a zero row and
+    column — d_k = 0 in the L diag(d) L' factors — so that component is never proposed away from its start and the reference's
+    recursion (:498-499) keeps the row at zero: the component is frozen, in the reference as here.  What must hold: no division
+    by zero (dn = 0 leaves column and alpha alone), everything else adapts, kernels == twin bit for bit incl. the final factors"""
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import gamma_table
+    shapes, scales, locs = H.prior_params()
+    p = oracle_pair("Amiodarone", "hERG")
+    packed = H.PackedHierPoints([p.experiments])
+    d = 11
+    theta0 = np.array([1., 5., 6., .3, 6., .8, 6.1, .7, 0.0, .9, 8.])
+    C, T, thin, adapt = 70, 500, 5, 50
+    H.set_kernel_policy(lanes=lanes, wps=1)
+    try:
+        s = H.HierarchicalSampler(packed, [0], C, thinning=thin, seed=11, adapt_start=adapt, problem_ids=[3], device=gpu)
+        s.init(theta0[None], cov_scale=0.01)
+        chain = torch.cat([s.advance(adapt + 1), s.advance(T - adapt - 1)]).cpu().numpy()
+        state = s.state.cpu().numpy().reshape(s.S, 1, C)
+    finally:
+        H.set_kernel_policy(0, 0)
+    pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+    for c in (0, 35, C - 1):
+        st = pk.init_state(theta0, 0.01)
+        rows = pk.advance(st, 0, T, thin, adapt, gamma_table(T), seed=11, chain_id=c, problem_id=3)
+        assert np.array_equal(chain[:, 0, :, c], rows) and np.array_equal(state[:, 0, c], st), c
+        assert np.all(rows[:, 8] == 0.0) and np.isfinite(st).all()
+        cov = co.hier_state_covariance(st, d)
+        assert np.all(cov[8] == 0.0) and np.all(np.delete(np.diag(cov), 8) > 0.0)
+
+
 @pytest.mark.parametrize("C", [1, 33])
 def test_two_lane_kernel_with_one_chain_and_with_a_ragged_wavefront(C, gpu, oracle_pair):
     """what small command-line runs launch (the default policy picks the two-lane kernel): 1 chain (--num-chains 1: one lane pair of

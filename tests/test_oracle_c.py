@@ -199,6 +199,37 @@ def test_hierarchical_factor_update_is_the_reference_covariance_recursion(oracle
     assert 0.05 < st[-1] / T < 0.7 and (np.diff(chain[:, 0]) != 0).sum() > 200
 
 
+def test_hierarchical_factor_update_with_a_zero_variance_direction(oracle_pair):
+    """a start point with a component that is exactly 0 gives the reference's initial covariance 0.01 diag|theta0| (PyHillFit.py:431)
+    a zero row and column: that component is never proposed away from its start, v_k stays 0 and the reference's recursion keeps the
+    row at zero — a frozen component, in the reference as here.  The L diag(d) L' update must not divide by zero on the way
+    (dn = 0 leaves the column and alpha alone) and must give the recursion's matrix everywhere else"""
+    p = oracle_pair("Amiodarone", "hERG")
+    shapes, scales, locs = orc.hierarchical_prior_params()
+    pk = co.PackedHierPair(p.experiments, shapes, scales, locs)
+    d = pk.dim
+    theta0 = np.array([1., 5., 6., .3, 6., .8, 6.1, .7, 0.0, .9, 8.])             # pIC50_3 = 0: inside the support (pIC50_i >= -2)
+    T, adapt = 1500, 50
+    gam = co.gamma_table(T)
+    st = pk.init_state(theta0, 0.01)
+    assert np.isfinite(st[d]) and co.hier_state_covariance(st, d)[8, 8] == 0.0
+    rows = pk.advance(st, 0, T, 1, adapt, gam, seed=11, chain_id=1, problem_id=3)
+    chain = np.vstack([np.concatenate([theta0, [pk.log_target(theta0)]]), rows])
+    assert np.all(chain[:, 8] == 0.0)                                             # no variance in that direction: it cannot move
+    cov = np.diag(0.01 * np.abs(theta0)); mean = theta0.copy()
+    for t in range(1, T + 1):
+        th = chain[t, :d]
+        if t > adapt:
+            gs = gam[t - adapt]
+            v = (th - mean)[None, :]
+            cov = (1 - gs) * cov + gs * np.dot(v.T, v)
+            mean = (1 - gs) * mean + gs * th
+    got = co.hier_state_covariance(st, d)
+    assert np.isfinite(got).all() and np.all(got[8] == 0.0) and np.all(cov[8] == 0.0)
+    np.testing.assert_allclose(got, cov, rtol=1e-8, atol=1e-13)
+    assert (np.diff(chain[:, 0]) != 0).sum() > 50
+
+
 def test_hierarchical_posterior_is_consistent_with_reference_samples(oracle_pair):
     """coarse statistical pin (the reference's stored chaste/samples: 500 draws of an unseeded run):
     top-level (alpha, mu) of Amiodarone-hERG and Dofetilide-hERG"""
