@@ -84,7 +84,7 @@ PHF_HD double phf_log_from_recip(double x, phf_logred lr, double inv_den, phf_kt
 /* The two points' lower tails Phi(a) (always needed) and upper arguments b — first part of phf_trunc_terms_x2_core. */
 PHF_HD void phf_trunc_lower_x2(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab ke, int kv,
                                double* t0, double* t1, double* b0_out, double* b1_out) {
-  const double a0 = -pred0 * inv_s, b0 = (100.0 - pred0) * inv_s, a1 = -pred1 * inv_s, b1 = (100.0 - pred1) * inv_s;
+  const double a0 = -pred0 * inv_s, b0 = (PHF_K100(kx) - pred0) * inv_s, a1 = -pred1 * inv_s, b1 = (PHF_K100(kx) - pred1) * inv_s;
   const double ya0 = -a0 * PHF_INV_SQRT2, ya1 = -a1 * PHF_INV_SQRT2;
   double qa[2] = {phf_erfcx_den(ya0), phf_erfcx_den(ya1)};
   phf_batch_recip(qa, 2);
@@ -160,7 +160,7 @@ PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s, phf_k
 }
 
 PHF_HD double phf_trunc_mass_core(double pred, double inv_s, phf_ktab kx, phf_ktab ke, int kv, int skip) {
-  const double a = -pred * inv_s, b = (100.0 - pred) * inv_s;
+  const double a = -pred * inv_s, b = (PHF_K100(kx) - pred) * inv_s;
   const double ya = -a * PHF_INV_SQRT2, yb = b * PHF_INV_SQRT2;
   const double ea = phf_erfcx_finish_kx(ya, phf_rcp(phf_erfcx_den(ya)), ke, kv);
   const double ga = phf_exp_capped_k(-0.5 * a * a, kx, 1);
@@ -366,7 +366,7 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
       const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc0 - ln_ic50), 40.0), ke, 0);
       const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc1 - ln_ic50), 40.0), ke, 0);
       const double inv = phf_rcp(d0 * d1);
-      const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
+      const double pred0 = phf_fma(-PHF_K100(k_exp), inv * d1, PHF_K100(k_exp)), pred1 = phf_fma(-PHF_K100(k_exp), inv * d0, PHF_K100(k_exp));
       const double r0 = y0 - pred0, r1 = y1 - pred1;
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
       mass *= phf_trunc_mass_x2_ke(pred0, pred1, inv_s, k_exp, ke_given, have_ke, skip_tails);
@@ -374,7 +374,7 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
     if (fixed_n ? (fcnt & 1) : (j < jend)) {                                 /* at most one left */
       const double lcs = fixed_n ? plc[poff + fcnt - 1] : lc[j], ys = fixed_n ? py[poff + fcnt - 1] : y[j];
       const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lcs - ln_ic50), 40.0), k_exp, 1));
-      const double pred = phf_fma(-100.0, w, 100.0);
+      const double pred = phf_fma(-PHF_K100(k_exp), w, PHF_K100(k_exp));
       const double r = ys - pred;
       sse = phf_fma(r, r, sse);
       mass *= phf_trunc_mass_ke(pred, inv_s, k_exp, ke_given, have_ke, skip_tails);
@@ -458,14 +458,14 @@ PHF_HD void phf_hier_experiment_terms(const phf_hier_common* c, double pic50, do
     const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
     const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke, 0);
     const double inv = phf_rcp(d0 * d1);
-    const double pred0 = phf_fma(-100.0, inv * d1, 100.0), pred1 = phf_fma(-100.0, inv * d0, 100.0);
+    const double pred0 = phf_fma(-PHF_K100(k_exp), inv * d1, PHF_K100(k_exp)), pred1 = phf_fma(-PHF_K100(k_exp), inv * d0, PHF_K100(k_exp));
     const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
     sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
     trunc += phf_trunc_terms_x2(pred0, pred1, c->inv_s, k_exp, k_log);
   }
   for (; j < n; ++j) {
     const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
-    const double pred = phf_fma(-100.0, w, 100.0);
+    const double pred = phf_fma(-PHF_K100(k_exp), w, PHF_K100(k_exp));
     const double r = y[j] - pred;
     sse = phf_fma(r, r, sse);
     trunc += phf_trunc_term(pred, c->inv_s, k_exp, k_log);

@@ -116,7 +116,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   double loga = PHF_SP(2 * D + 1 + TRI);
   double nacc = PHF_SP(2 * D + 2 + TRI);
   // coefficient tables in VGPRs for the launch: a lone wavefront cannot hide the scalar-load latency
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
@@ -358,7 +358,7 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
   double lt = PHF_SP(D);
   double loga = PHF_SP(2 * D + 1 + TRI);
   double nacc = PHF_SP(2 * D + 2 + TRI);
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);                      // used by every polynomial of the iteration: registers
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);                      // used by every polynomial of the iteration: registers
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   double kv_erfcx[WPS == 1 ? 24 : 1], kv_sc[WPS == 1 ? 12 : 1];
   if (WPS == 1) {
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
   double th[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   const double lt = phf_hier_log_target(NE, s_es, s_lc, s_y, th, 1, &a.prior, k_exp, k_log);
   double* sp = a.state + g;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_
   double th[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   out[i] = phf_hier_log_target(NE, pts.expt_start + (size_t)pair * (NE + 1), pts.ln_conc + (size_t)pair * pts.stride,
                                pts.response + (size_t)pair * pts.stride, th, 1, &prior, k_exp, k_log);
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
   for (int e = lane; e < TRI; e += kBlock) sLm[e] = sp[(size_t)(2 * D + 1 + e) * nch];
   __syncthreads();
   double lt = sp[(size_t)D * nch], loga = sp[(size_t)(2 * D + 1 + TRI) * nch], nacc = sp[(size_t)(2 * D + 2 + TRI) * nch];
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a)
     for (int j = 0; j <= i; ++j)
       sp[(size_t)(2 * D + 1 + i * (i + 1) / 2 + j) * nch] = (i != j) ? 0.0 : a.cov_scale * __builtin_fabs(v);
   }
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   const double lt = gen_target(a, ne, pair, sp, (int)nch, k_exp, k_log);
   sp[(size_t)D * nch] = lt;
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(64) void hier_generic_log_target_kernel(const phf_h
   if (i >= m) return;
   const int ne = pts.n_expts;
   const int pair = pair_index[i];
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   out[i] = phf_hier_log_target_any(ne, pts.expt_start + (size_t)pair * (ne + 1), pts.ln_conc + (size_t)pair * pts.stride,
                                pts.response + (size_t)pair * pts.stride, theta + i, (int)m, &prior, k_exp, k_log);

@@ -179,9 +179,15 @@ PHF_HD double phf_pow2i(int k) { return phf_from_bits((uint64_t)(k + 1023) << 52
  * k = nearest integer to x/ln2 (magic-number add), r = x - k ln2 (two fma), exp(r) = 1 + r + r^2 q(r), q degree 9
  * (approximation error 1.6e-17 relative on |r| <= ln2/2), scaled by 2^k with ldexp (subnormal results round once).  The argument is clamped to [-746, 710]: the scaling then overflows to +inf /
  * underflows to 0 by itself, no branches.  phf_exp_fast(NaN) = 0 (min/max drop the NaN); phf_exp keeps NaN. */
-PHF_KTABLE phf_k_exp[10] = {   /* (exp(r)-1-r)/r^2, coefficient of r^i */
+/* [10] is not a coefficient: the constant 100 of the percent scale, riding along in the table every target holds in registers — a
+ * double that is not an inline constant costs two v_mov_b32 at EVERY use otherwise (hipcc rematerialises it: 10 per single-level
+ * iteration, 24 per hierarchical one) */
+#define PHF_K_EXP_N 11
+#define PHF_K100(k_exp) ((k_exp)[10])
+PHF_KTABLE phf_k_exp[PHF_K_EXP_N] = {   /* (exp(r)-1-r)/r^2, coefficient of r^i */
     0x1.0000000000001p-1, 0x1.5555555555556p-3, 0x1.5555555553d63p-5, 0x1.11111111109b3p-7, 0x1.6c16c1788bd90p-10,
-    0x1.a01a01a7c41d5p-13, 0x1.a019b90d2ae7ap-16, 0x1.71de0dae63bb3p-19, 0x1.289185613a3d6p-22, 0x1.af38a9b0ec855p-26};
+    0x1.a01a01a7c41d5p-13, 0x1.a019b90d2ae7ap-16, 0x1.71de0dae63bb3p-19, 0x1.289185613a3d6p-22, 0x1.af38a9b0ec855p-26,
+    100.0};
 
 #define PHF_EXP_MAGIC 0x1.8p52   /* adding it rounds to an integer and leaves that integer in the low mantissa bits */
 
@@ -232,7 +238,7 @@ PHF_HD double phf_exp_capped_k(double x, phf_ktab k, int split) {
   return phf_exp_core_k(__builtin_fmax(x, -746.0), k, split);
 }
 
-PHF_HD double phf_exp_fast(double x) { PHF_KFETCH_V(k, phf_k_exp, 10); return phf_exp_fast_k(x, k); }
+PHF_HD double phf_exp_fast(double x) { PHF_KFETCH_V(k, phf_k_exp, PHF_K_EXP_N); return phf_exp_fast_k(x, k); }
 
 PHF_HD double phf_exp(double x) {
   const double r = phf_exp_fast(x);

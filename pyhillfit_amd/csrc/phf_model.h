@@ -41,7 +41,8 @@ PHF_HD double phf_hill_den(int model, double ln_conc, double hill, double ln_ic5
 }
 
 /* percent block from w = 1/(1 + x):  100 (1 - w) */
-PHF_HD double phf_hill_percent(double w) { return phf_fma(-100.0, w, 100.0); }
+PHF_HD double phf_hill_percent(double w, phf_ktab k_exp) { return phf_fma(-PHF_K100(k_exp), w, PHF_K100(k_exp)); }
+#define PHF_PCT_(w_) phf_hill_percent((w_), k_exp)      /* inside the target: k_exp is in scope */
 
 /* z-score of a censored point: y == 0 -> (0 - pred)/sigma (logcdf, :244); y == 100 -> (pred - 100)/sigma (logsf, :245) */
 PHF_HD double phf_censored_z(double pred, double y, double inv_s) {
@@ -84,8 +85,8 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
     const double p01 = d0 * d1, p23 = d2 * d3;
     const double inv = phf_rcp(p01 * p23);
     const double i01 = inv * p23, i23 = inv * p01;
-    const double r0 = y[j] - phf_hill_percent(i01 * d1), r1 = y[j + 1] - phf_hill_percent(i01 * d0);
-    const double r2 = y[j + 2] - phf_hill_percent(i23 * d3), r3 = y[j + 3] - phf_hill_percent(i23 * d2);
+    const double r0 = y[j] - PHF_PCT_(i01 * d1), r1 = y[j + 1] - PHF_PCT_(i01 * d0);
+    const double r2 = y[j + 2] - PHF_PCT_(i23 * d3), r3 = y[j + 3] - PHF_PCT_(i23 * d2);
     sse = phf_fma(w[j] * r0, r0, sse); sse = phf_fma(w[j + 1] * r1, r1, sse);
     sse = phf_fma(w[j + 2] * r2, r2, sse); sse = phf_fma(w[j + 3] * r3, r3, sse);
   }
@@ -97,17 +98,17 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
     const double p01 = d0 * d1;
     const double inv = phf_rcp(p01 * d2);
     const double i01 = inv * d2;
-    const double r0 = y[j] - phf_hill_percent(i01 * d1), r1 = y[j + 1] - phf_hill_percent(i01 * d0);
-    const double r2 = y[j + 2] - phf_hill_percent(inv * p01);
+    const double r0 = y[j] - PHF_PCT_(i01 * d1), r1 = y[j + 1] - PHF_PCT_(i01 * d0);
+    const double r2 = y[j + 2] - PHF_PCT_(inv * p01);
     sse = phf_fma(w[j] * r0, r0, sse); sse = phf_fma(w[j + 1] * r1, r1, sse); sse = phf_fma(w[j + 2] * r2, r2, sse);
   } else if (rem == 2) {
     const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double inv = phf_rcp(d0 * d1);
-    const double r0 = y[j] - phf_hill_percent(inv * d1), r1 = y[j + 1] - phf_hill_percent(inv * d0);
+    const double r0 = y[j] - PHF_PCT_(inv * d1), r1 = y[j + 1] - PHF_PCT_(inv * d0);
     sse = phf_fma(w[j] * r0, r0, sse); sse = phf_fma(w[j + 1] * r1, r1, sse);
   } else if (rem == 1) {
-    const double r = y[j] - phf_hill_percent(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1)));
+    const double r = y[j] - PHF_PCT_(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1)));
     sse = phf_fma(w[j] * r, r, sse);
   }
   j = n_other;
@@ -117,33 +118,34 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
     const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
     const double inv = phf_rcp(d0 * d1);
-    const double z0 = phf_censored_z(phf_hill_percent(inv * d1), y[j], inv_s);
-    const double z1 = phf_censored_z(phf_hill_percent(inv * d0), y[j + 1], inv_s);
+    const double z0 = phf_censored_z(PHF_PCT_(inv * d1), y[j], inv_s);
+    const double z1 = phf_censored_z(PHF_PCT_(inv * d0), y[j + 1], inv_s);
     double l0, l1;
     phf_log_ndtr_nonpos_x2_kx(z0, z1, &l0, &l1, k_erfcx, erfcx_resident, k_log);
     cens = phf_fma(w[j], l0, cens); cens = phf_fma(w[j + 1], l1, cens);
   }
   for (; j < n; ++j) {
     PHF_KFETCH_UNLESS(k_erfcx, erfcx_resident, k_erfcx_resident, phf_k_erfcx, 24);
-    const double pred = phf_hill_percent(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1)));
+    const double pred = PHF_PCT_(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1)));
     cens = phf_fma(w[j], phf_log_ndtr_nonpos_kx(phf_censored_z(pred, y[j], inv_s), k_erfcx, erfcx_resident, k_log), cens);
   }
   double a = cens - pi_bit;
   a = phf_fma(-n_other_points, log_sigma, a);                            /* :246 */
   a = phf_fma(-sse, 0.5 * inv_s * inv_s, a);                             /* :247 */
+  if (sigma <= PHF_SIGMA_FLOOR) a = -PHF_INF;                            /* :238-240 (one select: t * -inf = -inf for t > 0 ...) */
   double lik = temperature * a;                                          /* :248 */
-  if (sigma <= PHF_SIGMA_FLOOR) { lik = -PHF_INF; a = -PHF_INF; }        /* :238-240 */
-  if (temperature == 0.0) lik = 0.0;                                     /* :230-231 */
+  if (temperature == 0.0) lik = 0.0;                                     /* :230-231 (... and t = 0 is 0 whatever a is) */
   *out_lik = lik;
   *out_ll1 = a;
 
-  double lp = -PHF_PIC50_RATE * pic50;                                   /* :151-156 */
-  if (pic50 < PHF_PIC50_LOWER) lp = -PHF_INF;
-  double g = phf_fma(PHF_SIGMA_SHAPE_M1, log_sl, -sl * PHF_SIGMA_INV_SCALE);   /* :304-317 */
-  if (sigma <= PHF_SIGMA_LOC) g = -PHF_INF;                              /* x < loc -> -inf; x == loc -> log 0 = -inf */
-  lp = lp + g;
-  if (model == 2 && (hill < 0.0 || hill > PHF_HILL_UPPER)) lp = -PHF_INF; /* :181-182 */
-  *out_prior = lp;
+  /* the prior: -inf outside ANY of the supports, the sum of the two terms inside (one select on one combined predicate, not one per
+   * term: the reference's -inf + x and -inf + -inf are -inf either way) */
+  const int outside = (pic50 < PHF_PIC50_LOWER)                          /* :151-156 */
+                      | (sigma <= PHF_SIGMA_LOC)                         /* :304-317: x < loc -> -inf; x == loc -> log 0 = -inf */
+                      | ((model == 2) & ((hill < 0.0) | (hill > PHF_HILL_UPPER)));   /* :181-182 */
+  const double g = phf_fma(PHF_SIGMA_SHAPE_M1, log_sl, -sl * PHF_SIGMA_INV_SCALE);
+  const double lp = -PHF_PIC50_RATE * pic50 + g;
+  *out_prior = outside ? -PHF_INF : lp;
 }
 
 /* The random numbers of MH iteration t of one chain — ONE Philox4x32-10 block (128 bits) per iteration:
@@ -177,6 +179,7 @@ PHF_HD double phf_mh_common_draws(int d, phf_u32x4 b, phf_ktab k_log, phf_ktab k
   const double ra = phf_sqrt_pos(-2.0 * log_ua);
   z[0] = ra * cs; z[1] = ra * sn;
   const double log_u = phf_log_finish_k(lu, lu.f * (inv * da), k_log);
+  if (d != 2) return log_u;                          /* d == 3: u = (w + 1/2) / 2^32 is never 0 */
   return (u < PHF_DBL_MIN) ? -PHF_INF : log_u;       /* d == 2: u == 0 (probability 2^-53): log 0 = -inf, accept */
 }
 

@@ -35,11 +35,14 @@ __device__ __forceinline__ void chol_packed(const double* c, double* l) {
       double s = c[i * (i + 1) / 2 + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) s = phf_fma(-l[i * (i + 1) / 2 + k], l[j * (j + 1) / 2 + k], s);
-      if (i == j) {   // sqrt and reciprocal are computed unconditionally (no divergent branch); a non-positive pivot selects 0
-        const double r = phf_sqrt_nonneg(s);
-        const double ir = phf_rcp(r);
+      if (i == j) {   // sqrt and reciprocal are computed unconditionally (no divergent branch); a non-positive pivot selects 0 —
+                      // ONE predicate for both selects (sqrt(s) > 0 exactly when s > 0)
+        const bool pos = s > 0.0;
+        const double rs = phf_sqrt_pos(s);
+        const double r = pos ? rs : 0.0;
+        const double ir = phf_rcp(rs);
         l[i * (i + 1) / 2 + i] = r;
-        inv[i] = (r > 0.0) ? ir : 0.0;
+        inv[i] = pos ? ir : 0.0;
       } else {
         l[i * (i + 1) / 2 + j] = s * inv[j];
       }
@@ -120,7 +123,7 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   double nacc = sp[(size_t)(2 * D + 2 + NTRI) * nchains];
   double ll1 = sp[(size_t)(2 * D + 3 + NTRI) * nchains];   // untempered log-likelihood of the current state
   // exp and log coefficients: in VGPRs for the whole launch (17 doubles)
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   // the 24 erfcx coefficients too when this wavefront owns the whole register file (no scalar-cache refetch per use)
@@ -200,7 +203,7 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
           cov[i * (i + 1) / 2 + j] = phf_fma(gs, v[i] * v[j], omg * cov[i * (i + 1) / 2 + j]);
 #pragma unroll
       for (int i = 0; i < D; ++i) mean[i] = phf_fma(gm, th[i], omm * mean[i]);
-      loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
+      loga = phf_fma(gs, acc ? 0.75 : -0.25, loga);                                      // accepted - target_acceptance (1 - 0.25 is exact)
     }
     // ---- draws of the next iteration, factor and scale of the next proposal ----
     double z_next[3];
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
 #pragma unroll
   for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
   double lik0, prior0, ll10;
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   phf_sl_log_target(MODEL, s_pts, s_pts + a.pts.stride, s_pts + 2 * a.pts.stride, n_other, n_zero + n_hundred,
                     a.pts.extra[2 * pair], a.pts.extra[2 * pair + 1], a.pts.pi_bit[pair], a.prob.temperature[q],
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
   double lik, prior, ll1;
-  PHF_KFETCH_V(k_exp, phf_k_exp, 10);
+  PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, 7);
   phf_sl_log_target(MODEL, pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride,
                     pts.weight + (size_t)pair * pts.stride, cnt[0], cnt[1] + cnt[2], pts.extra[2 * pair], pts.extra[2 * pair + 1],
