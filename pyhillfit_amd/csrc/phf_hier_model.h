@@ -57,16 +57,10 @@ PHF_HD void phf_batch_recip(double* v, int n) {
   v[0] = inv;
 }
 
-/* log of a positive normal number from its reduction and the reciprocal of (2 + f); -inf below DBL_MIN */
-PHF_HD double phf_log_from_recip(double x, phf_logred lr, double inv_den, phf_ktab k_log) {
-  const double r = phf_log_finish_k(lr, lr.f * inv_den, k_log);
-  return (x < PHF_DBL_MIN) ? -PHF_INF : r;
-}
-
 /* Truncated-Gaussian terms of two points at once (PyHillFit.py:121-125): the masses Phi(b) - Phi(a) of the two points,
  * a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma.  Phi(b)-Phi(a) = 1 - [Q(b) + Phi(a)], both tails through erfcx (no cancellation
  * in the tails); the two lower tails share one division, the two upper tails another.  The per-Ne target multiplies the masses of
- * a half's points and takes one logarithm (phf_hier_target_half); the per-experiment form logs them two per division.
+ * a half's points and takes one logarithm (phf_hier_target_half); the per-experiment form takes one per point.
  *
  * An UPPER tail with argument/sqrt2 >= PHF_TAIL_CUT = 6 is DEFINED as zero: Q(6 sqrt2) = 1.1e-17 is below half an ulp of the 1 it is
  * subtracted from.  That makes it skippable: the upper tails of a pair of points — 2 erfcx, 2 exponentials, a division — are
@@ -89,7 +83,7 @@ PHF_HD void phf_trunc_lower_x2(double pred0, double pred1, double inv_s, phf_kta
   double qa[2] = {phf_erfcx_den(ya0), phf_erfcx_den(ya1)};
   phf_batch_recip(qa, 2);
   const double ea0 = phf_erfcx_finish_kx(ya0, qa[0], ke, kv), ea1 = phf_erfcx_finish_kx(ya1, qa[1], ke, kv);
-  const double ga0 = phf_exp_capped_k(-0.5 * a0 * a0, kx, 0), ga1 = phf_exp_capped_k(-0.5 * a1 * a1, kx, 0);
+  const double ga0 = phf_exp_capped_k(-0.5 * a0 * a0, kx), ga1 = phf_exp_capped_k(-0.5 * a1 * a1, kx);
   *t0 = ea0 * ga0; *t1 = ea1 * ga1;
   *b0_out = b0; *b1_out = b1;
 }
@@ -108,7 +102,7 @@ PHF_HD void phf_trunc_upper_mass_x2(double t0, double t1, double b0, double b1, 
     double qb[2] = {phf_erfcx_den(yb0), phf_erfcx_den(yb1)};
     phf_batch_recip(qb, 2);
     const double eb0 = phf_erfcx_finish_kx(yb0, qb[0], ke, kv), eb1 = phf_erfcx_finish_kx(yb1, qb[1], ke, kv);
-    const double gb0 = phf_exp_capped_k(-0.5 * b0 * b0, kx, 0), gb1 = phf_exp_capped_k(-0.5 * b1 * b1, kx, 0);
+    const double gb0 = phf_exp_capped_k(-0.5 * b0 * b0, kx), gb1 = phf_exp_capped_k(-0.5 * b1 * b1, kx);
     t0 += up0 ? eb0 * gb0 : 0.0;
     t1 += up1 ? eb1 * gb1 : 0.0;
   }
@@ -128,10 +122,7 @@ PHF_HD void phf_trunc_mass_x2_core(double pred0, double pred1, double inv_s, phf
 PHF_HD double phf_trunc_terms_x2_core(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
   double m0, m1;
   phf_trunc_mass_x2_core(pred0, pred1, inv_s, kx, ke, kv, skip, &m0, &m1);
-  const phf_logred l0 = phf_log_reduce(m0), l1 = phf_log_reduce(m1);
-  double d[2] = {2.0 + l0.f, 2.0 + l1.f};
-  phf_batch_recip(d, 2);
-  return phf_log_from_recip(m0, l0, d[0], kl) + phf_log_from_recip(m1, l1, d[1], kl);
+  return phf_log_fast_k(m0, kl) + phf_log_fast_k(m1, kl);
 }
 
 /* m0 m1, with the erfcx coefficients from the caller or fetched here (see phf_trunc_terms_x2_ke) */
@@ -163,12 +154,12 @@ PHF_HD double phf_trunc_mass_core(double pred, double inv_s, phf_ktab kx, phf_kt
   const double a = -pred * inv_s, b = (PHF_K100(kx) - pred) * inv_s;
   const double ya = -a * PHF_INV_SQRT2, yb = b * PHF_INV_SQRT2;
   const double ea = phf_erfcx_finish_kx(ya, phf_rcp(phf_erfcx_den(ya)), ke, kv);
-  const double ga = phf_exp_capped_k(-0.5 * a * a, kx, 1);
+  const double ga = phf_exp_capped_k(-0.5 * a * a, kx);
   double t = ea * ga;
   const int up = yb < PHF_TAIL_CUT;
   if (!skip || PHF_ANY_LANE(up)) {
     const double eb = phf_erfcx_finish_kx(yb, phf_rcp(phf_erfcx_den(yb)), ke, kv);
-    const double gb = phf_exp_capped_k(-0.5 * b * b, kx, 1);
+    const double gb = phf_exp_capped_k(-0.5 * b * b, kx);
     t += up ? eb * gb : 0.0;
   }
   return phf_fma(-0.5, t, 1.0);
@@ -176,8 +167,7 @@ PHF_HD double phf_trunc_mass_core(double pred, double inv_s, phf_ktab kx, phf_kt
 
 PHF_HD double phf_trunc_term_core(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
   const double m = phf_trunc_mass_core(pred, inv_s, kx, ke, kv, skip);
-  const phf_logred lr = phf_log_reduce(m);
-  return phf_log_from_recip(m, lr, phf_rcp(2.0 + lr.f), kl);
+  return phf_log_fast_k(m, kl);
 }
 
 PHF_HD double phf_trunc_mass_ke(double pred, double inv_s, phf_ktab kx, phf_ktab ke_given, int have_ke, int skip) {
@@ -204,8 +194,8 @@ PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl
  *       ln alpha | ln Hill_1 .. ln Hill_Ne | ln beta | ln(alpha-loc0) ln(beta-loc1) ln(mu-loc2) ln(s-loc3) ln(sigma-loc4) | ln s | ln sigma
  *     with weights
  *       -Ne beta |  beta - 1  (each)       |   Ne    |   shape_k - 1  (each: the Gamma priors, :187)                       | -Ne  | -n_pts
- *     half 0 takes the first ceil((9+Ne)/2) (always ln alpha and every ln Hill_i), half 1 the rest; each half shares ONE
- *     division among its logarithms, 1/sigma and 1/s;
+ *     half 0 takes the first ceil((9+Ne)/2) (always ln alpha and every ln Hill_i), half 1 the rest (a logarithm is a table
+ *     lookup and a short polynomial, phf_math.h: no division); 1/sigma and 1/s share ONE division;
  *   half 0: + sum_k -(x_k - loc_k)/scale_k   (linear part of the Gamma priors)
  *           - 2 ln prod_i (1 + (Hill_i/alpha)^beta)                          (log-logistic, :134-142: the sum of Ne logarithms as one)
  *   half 1: + sum_i -(pIC50_i - mu)/s  - 2 ln prod_i (1 + exp(-(pIC50_i - mu)/s))  (logistic, :144-154; either product term by
@@ -267,7 +257,7 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
       off += cnt;
     }
   }
-  /* ---- this half's share of the first batch of logarithms, 1/sigma and 1/s: one division ---- */
+  /* ---- this half's share of the first batch of logarithms; 1/sigma and 1/s: one division ---- */
   double ga[10 + PHF_HIER_CAP], gw[10 + PHF_HIER_CAP];            /* arguments and weights of all 9 + Ne (cheap), then the pick */
   double xl[5];
   ga[0] = alpha; gw[0] = -(double)n_expts * beta;
@@ -282,27 +272,17 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
   ga[n_expts + 7] = s; gw[n_expts + 7] = -(double)n_expts;
   ga[n_expts + 8] = sigma; gw[n_expts + 8] = -(double)n_pts;
   ga[nl] = 1.0; gw[nl] = 0.0;                                     /* pads half 1 when 9 + Ne is odd: ln 1 = 0 */
-  double lx[5 + PHF_HIER_CAP / 2 + 1], lw[5 + PHF_HIER_CAP / 2 + 1];
-  phf_logred lr[5 + PHF_HIER_CAP / 2 + 1];
-  double rc[2 + 5 + PHF_HIER_CAP / 2 + 1];
-  rc[0] = sigma; rc[1] = s;
-  PHF_UNROLL
-  for (int j = 0; j < n0; ++j) {
-    double a0 = ga[j], a1 = ga[n0 + j], w0 = gw[j], w1 = gw[n0 + j];
-    PHF_OPAQUE(a0); PHF_OPAQUE(a1); PHF_OPAQUE(w0); PHF_OPAQUE(w1);
-    lx[j] = PHF_PICK(h, a0, a1);
-    lw[j] = PHF_PICK(h, w0, w1);
-    lr[j] = phf_log_reduce(lx[j]);
-    rc[2 + j] = 2.0 + lr[j].f;
-  }
-  phf_batch_recip(rc, 2 + n0);
+  double rc[2] = {sigma, s};
+  phf_batch_recip(rc, 2);
   const double inv_s = rc[0], inv_sc = rc[1];
   double lg[5 + PHF_HIER_CAP / 2 + 1];
   double part = 0.0;
   PHF_UNROLL
   for (int j = 0; j < n0; ++j) {
-    lg[j] = phf_log_from_recip(lx[j], lr[j], rc[2 + j], k_log);
-    part = phf_fma(lw[j], lg[j], part);
+    double a0 = ga[j], a1 = ga[n0 + j], w0 = gw[j], w1 = gw[n0 + j];
+    PHF_OPAQUE(a0); PHF_OPAQUE(a1); PHF_OPAQUE(w0); PHF_OPAQUE(w1);
+    lg[j] = phf_log_fast_k(PHF_PICK(h, a0, a1), k_log);
+    part = phf_fma(PHF_PICK(h, w0, w1), lg[j], part);
   }
   /* ---- linear terms: Gamma priors (half 0), logistic density of the pIC50_i (half 1) ---- */
   double lin0 = 0.0, lin1 = 0.0;
@@ -324,18 +304,12 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
     PHF_UNROLL
     for (int i = 1; i < n_expts; ++i) prod *= la[i];
     const int big = !(prod < 0x1p1000);
-    const phf_logred lp = phf_log_reduce(prod);
-    double v = phf_log_finish_k(lp, phf_div(lp.f, 2.0 + lp.f), k_log);
+    double v = phf_log_pos_k(prod, k_log);
     if (PHF_ANY_LANE(big)) {
-      phf_logred l2[PHF_HIER_CAP];
-      double d2[PHF_HIER_CAP];
-      PHF_UNROLL
-      for (int i = 0; i < n_expts; ++i) { l2[i] = phf_log_reduce(la[i]); d2[i] = 2.0 + l2[i].f; }
-      phf_batch_recip(d2, n_expts);
       double vs = 0.0;
       PHF_UNROLL
       for (int i = 0; i < n_expts; ++i) {
-        const double vi = phf_log_finish_k(l2[i], l2[i].f * d2[i], k_log);
+        const double vi = phf_log_pos_k(la[i], k_log);
         vs += (la[i] > 0x1p1000) ? PHF_INF : vi;                             /* overflowed power: log(inf) = inf */
       }
       v = big ? vs : v;
@@ -363,8 +337,8 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
       const phf_ktab ke = k_exp;
       const double lc0 = fixed_n ? plc[poff + 2 * p] : lc[j], lc1 = fixed_n ? plc[poff + 2 * p + 1] : lc[j + 1];
       const double y0 = fixed_n ? py[poff + 2 * p] : y[j], y1 = fixed_n ? py[poff + 2 * p + 1] : y[j + 1];
-      const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc0 - ln_ic50), 40.0), ke, 0);
-      const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc1 - ln_ic50), 40.0), ke, 0);
+      const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc0 - ln_ic50), 40.0), ke);
+      const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc1 - ln_ic50), 40.0), ke);
       const double inv = phf_rcp(d0 * d1);
       const double pred0 = phf_fma(-PHF_K100(k_exp), inv * d1, PHF_K100(k_exp)), pred1 = phf_fma(-PHF_K100(k_exp), inv * d0, PHF_K100(k_exp));
       const double r0 = y0 - pred0, r1 = y1 - pred1;
@@ -373,7 +347,7 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
     }
     if (fixed_n ? (fcnt & 1) : (j < jend)) {                                 /* at most one left */
       const double lcs = fixed_n ? plc[poff + fcnt - 1] : lc[j], ys = fixed_n ? py[poff + fcnt - 1] : y[j];
-      const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lcs - ln_ic50), 40.0), k_exp, 1));
+      const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lcs - ln_ic50), 40.0), k_exp));
       const double pred = phf_fma(-PHF_K100(k_exp), w, PHF_K100(k_exp));
       const double r = ys - pred;
       sse = phf_fma(r, r, sse);
@@ -385,8 +359,7 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
 #undef PHF_NF_
   /* sum_j ln(Phi(b_j) - Phi(a_j)) as ONE logarithm of the product: every mass is in (0, 1], a half has a handful of points, so the
    * product cannot overflow and underflows only where sigma ~ 1e27 — there the half is -inf (a proposal to reject), never +inf */
-  const phf_logred lm = phf_log_reduce(mass);
-  const double trunc = phf_log_finish_k(lm, phf_div(lm.f, 2.0 + lm.f), k_log);
+  const double trunc = phf_log_pos_k(mass, k_log);
   const double r = part - phf_fma(sse, 0.5 * inv_s * inv_s, trunc);
   return (mass < PHF_DBL_MIN) ? -PHF_INF : r;
 }
@@ -417,7 +390,7 @@ typedef struct {
   int bad;                              /* hyper-parameter outside its support (:176,182) */
 } phf_hier_common;
 
-/* the part that depends on (alpha, beta, mu, s, sigma) only: 9 logarithms and 2 reciprocals behind one division */
+/* the part that depends on (alpha, beta, mu, s, sigma) only: 9 logarithms, and 1/sigma, 1/s behind one division */
 PHF_HD phf_hier_common phf_hier_common_terms(double alpha, double beta, double mu, double s, double sigma,
                                              const phf_hier_prior* pr, phf_ktab k_log) {
   phf_hier_common c;
@@ -427,16 +400,12 @@ PHF_HD phf_hier_common phf_hier_common_terms(double alpha, double beta, double m
   lx[0] = sigma; lx[1] = alpha; lx[2] = beta; lx[3] = s;
   PHF_UNROLL
   for (int k = 0; k < 5; ++k) lx[4 + k] = hv[k] - pr->loc[k];
-  phf_logred lr[9];
-  double rc[11];
-  rc[0] = sigma; rc[1] = s;
-  PHF_UNROLL
-  for (int k = 0; k < 9; ++k) { lr[k] = phf_log_reduce(lx[k]); rc[2 + k] = 2.0 + lr[k].f; }
-  phf_batch_recip(rc, 11);
+  double rc[2] = {sigma, s};
+  phf_batch_recip(rc, 2);
   c.inv_s = rc[0]; c.inv_sc = rc[1];
   double lg[9];
   PHF_UNROLL
-  for (int k = 0; k < 9; ++k) lg[k] = phf_log_from_recip(lx[k], lr[k], rc[2 + k], k_log);
+  for (int k = 0; k < 9; ++k) lg[k] = phf_log_fast_k(lx[k], k_log);
   c.log_sigma = lg[0]; c.ln_alpha = lg[1]; c.ln_beta = lg[2]; c.ln_s = lg[3]; c.beta = beta; c.mu = mu;
   double prior = 0.0;
   PHF_UNROLL
@@ -455,8 +424,8 @@ PHF_HD void phf_hier_experiment_terms(const phf_hier_common* c, double pic50, do
   int j = 0;
   for (; j + 2 <= n; j += 2) {                                               /* :117-125, two points at a time */
     const phf_ktab ke = k_exp;
-    const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke, 0);
-    const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke, 0);
+    const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), ke);
+    const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j + 1] - ln_ic50), 40.0), ke);
     const double inv = phf_rcp(d0 * d1);
     const double pred0 = phf_fma(-PHF_K100(k_exp), inv * d1, PHF_K100(k_exp)), pred1 = phf_fma(-PHF_K100(k_exp), inv * d0, PHF_K100(k_exp));
     const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
@@ -464,24 +433,19 @@ PHF_HD void phf_hier_experiment_terms(const phf_hier_common* c, double pic50, do
     trunc += phf_trunc_terms_x2(pred0, pred1, c->inv_s, k_exp, k_log);
   }
   for (; j < n; ++j) {
-    const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp, 1));
+    const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp));
     const double pred = phf_fma(-PHF_K100(k_exp), w, PHF_K100(k_exp));
     const double r = y[j] - pred;
     sse = phf_fma(r, r, sse);
     trunc += phf_trunc_term(pred, c->inv_s, k_exp, k_log);
   }
-  /* log-logistic density of Hill_i (:134-142), logistic density of pIC50_i (:144-154): three logarithms, one division */
+  /* log-logistic density of Hill_i (:134-142), logistic density of pIC50_i (:144-154): three logarithms */
   const double z = (pic50 - c->mu) * c->inv_sc;
-  const phf_logred lh = phf_log_reduce(hill);
+  const double ln_h = phf_log_fast_k(hill, k_log);
   const double la1 = 1.0 + phf_exp_fast_k(-z, k_exp);
-  const phf_logred l1 = phf_log_reduce(la1);
-  double d[2] = {2.0 + lh.f, 2.0 + l1.f};
-  phf_batch_recip(d, 2);
-  const double ln_h = phf_log_from_recip(hill, lh, d[0], k_log);
-  const double v1 = phf_log_finish_k(l1, l1.f * d[1], k_log);
+  const double v1 = phf_log_pos_k(la1, k_log);
   const double la0 = 1.0 + phf_exp_fast_k(c->beta * (ln_h - c->ln_alpha), k_exp);
-  const phf_logred l0 = phf_log_reduce(la0);
-  const double v0 = phf_log_finish_k(l0, phf_div(l0.f, 2.0 + l0.f), k_log);
+  const double v0 = phf_log_pos_k(la0, k_log);
   double hyper = (c->ln_beta - c->beta * c->ln_alpha) + (c->beta - 1.0) * ln_h;
   hyper += (-z - c->ln_s);
   hyper -= 2.0 * ((la0 > 0x1p1000) ? PHF_INF : v0);                          /* overflowed power: log(inf) = inf */
@@ -527,8 +491,7 @@ PHF_HD double phf_hier_log_target_any(int n_expts, const int* expt_start, const 
  * blocks 0..ceil(dim/4)-1) and log(u) of the accept uniform (block ceil(dim/4)).                                 */
 PHF_HD void phf_box_muller_k(uint32_t w1, uint32_t w2, double* z0, double* z1, phf_ktab k_log, phf_ktab k_sc) {
   const double ua = phf_unit_open32(w1);
-  const phf_logred lr = phf_log_reduce(ua);
-  const double rad = phf_sqrt_pos(-2.0 * phf_log_finish_k(lr, phf_div(lr.f, 2.0 + lr.f), k_log));
+  const double rad = phf_sqrt_pos(-2.0 * phf_log_pos_k(ua, k_log));
   double sn, cs;
   phf_sincos_2pi_u32_k(w2, &sn, &cs, k_sc);
   *z0 = rad * cs;
@@ -555,8 +518,7 @@ PHF_HD double phf_hier_draws_k(int dim, uint32_t chain_id, uint32_t problem_id, 
   }
   const phf_u32x4 wu = phf_philox4x32_10(chain_id, problem_id, t, (uint32_t)nb, seed_lo, seed_hi);
   const double u = phf_uniform53(wu.w[0], wu.w[1]);
-  const phf_logred lu = phf_log_reduce(u);
-  return phf_log_from_recip(u, lu, phf_rcp(2.0 + lu.f), k_log);
+  return phf_log_fast_k(u, k_log);
 }
 
 PHF_HD double phf_hier_draws(int dim, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,

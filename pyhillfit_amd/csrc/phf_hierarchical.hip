@@ -117,7 +117,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   double nacc = PHF_SP(2 * D + 2 + TRI);
   // coefficient tables in VGPRs for the launch: a lone wavefront cannot hide the scalar-load latency
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
 
@@ -246,6 +246,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 template <int NE>
 __global__ __launch_bounds__(kBlock, 1) void hier_advance_kernel(const HierArgs a) {
   extern __shared__ double s_mem[];
+  PHF_MATH_TABLES_TO_LDS();
   double* s_lc = s_mem + (size_t)Lds<NE>::tri * kBlock;
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
@@ -359,7 +360,7 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
   double loga = PHF_SP(2 * D + 1 + TRI);
   double nacc = PHF_SP(2 * D + 2 + TRI);
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);                      // used by every polynomial of the iteration: registers
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   double kv_erfcx[WPS == 1 ? 24 : 1], kv_sc[WPS == 1 ? 12 : 1];
   if (WPS == 1) {
 #pragma unroll
@@ -409,8 +410,7 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
         }
         if (b0 == NB || b1 == NB) {
           const double u = phf_uniform53(w.w[0], w.w[1]);
-          const phf_logred lu = phf_log_reduce(u);
-          const double v = phf_log_from_recip(u, lu, phf_rcp(2.0 + lu.f), k_log);
+          const double v = phf_log_fast_k(u, k_log);
           log_u = PHF_FROM_LANE((b0 == NB) ? 0 : 1, v);
         }
       }
@@ -565,6 +565,7 @@ constexpr int kChains2 = kBlock / 2;                       // chains per wavefro
 
 template <int NE, int WPS>
 __global__ __launch_bounds__(kBlock, WPS) void hier_advance2_kernel(const HierArgs a) {
+  PHF_MATH_TABLES_TO_LDS();
   extern __shared__ double s_mem[];
   double* s_k = s_mem + (size_t)Lds2<NE>::slots * kBlock;
   double* s_lc = s_k + Lds2<NE>::consts;
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(kBlock, WPS) void hier_advance2_kernel(const HierAr
 }
 template <int NE>
 __global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
+  PHF_MATH_TABLES_TO_LDS();
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
   extern __shared__ double s_mem[];
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
 #pragma unroll
   for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   const double lt = phf_hier_log_target(NE, s_es, s_lc, s_y, th, 1, &a.prior, k_exp, k_log);
   double* sp = a.state + g;
 #pragma unroll
@@ -636,6 +638,7 @@ __global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
 template <int NE>
 __global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_points pts, const phf_hier_prior prior, int64_t m,
                                                                  const int32_t* pair_index, const double* theta, double* out) {
+  PHF_MATH_TABLES_TO_LDS();
   constexpr int D = 5 + 2 * NE;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= m) return;
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   out[i] = phf_hier_log_target(NE, pts.expt_start + (size_t)pair * (NE + 1), pts.ln_conc + (size_t)pair * pts.stride,
                                pts.response + (size_t)pair * pts.stride, th, 1, &prior, k_exp, k_log);
 }
@@ -674,6 +677,7 @@ struct WaveLds {
 };
 
 __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArgs a) {
+  PHF_MATH_TABLES_TO_LDS();
   extern __shared__ double s_mem[];
   const int ne = a.pts.n_expts;
   const int D = 5 + 2 * ne;
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
   __syncthreads();
   double lt = sp[(size_t)D * nch], loga = sp[(size_t)(2 * D + 1 + TRI) * nch], nacc = sp[(size_t)(2 * D + 2 + TRI) * nch];
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
   const int thin = a.cfg.thinning;
@@ -735,8 +739,7 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
     }
     const phf_u32x4 wu = phf_philox4x32_10(cid, pid, (uint32_t)t, (uint32_t)nb, seed_lo, seed_hi);
     const double u = phf_uniform53(wu.w[0], wu.w[1]);
-    const phf_logred lu = phf_log_reduce(u);
-    const double log_u = phf_log_from_recip(u, lu, phf_rcp(2.0 + lu.f), k_log);
+    const double log_u = phf_log_fast_k(u, k_log);
     __syncthreads();
     // ---- proposal theta* = theta + e^(loga/2) L sqrt(D) z: u = sqrt(d) z in place, then rows lane, lane+64, ... ----
     for (int i = lane; i < D; i += kBlock) s_z[i] = phf_sqrt_nonneg(sLm[i * (i + 1) / 2 + i]) * s_z[i];
@@ -831,6 +834,7 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
 }
 
 __global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a) {
+  PHF_MATH_TABLES_TO_LDS();
   const int ne = a.pts.n_expts;
   const int D = 5 + 2 * ne;
   const int q = blockIdx.x / a.blocks_per_problem;
@@ -849,7 +853,7 @@ __global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a)
       sp[(size_t)(2 * D + 1 + i * (i + 1) / 2 + j) * nch] = (i != j) ? 0.0 : a.cov_scale * __builtin_fabs(v);
   }
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   const double lt = gen_target(a, ne, pair, sp, (int)nch, k_exp, k_log);
   sp[(size_t)D * nch] = lt;
   const int tri = D * (D + 1) / 2;
@@ -864,12 +868,13 @@ __global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a)
 
 __global__ __launch_bounds__(64) void hier_generic_log_target_kernel(const phf_hier_points pts, const phf_hier_prior prior, int64_t m,
                                                                      const int32_t* pair_index, const double* theta, double* out) {
+  PHF_MATH_TABLES_TO_LDS();
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= m) return;
   const int ne = pts.n_expts;
   const int pair = pair_index[i];
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   out[i] = phf_hier_log_target_any(ne, pts.expt_start + (size_t)pair * (ne + 1), pts.ln_conc + (size_t)pair * pts.stride,
                                pts.response + (size_t)pair * pts.stride, theta + i, (int)m, &prior, k_exp, k_log);
 }
@@ -922,12 +927,15 @@ HierPolicy& hier_policy() {                                       // first use r
 int hier_lanes_override() { return hier_policy().lanes; }
 int hier_wps_override() { return hier_policy().wps; }
 
+// a workgroup's 160 KB of LDS less the static part every kernel here has: the exp / log tables of phf_math.h
+constexpr size_t kMaxDynamicLds = 160 * 1024 - PHF_MATH_LDS_BYTES;
+
 template <typename K>
 int allow_big_lds(K kernel, bool* configured) {                   // the attribute is per function AND per device
   const int dev = current_device();
   if (!configured[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return phf_check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) for a hierarchical kernel");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds) != hipSuccess)
+      return phf_check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB less the math tables) for a hierarchical kernel");
     configured[dev] = true;
   }
   return PHF_OK;
@@ -936,7 +944,7 @@ int allow_big_lds(K kernel, bool* configured) {                   // the attribu
 template <int NE>
 int launch_advance1(const HierArgs& a, hipStream_t stream) {
   const size_t lds = Lds<NE>::bytes(a.pts.stride);
-  if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
+  if (lds > kMaxDynamicLds) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
   const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
   static bool configured[kMaxDevices] = {};
   if (int rc = allow_big_lds(&hier_advance_kernel<NE>, configured)) return rc;
@@ -956,7 +964,7 @@ int launch_advance2_wps(const HierArgs& a, size_t lds, hipStream_t stream) {
 template <int NE>
 int launch_advance2(HierArgs a, hipStream_t stream) {
   const size_t lds = Lds2<NE>::bytes(a.pts.stride);
-  if (lds > 160 * 1024) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
+  if (lds > kMaxDynamicLds) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
   a.blocks_per_problem = (a.prob.chains_per_problem + kChains2 - 1) / kChains2;
   const int64_t blocks = (int64_t)a.blocks_per_problem * a.prob.num_problems;
   if (blocks > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
@@ -999,7 +1007,7 @@ int launch_wave_advance(const HierArgs& a, hipStream_t stream, bool* launched) {
   WaveLds w;
   w.ne = a.pts.n_expts; w.D = 5 + 2 * w.ne; w.tri = w.D * (w.D + 1) / 2; w.stride = a.pts.stride;
   *launched = false;
-  if (w.bytes() > 160 * 1024) return PHF_OK;                     // dimension too large for LDS (cannot happen for Ne <= 64): caller reports it
+  if (w.bytes() > kMaxDynamicLds) return PHF_OK;                     // dimension too large for LDS (cannot happen for Ne <= 64): caller reports it
   const int64_t blocks = (int64_t)a.prob.num_problems * a.prob.chains_per_problem;
   if (blocks > 0x7fffffffLL) return PHF_OK;
   static bool configured[kMaxDevices] = {};

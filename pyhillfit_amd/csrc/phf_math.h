@@ -7,18 +7,21 @@
  * differ in the last ulp and would not be.
  *
  * Shaped for CDNA4's fp64 VALU (measured with tools/microbench.hip on MI355X: v_fma_f64 2.25 ns per
- * wave-instruction per SIMD, v_mov_b64 2.1 ns, IEEE division ~26 ns, v_rcp/v_sqrt_f64 7 ns):
+ * wave-instruction per SIMD, v_mov_b64 2.1 ns, IEEE division ~26 ns, v_rcp/v_sqrt_f64 7 ns) — the kernels are bound by
+ * vector-ALU issue, so what counts is the NUMBER of vector instructions:
+ *   - exp and log reduce their argument through a small table in LDS (a gather is a ds_read, not a vector-ALU
+ *     instruction): 11 and 12 fp64 operations instead of 17 and 27, no division in the logarithm;
  *   - polynomial steps are literal 3-operand v_fma_f64 with the coefficient in an SGPR pair fetched through the
  *     scalar cache or held in VGPRs (PHF_KFETCH / PHF_KFETCH_V below);
- *   - polynomials are split into even/odd halves (two independent dependency chains) so a lone wave on a
- *     SIMD is not latency-bound;
+ *   - the long polynomials (erfcx, sin/cos) are split into even/odd halves (two independent dependency chains) so a
+ *     lone wave on a SIMD is not latency-bound;
  *   - the *_fast / *_core entry points used inside the kernels are branch-free: range problems are handled by
- *     clamping and IEEE overflow/underflow, never by divergent control flow;
- *   - every division is exposed (reduce / finish pairs) so callers can share one IEEE division among several
- *     evaluations (batched reciprocal, see phf_model.h).
- * No table lookups: every lane runs the same instruction stream whatever its argument.
+ *     clamping and IEEE overflow/underflow, never by divergent control flow: every lane runs the same instruction
+ *     stream whatever its argument (a table lookup differs in the address only);
+ *   - the remaining divisions are exposed (den / finish pairs of erfcx, the Hill curve's 1/(1+x)) so callers can share
+ *     one IEEE division among several evaluations (batched reciprocal, see phf_model.h).
  *
- * Coefficients: Chebyshev-interpolant (near-minimax) fits from tools/gen_math_coeffs.py (mpmath, 60 digits);
+ * Tables and coefficients: tools/gen_math_coeffs.py (mpmath, 60 digits; Chebyshev-interpolant = near-minimax fits);
  * approximation errors are quoted per function.
  *
  * Replaces, on the hot path, the third-party numerics the reference calls:
@@ -65,7 +68,7 @@ typedef const double __attribute__((address_space(4))) * phf_ktab4;
     for (int phf_i_ = 0; phf_i_ < (n); ++phf_i_) name##_buf[phf_i_] = phf_p_[phf_i_];       \
   }                                                                                         \
   const phf_ktab name = name##_buf
-/* VGPR-resident: materialised once (kernels do it before the MH loop) and kept in vector registers (exp, log: 17
+/* VGPR-resident: materialised once (kernels do it before the MH loop) and kept in vector registers (exp, log: 8
  * coefficients used by every polynomial of the iteration — no scalar-load latency, no SGPR pressure) */
 #define PHF_KFETCH_V(name, table, n)                                                        \
   double name##_buf[n];                                                                     \
@@ -175,67 +178,225 @@ PHF_HD double phf_sqrt_nonneg(double x) {
 }
 PHF_HD double phf_pow2i(int k) { return phf_from_bits((uint64_t)(k + 1023) << 52); } /* -1022 <= k <= 1023 */
 
+/* ------------------------------------------------------------------------------------------------ lookup tables
+ * exp and log reduce their argument with a small table: 2^(j/64) (64 doubles) and {1/c_j, log c_j} on a grid of 129 points c_j of
+ * [sqrt(1/2), sqrt 2] (tools/gen_math_coeffs.py).  On the device the tables live in LDS — 2 576 bytes per workgroup, filled by
+ * PHF_MATH_TABLES_TO_LDS(), which EVERY kernel that evaluates anything of this header calls first, with all its threads — and a
+ * lookup is one ds_read (b64 / b128) at a per-lane address: a gather costs no vector-ALU slot, which is what these kernels are
+ * short of (measured, C3: polynomial-only exp and log -> tables: 151.4 -> 138.4 ms per 8 000 iterations).
+ * On the host the tables are the arrays themselves: same values, same operations, same results.                              */
+typedef struct { double invc, logc; } phf_logtab;
+PHF_KTABLE phf_t_exp2[64] = {   /* 2^(j/64), correctly rounded */
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+#define PHF_LOG_TAB_N 129
+#define PHF_LOG_TAB_BASE 0x1ff35   /* (bits(sqrt(1/2) rounded up) + 2^44) >> 45: entry j belongs to the double with bits (BASE + j) << 45 */
+static const phf_logtab phf_t_log[PHF_LOG_TAB_N] = {   /* {1/c rounded, -log of that rounded reciprocal}; entry 53 is c = 1: {1, 0} */
+    {0x1.6a13cd1537290p+0, -0x1.630030b3aac48p-2},   /* c = 0.70703125 */
+    {0x1.6816816816817p+0, -0x1.5d5bddf595f31p-2},
+    {0x1.661ec6a5122f9p+0, -0x1.57bf753c8d1fbp-2},
+    {0x1.642c8590b2164p+0, -0x1.522ae0738a3d7p-2},
+    {0x1.623fa77016240p+0, -0x1.4c9e09e172c3dp-2},
+    {0x1.6058160581606p+0, -0x1.4718dc271c41cp-2},
+    {0x1.5e75bb8d015e7p+0, -0x1.419b423d5e8c6p-2},
+    {0x1.5c9882b931057p+0, -0x1.3c25277333183p-2},
+    {0x1.5ac056b015ac0p+0, -0x1.36b6776be1116p-2},
+    {0x1.58ed2308158edp+0, -0x1.314f1e1d35ce3p-2},
+    {0x1.571ed3c506b3ap+0, -0x1.2bef07cdc9355p-2},
+    {0x1.5555555555555p+0, -0x1.269621134db91p-2},
+    {0x1.5390948f40febp+0, -0x1.214456d0eb8d5p-2},
+    {0x1.51d07eae2f815p+0, -0x1.1bf99635a6b95p-2},
+    {0x1.5015015015015p+0, -0x1.16b5ccbacfb73p-2},
+    {0x1.4e5e0a72f0539p+0, -0x1.1178e8227e47ap-2},
+    {0x1.4cab88725af6ep+0, -0x1.0c42d676162e2p-2},   /* c = 0.76953125 */
+    {0x1.4afd6a052bf5bp+0, -0x1.07138604d5864p-2},
+    {0x1.49539e3b2d067p+0, -0x1.01eae5626c691p-2},
+    {0x1.47ae147ae147bp+0, -0x1.f991c6cb3b37ap-3},
+    {0x1.460cbc7f5cf9ap+0, -0x1.ef5ade4dcffe5p-3},
+    {0x1.446f86562d9fbp+0, -0x1.e530effe71013p-3},
+    {0x1.42d6625d51f87p+0, -0x1.db13db0d48941p-3},
+    {0x1.4141414141414p+0, -0x1.d1037f2655e7bp-3},
+    {0x1.3fb013fb013fbp+0, -0x1.c6ffbc6f00f71p-3},
+    {0x1.3e22cbce4a902p+0, -0x1.bd087383bd8aap-3},
+    {0x1.3c995a47babe7p+0, -0x1.b31d8575bce3bp-3},
+    {0x1.3b13b13b13b14p+0, -0x1.a93ed3c8ad9e5p-3},
+    {0x1.3991c2c187f63p+0, -0x1.9f6c407089663p-3},
+    {0x1.3813813813814p+0, -0x1.95a5adcf70182p-3},
+    {0x1.3698df3de0748p+0, -0x1.8beafeb38fe8fp-3},
+    {0x1.3521cfb2b78c1p+0, -0x1.823c16551a3c0p-3},
+    {0x1.33ae45b57bcb2p+0, -0x1.7898d85444c74p-3},   /* c = 0.83203125 */
+    {0x1.323e34a2b10bfp+0, -0x1.6f0128b756ab9p-3},
+    {0x1.30d190130d190p+0, -0x1.6574ebe8c1339p-3},
+    {0x1.2f684bda12f68p+0, -0x1.5bf406b543db0p-3},
+    {0x1.2e025c04b8097p+0, -0x1.527e5e4a1b58dp-3},
+    {0x1.2c9fb4d812ca0p+0, -0x1.4913d8333b563p-3},
+    {0x1.2b404ad012b40p+0, -0x1.3fb45a59928cap-3},
+    {0x1.29e4129e4129ep+0, -0x1.365fcb0159014p-3},
+    {0x1.288b01288b013p+0, -0x1.2d1610c86813dp-3},
+    {0x1.27350b8812735p+0, -0x1.23d712a49c201p-3},
+    {0x1.25e22708092f1p+0, -0x1.1aa2b7e23f729p-3},
+    {0x1.2492492492492p+0, -0x1.1178e8227e47ap-3},
+    {0x1.23456789abcdfp+0, -0x1.08598b59e3a07p-3},
+    {0x1.21fb78121fb78p+0, -0x1.fe89139dbd565p-4},
+    {0x1.20b470c67c0d9p+0, -0x1.ec739830a1126p-4},
+    {0x1.1f7047dc11f70p+0, -0x1.da7276384469ep-4},
+    {0x1.1e2ef3b3fb874p+0, -0x1.c885801bc4b20p-4},   /* c = 0.89453125 */
+    {0x1.1cf06ada2811dp+0, -0x1.b6ac88dad5b1dp-4},
+    {0x1.1bb4a4046ed29p+0, -0x1.a4e7640b1bc38p-4},
+    {0x1.1a7b9611a7b96p+0, -0x1.9335e5d594988p-4},
+    {0x1.19453808ca29cp+0, -0x1.8197e2f40e3f0p-4},
+    {0x1.1811811811812p+0, -0x1.700d30aeac0e8p-4},
+    {0x1.16e0689427379p+0, -0x1.5e95a4d9791cdp-4},
+    {0x1.15b1e5f75270dp+0, -0x1.4d3115d207eacp-4},
+    {0x1.1485f0e0acd3bp+0, -0x1.3bdf5a7d1ee5ep-4},
+    {0x1.135c81135c811p+0, -0x1.2aa04a44717a1p-4},
+    {0x1.12358e75d3033p+0, -0x1.1973bd1465561p-4},
+    {0x1.1111111111111p+0, -0x1.08598b59e3a06p-4},
+    {0x1.0fef010fef011p+0, -0x1.eea31c006b87cp-5},
+    {0x1.0ecf56be69c90p+0, -0x1.ccb73cdddb2d0p-5},
+    {0x1.0db20a88f4696p+0, -0x1.aaef2d0fb1108p-5},
+    {0x1.0c9714fbcda3bp+0, -0x1.894aa149fb34bp-5},
+    {0x1.0b7e6ec259dc8p+0, -0x1.67c94f2d4bb65p-5},   /* c = 0.95703125 */
+    {0x1.0a6810a6810a7p+0, -0x1.466aed42de3f9p-5},
+    {0x1.0953f39010954p+0, -0x1.252f32f8d1840p-5},
+    {0x1.0842108421084p+0, -0x1.0415d89e74440p-5},
+    {0x1.073260a47f7c6p+0, -0x1.c63d2ec14aad7p-6},
+    {0x1.0624dd2f1a9fcp+0, -0x1.8492528c8cac5p-6},
+    {0x1.05197f7d73404p+0, -0x1.432a925980cbcp-6},
+    {0x1.0410410410410p+0, -0x1.0205658935837p-6},
+    {0x1.03091b51f5e1ap+0, -0x1.82448a388a283p-7},
+    {0x1.0204081020408p+0, -0x1.010157588de69p-7},
+    {0x1.0101010101010p+0, -0x1.0080559588b25p-8},
+    {0x1.0000000000000p+0, 0x0.0p+0},   /* c = 1 */
+    {0x1.fc07f01fc07f0p-1, 0x1.fe02a6b106799p-8},
+    {0x1.f81f81f81f820p-1, 0x1.fc0a8b0fc03c4p-7},
+    {0x1.f44659e4a4271p-1, 0x1.7b91b07d5b126p-6},
+    {0x1.f07c1f07c1f08p-1, 0x1.f829b0e7832f8p-6},
+    {0x1.ecc07b301ecc0p-1, 0x1.39e87b9febd68p-5},   /* c = 1.0390625 */
+    {0x1.e9131abf0b767p-1, 0x1.77458f632dcffp-5},
+    {0x1.e573ac901e574p-1, 0x1.b42dd711971b9p-5},
+    {0x1.e1e1e1e1e1e1ep-1, 0x1.f0a30c01162a8p-5},
+    {0x1.de5d6e3f8868ap-1, 0x1.16536eea37ae3p-4},
+    {0x1.dae6076b981dbp-1, 0x1.341d7961bd1d0p-4},
+    {0x1.d77b654b82c34p-1, 0x1.51b073f06183cp-4},
+    {0x1.d41d41d41d41dp-1, 0x1.6f0d28ae56b4ep-4},
+    {0x1.d0cb58f6ec074p-1, 0x1.8c345d6319b23p-4},
+    {0x1.cd85689039b0bp-1, 0x1.a926d3a4ad562p-4},
+    {0x1.ca4b3055ee191p-1, 0x1.c5e548f5bc743p-4},
+    {0x1.c71c71c71c71cp-1, 0x1.e27076e2af2eap-4},
+    {0x1.c3f8f01c3f8f0p-1, 0x1.fec9131dbeabcp-4},
+    {0x1.c0e070381c0e0p-1, 0x1.0d77e7cd08e5bp-3},
+    {0x1.bdd2b899406f7p-1, 0x1.1b72ad52f67a2p-3},
+    {0x1.bacf914c1bad0p-1, 0x1.29552f81ff521p-3},
+    {0x1.b7d6c3dda338bp-1, 0x1.371fc201e8f75p-3},   /* c = 1.1640625 */
+    {0x1.b4e81b4e81b4fp-1, 0x1.44d2b6ccb7d1cp-3},
+    {0x1.b2036406c80d9p-1, 0x1.526e5e3a1b438p-3},
+    {0x1.af286bca1af28p-1, 0x1.5ff3070a793d6p-3},
+    {0x1.ac5701ac5701bp-1, 0x1.6d60fe719d21bp-3},
+    {0x1.a98ef606a63bep-1, 0x1.7ab890210d907p-3},
+    {0x1.a6d01a6d01a6dp-1, 0x1.87fa06520c911p-3},
+    {0x1.a41a41a41a41ap-1, 0x1.9525a9cf456b6p-3},
+    {0x1.a16d3f97a4b02p-1, 0x1.a23bc1fe2b561p-3},
+    {0x1.9ec8e951033d9p-1, 0x1.af3c94e80bff3p-3},
+    {0x1.9c2d14ee4a102p-1, 0x1.bc286742d8cd4p-3},
+    {0x1.999999999999ap-1, 0x1.c8ff7c79a9a20p-3},
+    {0x1.970e4f80cb872p-1, 0x1.d5c216b4fbb94p-3},
+    {0x1.948b0fcd6e9e0p-1, 0x1.e27076e2af2e8p-3},
+    {0x1.920fb49d0e229p-1, 0x1.ef0adcbdc5935p-3},
+    {0x1.8f9c18f9c18fap-1, 0x1.fb9186d5e3e29p-3},
+    {0x1.8d3018d3018d3p-1, 0x1.0402594b4d041p-2},   /* c = 1.2890625 */
+    {0x1.8acb90f6bf3aap-1, 0x1.0a324e27390e2p-2},
+    {0x1.886e5f0abb04ap-1, 0x1.1058bf9ae4ad4p-2},
+    {0x1.8618618618618p-1, 0x1.1675cababa60fp-2},
+    {0x1.83c977ab2beddp-1, 0x1.1c898c16999fbp-2},
+    {0x1.8181818181818p-1, 0x1.22941fbcf7966p-2},
+    {0x1.7f405fd017f40p-1, 0x1.2895a13de86a4p-2},
+    {0x1.7d05f417d05f4p-1, 0x1.2e8e2bae11d31p-2},
+    {0x1.7ad2208e0ecc3p-1, 0x1.347dd9a987d56p-2},
+    {0x1.78a4c8178a4c8p-1, 0x1.3a64c556945eap-2},
+    {0x1.767dce434a9b1p-1, 0x1.404308686a7e4p-2},
+    {0x1.745d1745d1746p-1, 0x1.4618bc21c5ec2p-2},
+    {0x1.724287f46debcp-1, 0x1.4be5f957778a1p-2},
+    {0x1.702e05c0b8170p-1, 0x1.51aad872df82ep-2},
+    {0x1.6e1f76b4337c7p-1, 0x1.5767717455a6cp-2},
+    {0x1.6c16c16c16c17p-1, 0x1.5d1bdbf5809cap-2},
+    {0x1.6a13cd1537290p-1, 0x1.62c82f2b9c796p-2},   /* c = 1.4140625 */
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+static __shared__ double phf_lds_exp2[64];
+static __shared__ __attribute__((aligned(16))) phf_logtab phf_lds_log[PHF_LOG_TAB_N];
+#define PHF_T_EXP2(j) phf_lds_exp2[j]
+#define PHF_T_LOG(j) phf_lds_log[j]
+#define PHF_MATH_TABLES_TO_LDS()                                                                                          \
+  do {                                                                                                                    \
+    for (int phf_i_ = threadIdx.x; phf_i_ < 64; phf_i_ += blockDim.x) phf_lds_exp2[phf_i_] = phf_t_exp2[phf_i_];          \
+    for (int phf_i_ = threadIdx.x; phf_i_ < PHF_LOG_TAB_N; phf_i_ += blockDim.x) phf_lds_log[phf_i_] = phf_t_log[phf_i_]; \
+    __syncthreads();                                                                                                      \
+  } while (0)
+#else
+#define PHF_T_EXP2(j) phf_t_exp2[j]
+#define PHF_T_LOG(j) phf_t_log[j]
+#define PHF_MATH_TABLES_TO_LDS() do { } while (0)
+#endif
+#define PHF_MATH_LDS_BYTES (64 * 8 + PHF_LOG_TAB_N * 16)
+
 /* ------------------------------------------------------------------------------------------------ exp
- * k = nearest integer to x/ln2 (magic-number add), r = x - k ln2 (two fma), exp(r) = 1 + r + r^2 q(r), q degree 9
- * (approximation error 1.6e-17 relative on |r| <= ln2/2), scaled by 2^k with ldexp (subnormal results round once).  The argument is clamped to [-746, 710]: the scaling then overflows to +inf /
- * underflows to 0 by itself, no branches.  phf_exp_fast(NaN) = 0 (min/max drop the NaN); phf_exp keeps NaN. */
-/* [10] is not a coefficient: the constant 100 of the percent scale, riding along in the table every target holds in registers — a
+ * n = nearest integer to 64 x / ln2 (magic-number add) = 64 k + j, r = x - n ln2/64 (two fma, |r| <= ln2/128),
+ * exp(x) = 2^k T[j] (1 + p(r)), p(r) = r + r^2 (1/2 + r q(r)), q degree 2 (approximation error 8.9e-18 relative), T[j] = 2^(j/64)
+ * from the table, scaled by 2^k with ldexp (subnormal results round once); ~1 ulp.  The argument is clamped to [-746, 710]: the
+ * scaling then overflows to +inf / underflows to 0 by itself, no branches.  phf_exp_fast(NaN) = 0 (min/max drop the NaN); phf_exp keeps NaN. */
+/* [3] is not a coefficient: the constant 100 of the percent scale, riding along in the table every target holds in registers — a
  * double that is not an inline constant costs two v_mov_b32 at EVERY use otherwise (hipcc rematerialises it: 10 per single-level
  * iteration, 24 per hierarchical one) */
-#define PHF_K_EXP_N 11
-#define PHF_K100(k_exp) ((k_exp)[10])
-PHF_KTABLE phf_k_exp[PHF_K_EXP_N] = {   /* (exp(r)-1-r)/r^2, coefficient of r^i */
-    0x1.0000000000001p-1, 0x1.5555555555556p-3, 0x1.5555555553d63p-5, 0x1.11111111109b3p-7, 0x1.6c16c1788bd90p-10,
-    0x1.a01a01a7c41d5p-13, 0x1.a019b90d2ae7ap-16, 0x1.71de0dae63bb3p-19, 0x1.289185613a3d6p-22, 0x1.af38a9b0ec855p-26,
+#define PHF_K_EXP_N 4
+#define PHF_K100(k_exp) ((k_exp)[3])
+PHF_KTABLE phf_k_exp[PHF_K_EXP_N] = {   /* (expm1(r) - r - r^2/2)/r^3, coefficient of r^i */
+    0x1.5555555555555p-3, 0x1.555565c3ff8a9p-5, 0x1.11111a74dffd2p-7,
     100.0};
 
-#define PHF_EXP_MAGIC 0x1.8p52   /* adding it rounds to an integer and leaves that integer in the low mantissa bits */
+#define PHF_EXP_MAGIC 0x1.8p52        /* adding it rounds to an integer and leaves that integer in the low mantissa bits */
+#define PHF_64_LOG2E 0x1.71547652b82fep+6
+#define PHF_LN2_64_HI 0x1.62e42fee00000p-7   /* PHF_LN2_HI / 64: 21 trailing zero bits, n * this is exact for |n| < 2^21 */
+#define PHF_LN2_64_LO 0x1.a39ef35793c76p-39  /* PHF_LN2_LO / 64 */
 
-/* core: x already within [-746, 710].  SPLIT = 1: even/odd halves (two dependency chains, for lone evaluations);
- * SPLIT = 0: plain Horner (one instruction fewer; used where several evaluations already interleave).           */
-PHF_HD double phf_exp_core_k(double xc, phf_ktab k, int split) {
-  const double t = phf_fma(xc, PHF_LOG2E, PHF_EXP_MAGIC);
-  const double kd = t - PHF_EXP_MAGIC;
-  const int ki = (int)(int32_t)(uint32_t)phf_bits(t);
-  double r = phf_fma(kd, -PHF_LN2_HI, xc);
-  r = phf_fma(kd, -PHF_LN2_LO, r);
+/* core: x already within [-746, 710] */
+PHF_HD double phf_exp_core_k(double xc, phf_ktab k) {
+  const double t = phf_fma(xc, PHF_64_LOG2E, PHF_EXP_MAGIC);
+  const double nd = t - PHF_EXP_MAGIC;
+  const int n = (int)(int32_t)(uint32_t)phf_bits(t);
+  const double tj = PHF_T_EXP2(n & 63);
+  double r = phf_fma(nd, -PHF_LN2_64_HI, xc);
+  r = phf_fma(nd, -PHF_LN2_64_LO, r);
   const double r2 = r * r;
-  double q;
-  if (split) {
-    double qe = k[8];                             /* even coefficients in r^2 */
-    qe = PHF_FMA_KV(qe, r2, k[6]);
-    qe = PHF_FMA_KV(qe, r2, k[4]);
-    qe = PHF_FMA_KV(qe, r2, k[2]);
-    qe = PHF_FMA_KV(qe, r2, k[0]);
-    double qo = k[9];                             /* odd coefficients */
-    qo = PHF_FMA_KV(qo, r2, k[7]);
-    qo = PHF_FMA_KV(qo, r2, k[5]);
-    qo = PHF_FMA_KV(qo, r2, k[3]);
-    qo = PHF_FMA_KV(qo, r2, k[1]);
-    q = phf_fma(qo, r, qe);
-  } else {
-    q = k[9];
-    q = PHF_FMA_KV(q, r, k[8]);
-    q = PHF_FMA_KV(q, r, k[7]);
-    q = PHF_FMA_KV(q, r, k[6]);
-    q = PHF_FMA_KV(q, r, k[5]);
-    q = PHF_FMA_KV(q, r, k[4]);
-    q = PHF_FMA_KV(q, r, k[3]);
-    q = PHF_FMA_KV(q, r, k[2]);
-    q = PHF_FMA_KV(q, r, k[1]);
-    q = PHF_FMA_KV(q, r, k[0]);
-  }
-  const double p = phf_fma(r2, q, r) + 1.0;
-  return __builtin_ldexp(p, ki);                  /* v_ldexp_f64: exact scaling, one rounding if the result is subnormal */
+  double q = PHF_FMA_KV(k[2], r, k[1]);
+  q = PHF_FMA_KV(q, r, k[0]);
+  q = phf_fma(q, r, 0.5);
+  const double p = phf_fma(r2, q, r);
+  return __builtin_ldexp(phf_fma(tj, p, tj), n >> 6);   /* v_ldexp_f64: exact scaling, one rounding if the result is subnormal */
 }
 
 PHF_HD double phf_exp_fast_k(double x, phf_ktab k) {
-  return phf_exp_core_k(__builtin_fmin(__builtin_fmax(x, -746.0), 710.0), k, 1);
+  return phf_exp_core_k(__builtin_fmin(__builtin_fmax(x, -746.0), 710.0), k);
 }
 
 /* x known to be <= 709 (callers that have already capped their argument): lower clamp only */
-PHF_HD double phf_exp_capped_k(double x, phf_ktab k, int split) {
-  return phf_exp_core_k(__builtin_fmax(x, -746.0), k, split);
+PHF_HD double phf_exp_capped_k(double x, phf_ktab k) {
+  return phf_exp_core_k(__builtin_fmax(x, -746.0), k);
 }
 
 PHF_HD double phf_exp_fast(double x) { PHF_KFETCH_V(k, phf_k_exp, PHF_K_EXP_N); return phf_exp_fast_k(x, k); }
@@ -246,57 +407,45 @@ PHF_HD double phf_exp(double x) {
 }
 
 /* ------------------------------------------------------------------------------------------------ log
- * x = 2^k m, m in [sqrt(1/2), sqrt 2), f = m-1, s = f/(2+f), z = s^2,
- * log(1+f) = f - (f^2/2 - s (f^2/2 + z G(z))), G degree 6 as even + z*odd (approximation error 4.6e-18).
- * reduce/finish are split so the caller may obtain s = f/(2+f) from a shared (batched) reciprocal.            */
-typedef struct { double f; double dk; } phf_logred;
+ * x = 2^k m, m in [sqrt(1/2), sqrt 2); c_j = the grid point nearest to m (the double whose bits are (BASE + j) << 45: 128 steps per
+ * binade, c = 1 among them); r = m (1/c_j) - 1 by ONE fma (|r| <= 2^-8; the table's reciprocal is rounded, its logarithm is that of
+ * the rounded value, so nothing is lost); log x = k ln2 + log c_j + (r + r^2 q(r)), q degree 4 with q(0) = -1/2 exactly
+ * (approximation error 3.2e-17 of log1p(r)).  No division.  <= 2 ulp; near x = 1 the table entry is {1, 0} and the result is the
+ * polynomial alone, so log(1 + tiny) keeps its relative accuracy.                                                              */
+#define PHF_K_LOG_N 4
+PHF_KTABLE phf_k_log[PHF_K_LOG_N] = {   /* (log1p(r) - r)/r^2 + 1/2, coefficients of r^1..r^4 */
+    0x1.55555555276f7p-2, -0x1.ffffffffafadap-3, 0x1.999b080ce97c7p-3, -0x1.555695fa425fap-3};
 
-PHF_HD phf_logred phf_log_reduce(double x) { /* exact for positive normal finite x; harmless bit-twiddling otherwise */
+/* positive normal finite x only (no checks; harmless bit-twiddling on anything else) */
+PHF_HD double phf_log_pos_k(double x, phf_ktab k) {
   uint64_t u = phf_bits(x);
   u += 0x3ff0000000000000ull - 0x3fe6a09e667f3bcdull;
-  const int k = (int)(u >> 52) - 1023;
-  u = (u & 0x000fffffffffffffull) + 0x3fe6a09e667f3bcdull;
-  phf_logred lr;
-  lr.f = phf_from_bits(u) - 1.0;
-  lr.dk = (double)k;
-  return lr;
+  const int e = (int)(u >> 52) - 1023;
+  u = (u & 0x000fffffffffffffull) + 0x3fe6a09e667f3bcdull;                     /* bits of m */
+  const int j = (int)(((uint32_t)(u >> 32) + 0x1000u) >> 13) - PHF_LOG_TAB_BASE;  /* nearest grid point: (bits + 2^44) >> 45 */
+  const phf_logtab c = PHF_T_LOG(j);
+  const double r = phf_fma(phf_from_bits(u), c.invc, -1.0);
+  const double dk = (double)e;
+  const double r2 = r * r;
+  double q = PHF_FMA_KV(k[3], r, k[2]);
+  q = PHF_FMA_KV(q, r, k[1]);
+  q = PHF_FMA_KV(q, r, k[0]);
+  q = phf_fma(q, r, -0.5);
+  const double hi = phf_fma(dk, PHF_LN2_HI, c.logc);
+  const double lo = phf_fma(dk, PHF_LN2_LO, r2 * q);
+  return hi + (r + lo);
 }
 
-PHF_KTABLE phf_k_log[7] = {    /* G(z), coefficient of z^i */
-    0x1.5555555555558p-1, 0x1.99999999952ccp-2, 0x1.2492492df3ba9p-2, 0x1.c71c62e26208bp-3, 0x1.7462b58e46ebep-3,
-    0x1.39fe42e9740a7p-3, 0x1.2b59b713616c9p-3};
-
-PHF_HD double phf_log_finish_k(phf_logred lr, double s, phf_ktab k) {
-  const double f = lr.f, dk = lr.dk;
-  const double z = s * s;
-  const double z2 = z * z;
-  double ge = k[6];
-  ge = PHF_FMA_KV(ge, z2, k[4]);
-  ge = PHF_FMA_KV(ge, z2, k[2]);
-  ge = PHF_FMA_KV(ge, z2, k[0]);
-  double go = k[5];
-  go = PHF_FMA_KV(go, z2, k[3]);
-  go = PHF_FMA_KV(go, z2, k[1]);
-  const double g = phf_fma(go, z, ge);
-  const double hfsq = 0.5 * f * f;
-  const double t = phf_fma(dk, PHF_LN2_LO, s * phf_fma(z, g, hfsq));
-  return phf_fma(dk, PHF_LN2_HI, f - (hfsq - t));
-}
-
-PHF_HD double phf_log_finish(phf_logred lr, double s) { PHF_KFETCH_V(k, phf_k_log, 7); return phf_log_finish_k(lr, s, k); }
-
-/* positive normal finite x only (no checks) */
-PHF_HD double phf_log_core(double x) {
-  const phf_logred lr = phf_log_reduce(x);
-  return phf_log_finish(lr, phf_div(lr.f, 2.0 + lr.f));
-}
+PHF_HD double phf_log_core(double x) { PHF_KFETCH_V(k, phf_k_log, PHF_K_LOG_N); return phf_log_pos_k(x, k); }
 
 /* kernels: x >= 2^-1022 exact; anything below (0, negatives, subnormals) gives -inf; branch-free.
  * (+inf and NaN are not handled: the kernels never produce them here.)                              */
-PHF_HD double phf_log_fast(double x) {
-  const double r = phf_log_core(x);
+PHF_HD double phf_log_fast_k(double x, phf_ktab k) {
+  const double r = phf_log_pos_k(x, k);
   return (x < PHF_DBL_MIN) ? -PHF_INF : r;
 }
+
+PHF_HD double phf_log_fast(double x) { PHF_KFETCH_V(k, phf_k_log, PHF_K_LOG_N); return phf_log_fast_k(x, k); }
 
 /* full IEEE behaviour (subnormals, 0, negatives, inf, NaN) */
 PHF_HD double phf_log(double x) {
@@ -304,9 +453,7 @@ PHF_HD double phf_log(double x) {
   if (u < 0x0010000000000000ull || (u >> 63)) { /* +0, +subnormal, or sign bit set */
     if (x == 0.0) return -PHF_INF;
     if (u >> 63) return (x != x) ? x : PHF_NAN;
-    const phf_logred lr = phf_log_reduce(x * 0x1p54);
-    phf_logred l2; l2.f = lr.f; l2.dk = lr.dk - 54.0;
-    return phf_log_finish(l2, lr.f / (2.0 + lr.f));
+    return phf_log_core(x * 0x1p54) - 54.0 * (PHF_LN2_HI + PHF_LN2_LO);
   }
   if (u >= 0x7ff0000000000000ull) return x; /* +inf or NaN */
   return phf_log_core(x);
@@ -391,18 +538,15 @@ PHF_HD double phf_log_ndtr_nonpos(double x) {
   return phf_fma(-0.5 * x, x, phf_log_core(0.5 * e));
 }
 
-/* two at once, sharing one division for the two erfcx and one for the two logs */
+/* two at once, sharing one division for the two erfcx */
 PHF_HD void phf_log_ndtr_nonpos_x2_kx(double x0, double x1, double* r0, double* r1, phf_ktab ke, int ke_in_vgpr, phf_ktab kl) {
   const double y0 = -x0 * PHF_INV_SQRT2, y1 = -x1 * PHF_INV_SQRT2;
   const double q0 = phf_erfcx_den(y0), q1 = phf_erfcx_den(y1);
   const double iq = phf_rcp(q0 * q1);
   double e0, e1;
   phf_erfcx_finish_x2_kx(y0, iq * q1, y1, iq * q0, ke, ke_in_vgpr, &e0, &e1);
-  const phf_logred l0 = phf_log_reduce(0.5 * e0), l1 = phf_log_reduce(0.5 * e1);
-  const double d0 = 2.0 + l0.f, d1 = 2.0 + l1.f;
-  const double id = phf_rcp(d0 * d1);
-  *r0 = phf_fma(-0.5 * x0, x0, phf_log_finish_k(l0, l0.f * (id * d1), kl));
-  *r1 = phf_fma(-0.5 * x1, x1, phf_log_finish_k(l1, l1.f * (id * d0), kl));
+  *r0 = phf_fma(-0.5 * x0, x0, phf_log_pos_k(0.5 * e0, kl));
+  *r1 = phf_fma(-0.5 * x1, x1, phf_log_pos_k(0.5 * e1, kl));
 }
 
 PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r1, phf_ktab ke, phf_ktab kl) {
@@ -411,7 +555,7 @@ PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r
 
 PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1) {
   PHF_KFETCH(ke, phf_k_erfcx, 24);
-  PHF_KFETCH_V(kl, phf_k_log, 7);
+  PHF_KFETCH_V(kl, phf_k_log, PHF_K_LOG_N);
   phf_log_ndtr_nonpos_x2_k(x0, x1, r0, r1, ke, kl);
 }
 
@@ -419,8 +563,7 @@ PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1)
 PHF_HD double phf_log_ndtr_nonpos_kx(double x, phf_ktab ke, int ke_in_vgpr, phf_ktab kl) {
   const double yv = -x * PHF_INV_SQRT2;
   const double e = phf_erfcx_finish_kx(yv, phf_rcp(phf_erfcx_den(yv)), ke, ke_in_vgpr);
-  const phf_logred lr = phf_log_reduce(0.5 * e);
-  return phf_fma(-0.5 * x, x, phf_log_finish_k(lr, phf_div(lr.f, 2.0 + lr.f), kl));
+  return phf_fma(-0.5 * x, x, phf_log_pos_k(0.5 * e, kl));
 }
 
 PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab ke, phf_ktab kl) { return phf_log_ndtr_nonpos_kx(x, ke, 0, kl); }

@@ -35,9 +35,9 @@
 #define PHF_HILL_ARG_CAP 40.0                   /* exp(40): 100/(1+x) already rounds pred to exactly 100 */
 
 /* Hill-curve denominator 1 + (dose/IC50)^hill = 1 + exp(hill (ln dose - ln IC50))   (doseresponse.py:84-88) */
-PHF_HD double phf_hill_den(int model, double ln_conc, double hill, double ln_ic50, phf_ktab k_exp, int split) {
+PHF_HD double phf_hill_den(int model, double ln_conc, double hill, double ln_ic50, phf_ktab k_exp) {
   const double a = (model == 1) ? (ln_conc - ln_ic50) : hill * (ln_conc - ln_ic50);
-  return 1.0 + phf_exp_capped_k(__builtin_fmin(a, PHF_HILL_ARG_CAP), k_exp, split);
+  return 1.0 + phf_exp_capped_k(__builtin_fmin(a, PHF_HILL_ARG_CAP), k_exp);
 }
 
 /* percent block from w = 1/(1 + x):  100 (1 - w) */
@@ -65,23 +65,17 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
   const double hill = (model == 1) ? 1.0 : th[1];
   const double sigma = (model == 1) ? th[1] : th[2];
   const double ln_ic50 = PHF_LN10 * (6.0 - pic50);
-  /* one division for 1/sigma, log sigma and log(sigma - loc) */
   const double sl = sigma - PHF_SIGMA_LOC;
-  const phf_logred lr_s = phf_log_reduce(sigma), lr_l = phf_log_reduce(sl);
-  const double ds = 2.0 + lr_s.f, dl = 2.0 + lr_l.f;
-  const double p1 = sigma * ds;
-  const double inv3 = phf_rcp(p1 * dl);
-  const double i1 = inv3 * dl;                    /* 1/(sigma ds) */
-  const double inv_s = i1 * ds;
-  const double log_sigma = phf_log_finish_k(lr_s, lr_s.f * (i1 * sigma), k_log);
-  const double log_sl = phf_log_finish_k(lr_l, lr_l.f * (inv3 * p1), k_log);
+  const double inv_s = phf_rcp(sigma);
+  const double log_sigma = phf_log_pos_k(sigma, k_log);
+  const double log_sl = phf_log_pos_k(sl, k_log);
 
   double sse = ss_within, cens = 0.0;
   int j = 0;
   for (; j + 4 <= n_other; j += 4) {              /* uncensored entries, four at a time (:247) */
     const phf_ktab ke = k_exp;
-    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
-    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke, 0), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50, ke, 0);
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke);
+    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke), d3 = phf_hill_den(model, lc[j + 3], hill, ln_ic50, ke);
     const double p01 = d0 * d1, p23 = d2 * d3;
     const double inv = phf_rcp(p01 * p23);
     const double i01 = inv * p23, i23 = inv * p01;
@@ -93,8 +87,8 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
   const int rem = n_other - j;                    /* 0..3 left: still one division */
   if (rem == 3) {
     const phf_ktab ke = k_exp;
-    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
-    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke, 0);
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke);
+    const double d2 = phf_hill_den(model, lc[j + 2], hill, ln_ic50, ke);
     const double p01 = d0 * d1;
     const double inv = phf_rcp(p01 * d2);
     const double i01 = inv * d2;
@@ -103,12 +97,12 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
     sse = phf_fma(w[j] * r0, r0, sse); sse = phf_fma(w[j + 1] * r1, r1, sse); sse = phf_fma(w[j + 2] * r2, r2, sse);
   } else if (rem == 2) {
     const phf_ktab ke = k_exp;
-    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke);
     const double inv = phf_rcp(d0 * d1);
     const double r0 = y[j] - PHF_PCT_(inv * d1), r1 = y[j + 1] - PHF_PCT_(inv * d0);
     sse = phf_fma(w[j] * r0, r0, sse); sse = phf_fma(w[j + 1] * r1, r1, sse);
   } else if (rem == 1) {
-    const double r = y[j] - PHF_PCT_(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1)));
+    const double r = y[j] - PHF_PCT_(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp)));
     sse = phf_fma(w[j] * r, r, sse);
   }
   j = n_other;
@@ -116,7 +110,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
   for (; j + 2 <= n; j += 2) {                    /* censored entries, two at a time (:244-245) */
     PHF_KFETCH_UNLESS(k_erfcx, erfcx_resident, k_erfcx_resident, phf_k_erfcx, 24);   /* issued now, needed after the two exponentials */
     const phf_ktab ke = k_exp;
-    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke, 0), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke, 0);
+    const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke);
     const double inv = phf_rcp(d0 * d1);
     const double z0 = phf_censored_z(PHF_PCT_(inv * d1), y[j], inv_s);
     const double z1 = phf_censored_z(PHF_PCT_(inv * d0), y[j + 1], inv_s);
@@ -126,7 +120,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
   }
   for (; j < n; ++j) {
     PHF_KFETCH_UNLESS(k_erfcx, erfcx_resident, k_erfcx_resident, phf_k_erfcx, 24);
-    const double pred = PHF_PCT_(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp, 1)));
+    const double pred = PHF_PCT_(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp)));
     cens = phf_fma(w[j], phf_log_ndtr_nonpos_kx(phf_censored_z(pred, y[j], inv_s), k_erfcx, erfcx_resident, k_log), cens);
   }
   double a = cens - pi_bit;
@@ -170,15 +164,12 @@ PHF_HD double phf_mh_common_draws(int d, phf_u32x4 b, phf_ktab k_log, phf_ktab k
     ua = phf_unit_open24(b.w[0] >> 8); ang_a = (b.w[0] << 24) | ((b.w[1] >> 8) & 0x00ffff00u);   /* 8 + 16 angle bits */
     u = phf_unit_open32(b.w[3]);
   }
-  const phf_logred la = phf_log_reduce(ua), lu = phf_log_reduce(u);                                /* the two logarithms share one division */
-  const double da = 2.0 + la.f, du = 2.0 + lu.f;
-  const double inv = phf_rcp(da * du);
-  const double log_ua = phf_log_finish_k(la, la.f * (inv * du), k_log);
+  const double log_ua = phf_log_pos_k(ua, k_log);
   double sn, cs;
   phf_sincos_2pi_u32_k(ang_a, &sn, &cs, k_sc);
   const double ra = phf_sqrt_pos(-2.0 * log_ua);
   z[0] = ra * cs; z[1] = ra * sn;
-  const double log_u = phf_log_finish_k(lu, lu.f * (inv * da), k_log);
+  const double log_u = phf_log_pos_k(u, k_log);
   if (d != 2) return log_u;                          /* d == 3: u = (w + 1/2) / 2^32 is never 0 */
   return (u < PHF_DBL_MIN) ? -PHF_INF : log_u;       /* d == 2: u == 0 (probability 2^-53): log 0 = -inf, accept */
 }
@@ -186,8 +177,7 @@ PHF_HD double phf_mh_common_draws(int d, phf_u32x4 b, phf_ktab k_log, phf_ktab k
 /* pair B of a block (d == 3): radius from 16 + 8 bits, angle from 24 bits */
 PHF_HD void phf_mh_pair_b(phf_u32x4 b, phf_ktab k_log, phf_ktab k_sc, double* cos_half, double* sin_half) {
   const double ub = phf_unit_open24(((b.w[1] & 0xffffu) << 8) | (b.w[2] >> 24));
-  const phf_logred lb = phf_log_reduce(ub);
-  const double log_ub = phf_log_finish_k(lb, phf_div(lb.f, 2.0 + lb.f), k_log);
+  const double log_ub = phf_log_pos_k(ub, k_log);
   double sn, cs;
   phf_sincos_2pi_u32_k(b.w[2] << 8, &sn, &cs, k_sc);
   const double rb = phf_sqrt_pos(-2.0 * log_ub);

@@ -34,6 +34,7 @@ struct PredArgs {
 };
 
 __global__ __launch_bounds__(kThreads) void pred_partial_kernel(const PredArgs a) {
+  PHF_MATH_TABLES_TO_LDS();
   __shared__ double s_par[4][PHF_PRED_TILE];
   const int q = blockIdx.z, tile = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);

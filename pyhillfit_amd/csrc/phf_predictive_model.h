@@ -42,8 +42,8 @@ PHF_HD void phf_pred_accumulate2(double lna, double beta, double mu, double inv_
   for (int j = 0; j < 2; ++j) {
     const double w = beta * (lna - lnx[j]);                 /* ln (x/alpha)^-beta */
     const double z = (mu - px[j]) * inv_s;                  /* -(x-mu)/s */
-    u[j] = phf_exp_capped_k(__builtin_fmin(w, PHF_PRED_EXP_CAP), k_exp, 1);
-    v[j] = phf_exp_capped_k(__builtin_fmin(z, PHF_PRED_EXP_CAP), k_exp, 1);
+    u[j] = phf_exp_capped_k(__builtin_fmin(w, PHF_PRED_EXP_CAP), k_exp);
+    v[j] = phf_exp_capped_k(__builtin_fmin(z, PHF_PRED_EXP_CAP), k_exp);
     a[j] = 1.0 + u[j];
     b[j] = 1.0 + v[j];
   }

@@ -124,7 +124,7 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   double ll1 = sp[(size_t)(2 * D + 3 + NTRI) * nchains];   // untempered log-likelihood of the current state
   // exp and log coefficients: in VGPRs for the whole launch (17 doubles)
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   // the 24 erfcx coefficients too when this wavefront owns the whole register file (no scalar-cache refetch per use)
   double k_erfcx_buf[ERFCX_IN_VGPRS ? 24 : 1];
@@ -298,6 +298,7 @@ __device__ __forceinline__ void run_block(const AdvanceArgs& a, double* s_pts, i
 // the counter so that every wavefront drains.
 template <int MODEL, bool MOMENTS, int WPS>
 __global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceArgs a) {
+  PHF_MATH_TABLES_TO_LDS();
   extern __shared__ double s_pts[];
   const bool queued = a.queue != nullptr;                         // wave-uniform; ONE call site of run_block serves both kinds of launch
   const int nblocks = a.blocks_per_problem * a.prob.num_problems;
@@ -357,6 +358,7 @@ struct InitArgs {
 
 template <int MODEL>
 __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
+  PHF_MATH_TABLES_TO_LDS();
   constexpr int D = Dim<MODEL>::d;
   constexpr int NTRI = D * (D + 1) / 2;
   extern __shared__ double s_pts[];
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
   for (int i = 0; i < D; ++i) th[i] = a.theta0[(size_t)i * nchains + g];
   double lik0, prior0, ll10;
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   phf_sl_log_target(MODEL, s_pts, s_pts + a.pts.stride, s_pts + 2 * a.pts.stride, n_other, n_zero + n_hundred,
                     a.pts.extra[2 * pair], a.pts.extra[2 * pair + 1], a.pts.pi_bit[pair], a.prob.temperature[q],
                     th, k_exp, k_log, nullptr, 0, &lik0, &prior0, &ll10);
@@ -405,6 +407,7 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, int64_t m, const int32_t* pair_index,
                                                           const double* temperature, const double* theta,
                                                           double* out_lik, double* out_prior) {
+  PHF_MATH_TABLES_TO_LDS();
   constexpr int D = Dim<MODEL>::d;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
   for (int k = 0; k < D; ++k) th[k] = theta[(size_t)k * m + i];
   double lik, prior, ll1;
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
-  PHF_KFETCH_V(k_log, phf_k_log, 7);
+  PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   phf_sl_log_target(MODEL, pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride,
                     pts.weight + (size_t)pair * pts.stride, cnt[0], cnt[1] + cnt[2], pts.extra[2 * pair], pts.extra[2 * pair + 1],
                     pts.pi_bit[pair], temperature[i], th, k_exp, k_log, nullptr, 0, &lik, &prior, &ll1);
@@ -424,6 +427,7 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
 }
 
 __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* out) {
+  PHF_MATH_TABLES_TO_LDS();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double x = in[i];

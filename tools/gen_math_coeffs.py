@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Derive the polynomial coefficients used by pyhillfit_amd/csrc/phf_math.h (mpmath, 60 digits).
+"""Derive the tables and polynomial coefficients used by pyhillfit_amd/csrc/phf_math.h (mpmath, 60 digits).
 
 Chebyshev interpolation (near-minimax) of each kernel function, converted to the monomial basis
 and rounded to double; the reported max relative error is measured against mpmath on a dense grid
@@ -72,29 +72,50 @@ def show(name, coefs):
 
 
 def gen_exp():
-    a = mp.log(2) / 2 * mp.mpf("1.0001")
-    q = lambda r: (mp.exp(r) - 1 - r) / (r * r) if abs(r) > mp.mpf('1e-15') else mp.mpf(1) / 2 + r / 6
-    for deg in (8, 9, 10):
+    """exp(x) = 2^k * T[j] * (1 + p(r)), n = nearest integer to 64 x / ln2 = 64 k + j, r = x - n ln2/64 (|r| <= ln2/128),
+    T[j] = 2^(j/64) (64 doubles, correctly rounded), p(r) = r + r^2/2 + r^3 q(r), q degree 2."""
+    print("/* 2^(j/64), j = 0..63 */")
+    row = [float(mp.mpf(2) ** (mp.mpf(j) / 64)).hex() for j in range(64)]
+    for i in range(0, 64, 4):
+        print("    " + ", ".join(row[i:i + 4]) + ",")
+    a = mp.log(2) / 128 * mp.mpf("1.001")
+    q = lambda r: (mp.expm1(r) - r - r * r / 2) / r ** 3 if abs(r) > mp.mpf('1e-12') else mp.mpf(1) / 6 + r / 24
+    for deg in (1, 2, 3):
         c = to_double(cheb_fit(q, -a, a, deg))
-        err = max_rel_err(lambda r: 1 + r + r * r * horner(c, r), mp.exp, -a, a)
+        err = max_rel_err(lambda r: 1 + r + r * r / 2 + r ** 3 * horner(c, r), mp.exp, -a, a)
         print("exp: q deg", deg, "rel err", mp.nstr(err, 3))
-    c = to_double(cheb_fit(q, -a, a, 9))
-    show("exp: (exp(r)-1-r)/r^2, |r|<=ln2/2", c)
+    show("exp: (expm1(r) - r - r^2/2)/r^3, |r| <= ln2/128", to_double(cheb_fit(q, -a, a, 2)))
+
+
+LOG_LO = 0x3fe6a09e667f3bcd            # bits of the smallest reduced mantissa m (sqrt(1/2) rounded up)
 
 
 def gen_log():
-    smax = (mp.sqrt(2) - 1) / (mp.sqrt(2) + 1) * mp.mpf("1.0001")
-    zmax = smax ** 2
-    # log((1+s)/(1-s)) = 2s + s*z*G(z),  G(z) = sum 2/(2k+3) z^k
-    G = lambda z: (mp.log((1 + mp.sqrt(z)) / (1 - mp.sqrt(z))) - 2 * mp.sqrt(z)) / (mp.sqrt(z) * z) if z > mp.mpf('1e-20') else mp.mpf(2) / 3
-    for deg in (5, 6, 7):
-        c = to_double(cheb_fit(G, mp.mpf(0), zmax, deg))
-        f = lambda s: 2 * s + s * s * s * horner(c, s * s)
-        ex = lambda s: mp.log((1 + s) / (1 - s))
-        err = max_rel_err(f, ex, mp.mpf("1e-6"), smax)
-        print("log: G deg", deg, "rel err", mp.nstr(err, 3))
-    c = to_double(cheb_fit(G, mp.mpf(0), zmax, 6))
-    show("log: G(z), z=s^2<=0.02944", c)
+    """log(x) = k ln2 + log c_j + log1p(r): x = 2^k m, m in [sqrt(1/2), sqrt 2); c_j = the double whose bits are (base + j) << 45
+    nearest to m (129 grid points, c = 1 among them); r = m * invc_j - 1 by one fma (|r| <= 2^-8);
+    table: invc_j = 1/c_j rounded, logc_j = -log(invc_j); log1p(r) = r + r^2 q(r), q degree 4 (q(0) = -1/2 exactly)."""
+    import struct
+    frombits = lambda u: struct.unpack('<d', struct.pack('<Q', u))[0]
+    base = (LOG_LO + (1 << 44)) >> 45
+    n = (((LOG_LO + (1 << 52)) + (1 << 44)) >> 45) - base + 1
+    print("/* log table: base %s, %d entries {1/c, log c} */" % (hex(base), n))
+    worst = mp.mpf(0)
+    for j in range(n):
+        c = frombits((base + j) << 45)
+        invc = float(1 / mp.mpf(c))
+        logc = float(-mp.log(mp.mpf(invc)))
+        print("    {%s, %s},%s" % (invc.hex(), logc.hex(), "   /* c = %.10g */" % c if j % 16 == 0 or c == 1.0 else ""))
+        lo = frombits(max(((base + j) << 45) - (1 << 44), LOG_LO))
+        hi = frombits(min(((base + j) << 45) + (1 << 44) - 1, LOG_LO + (1 << 52) - 1))
+        worst = max(worst, abs(mp.mpf(lo) * invc - 1), abs(mp.mpf(hi) * invc - 1))
+    print("log: max |r|", mp.nstr(worst, 8))
+    w = worst * mp.mpf("1.001")
+    q = lambda r: (mp.log1p(r) - r) / (r * r) if abs(r) > mp.mpf('1e-20') else -mp.mpf(1) / 2 + r / 3
+    for deg in (3, 4, 5):
+        c = to_double(cheb_fit(q, -w, w, deg))
+        err = max_rel_err(lambda r: r + r * r * horner(c, r), mp.log1p, -w, w, 4000)   # even count: r = 0 is not sampled
+        print("log: q deg", deg, "rel err of log1p", mp.nstr(err, 3), "q(0) + 1/2 =", c[0] + 0.5)
+    show("log: (log1p(r) - r)/r^2, |r| <= 2^-8", to_double(cheb_fit(q, -w, w, 4)))
 
 
 def gen_erfcx():
