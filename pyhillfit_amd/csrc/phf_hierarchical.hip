@@ -4,7 +4,7 @@
 // chains of the same (drug, channel) pair in lock-step.  The kernel is compiled per Ne so that theta, mean and the
 // proposal live in registers with static indices.  What does not fit in registers is the adapted covariance: its factors
 // cov = L diag(d) L' (PHF_LDL_COLUMN below; dim(dim+1)/2 = 66..153 doubles per chain) live in LDS as
-// L[element][lane] (stride 64 doubles: every ds_read/ds_write is conflict-free, 34..78 KB per wavefront) for the
+// L[element][lane] (stride 64 doubles: every ds_read/ds_write is conflict-free, 28..105 KB per wavefront; the one-lane kernels keep the diagonal in registers) for the
 // whole launch, so that its two passes per iteration (y = L z, and the rank-one adaptation update) cost no HBM
 // traffic at all.  HBM sees the state once per launch and the thinned samples.
 #include <hip/hip_runtime.h>
@@ -62,14 +62,16 @@ struct HierArgs {
   double* row0;
 };
 
-// One lane per chain: the factors (unit lower L, d in the diagonal slots) in LDS ([tri][64] doubles, 34..78 KB per wavefront: at most
-// 4 wavefronts per CU, one per SIMD) and all 512 registers for the iteration.
+// One lane per chain: the strictly lower triangle of L in LDS ([dim(dim-1)/2][64] doubles, 28..105 KB per wavefront: at most 4
+// wavefronts per CU, one per SIMD), the diagonal d in registers, and all 512 registers for the iteration.  (LDS is what the four
+// groups of C4 compete for — a CU holds its four wavefronts only if their footprints add up to 160 KB: +2.5 KB per wavefront cost
+// 5 % of C4 on one box — so the diagonal, 11..21 doubles that the exp / log tables' shorter coefficient sets pay for, left LDS.)
 template <int NE>
 struct Lds {
   static constexpr int dim = 5 + 2 * NE;
-  static constexpr int tri = dim * (dim + 1) / 2;
+  static constexpr int slots = dim * (dim - 1) / 2;
   static size_t point_bytes(int stride) { return (size_t)stride * 16 + (NE + 1) * 4 + 8; }
-  static size_t bytes(int stride) { return (size_t)tri * kBlock * 8 + point_bytes(stride); }
+  static size_t bytes(int stride) { return (size_t)slots * kBlock * 8 + point_bytes(stride); }
 };
 
 template <int NE>
@@ -90,9 +92,9 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
                                                   const int* s_es, int q, int c) {
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
-  double* sL = s_mem + threadIdx.x;                        // factor element e: sL[e * 64]
-#define PHF_LGET(e) sL[(e) * kBlock]
-#define PHF_LSET(e, v) sL[(e) * kBlock] = (v)
+  double* sL = s_mem + threadIdx.x;                        // element (i, k < i) of L: sL[(i (i - 1) / 2 + k) * 64]; the diagonal d: dg[]
+#define PHF_LGET(i, k) sL[((i) * ((i) - 1) / 2 + (k)) * kBlock]
+#define PHF_LSET(i, k, v) sL[((i) * ((i) - 1) / 2 + (k)) * kBlock] = (v)
   const int C = a.prob.chains_per_problem;
   const uint32_t pid = a.prob.problem_id[q];
   const uint32_t cid = a.prob.chain_id_base + (a.prob.chain_offset ? a.prob.chain_offset[q] : 0u) + (uint32_t)c;
@@ -100,7 +102,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   const size_t nchains = (size_t)a.prob.num_problems * C;
   const size_t g = (size_t)q * C + c;
 
-  double th[D], mean[D];
+  double th[D], mean[D], dg[D];
   // element k of this lane's state: a wave-uniform base (scalar registers, recomputed by the scalar unit) + the lane number, so that
   // the ~60 distinct addresses of an iteration cost no vector registers (as per-lane 64-bit pointers they were hipcc's first spill victims)
   double* const sbase = a.state + ((size_t)q * C + (size_t)(c - (int)threadIdx.x));
@@ -112,7 +114,11 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #pragma unroll
   for (int i = 0; i < D; ++i) mean[i] = PHF_SP(D + 1 + i);
 #pragma unroll
-  for (int e = 0; e < TRI; ++e) PHF_LSET(e, PHF_SP(2 * D + 1 + e));
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int k = 0; k < i; ++k) PHF_LSET(i, k, PHF_SP(2 * D + 1 + i * (i + 1) / 2 + k));
+    dg[i] = PHF_SP(2 * D + 1 + i * (i + 1) / 2 + i);
+  }
   double loga = PHF_SP(2 * D + 1 + TRI);
   double nacc = PHF_SP(2 * D + 2 + TRI);
   // coefficient tables in VGPRs for the launch: a lone wavefront cannot hide the scalar-load latency
@@ -132,10 +138,10 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   // starts); once adapting, the update sweep below produces it from the elements it has in registers anyway.
 #define PHF_PLAIN_LU(zz, yy)                                                                              \
   do {                                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < D; ++i) (zz)[i] = phf_sqrt_nonneg(PHF_LGET(i * (i + 1) / 2 + i)) * (zz)[i]; \
+    _Pragma("unroll") for (int i = 0; i < D; ++i) (zz)[i] = phf_sqrt_nonneg(dg[i]) * (zz)[i];             \
     _Pragma("unroll") for (int i = 0; i < D; ++i) {                                                       \
       double v_ = 0.0;                                                                                    \
-      _Pragma("unroll") for (int k = 0; k < i; ++k) v_ = phf_fma(PHF_LGET(i * (i + 1) / 2 + k), (zz)[k], v_); \
+      _Pragma("unroll") for (int k = 0; k < i; ++k) v_ = phf_fma(PHF_LGET(i, k), (zz)[k], v_);            \
       (yy)[i] = v_ + (zz)[i];                                                                             \
     }                                                                                                     \
   } while (0)
@@ -163,9 +169,11 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
     // ---- the factors for the sweep, read from LDS HERE — ahead of the draws, whose ~700 instructions cover the LDS latency a lone
     // wavefront would otherwise wait out element by element inside the sweep (same box: Ne = 3 group 13.80 -> 13.62 ms, Ne = 4 6.37 ->
     // 6.17, C4 19.11 -> 18.86) — and the draws of iteration t + 1 (a function of (chain, t + 1) alone) ----
-    double Lr[TRI];
+    double Lr[TRI - D];
 #pragma unroll
-    for (int e = 0; e < TRI; ++e) Lr[e] = PHF_LGET(e);
+    for (int i = 1; i < D; ++i)
+#pragma unroll
+      for (int k = 0; k < i; ++k) Lr[i * (i - 1) / 2 + k] = PHF_LGET(i, k);
     double zn[D];
     log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, k_sc, 1, zn, 1);
     // ---- adaptation (:495-501): cov <- (1-g) cov + g v v' applied to the L D L' factors as a rank-one update (PHF_LDL_COLUMN),
@@ -187,15 +195,15 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         double dn, beta;
-        PHF_LDL_COLUMN(omg, alpha, w[k], Lr[k * (k + 1) / 2 + k], dn, beta);
-        PHF_LSET(k * (k + 1) / 2 + k, dn);
+        PHF_LDL_COLUMN(omg, alpha, w[k], dg[k], dn, beta);
+        dg[k] = dn;
         zn[k] = phf_sqrt_nonneg(dn) * zn[k];               // u_k of the next proposal
 #pragma unroll
         for (int i = k + 1; i < D; ++i) {
-          const double lik = Lr[i * (i + 1) / 2 + k];
+          const double lik = Lr[i * (i - 1) / 2 + k];
           w[i] = phf_fma(-w[k], lik, w[i]);
           const double nl = phf_fma(beta, w[i], lik);
-          PHF_LSET(i * (i + 1) / 2 + k, nl);
+          PHF_LSET(i, k, nl);
           y[i] = phf_fma(nl, zn[k], y[i]);
         }
         y[k] = y[k] + zn[k];
@@ -214,7 +222,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
         out += row_stride;
       }
       if (want_moments && t > a.moments_after) {
-        // registers and LDS are full (512 registers + AGPR spills, 34..78 KB of factor): the running sums live in HBM and are
+        // registers and LDS are full (512 registers + AGPR spills, 28..105 KB of factor): the running sums live in HBM and are
         // advanced by fire-and-forget fp64 atomics — one lane per address, so the sums are the sequential ones; a
         // load-add-store here made the lone wavefront wait for 24 loads per saved sample (C4 +5.6 %)
 #pragma unroll
@@ -234,7 +242,11 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #pragma unroll
   for (int i = 0; i < D; ++i) PHF_SP(D + 1 + i) = mean[i];
 #pragma unroll
-  for (int e = 0; e < TRI; ++e) PHF_SP(2 * D + 1 + e) = PHF_LGET(e);
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int k = 0; k < i; ++k) PHF_SP(2 * D + 1 + i * (i + 1) / 2 + k) = PHF_LGET(i, k);
+    PHF_SP(2 * D + 1 + i * (i + 1) / 2 + i) = dg[i];
+  }
   PHF_SP(2 * D + 1 + TRI) = loga;
   PHF_SP(2 * D + 2 + TRI) = nacc;
 #undef PHF_PLAIN_LU
@@ -247,7 +259,7 @@ template <int NE>
 __global__ __launch_bounds__(kBlock, 1) void hier_advance_kernel(const HierArgs a) {
   extern __shared__ double s_mem[];
   PHF_MATH_TABLES_TO_LDS();
-  double* s_lc = s_mem + (size_t)Lds<NE>::tri * kBlock;
+  double* s_lc = s_mem + (size_t)Lds<NE>::slots * kBlock;
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
   const int slot = blockIdx.x / a.blocks_per_problem;
