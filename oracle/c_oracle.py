@@ -153,6 +153,14 @@ def sincos(w):
     return s, c
 
 
+def normal_u32(w):
+    """the single-level sampler's standard normal of a 32-bit word (phf_math.h: phf_normal_u32)"""
+    w = np.ascontiguousarray(w, dtype=np.uint32)
+    out = np.empty(w.size)
+    lib().phfo_vec_normal_u32(C.c_int64(w.size), _p(w), _p(out))
+    return out
+
+
 def philox(ctr_key):
     ck = np.ascontiguousarray(ctr_key, dtype=np.uint32).reshape(-1, 6)
     out = np.empty((ck.shape[0], 4), dtype=np.uint32)

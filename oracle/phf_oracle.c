@@ -131,7 +131,7 @@ static void advance_generic(int d, target_fn target, const void* ctx, const phfo
       log_u = phf_log(u_replay[t - run->t_begin - 1]);
     } else {
       /* PyHillFit.py:831/485 — theta* ~ N(theta, e^loga cov) drawn as theta + e^(loga/2) L z */
-      log_u = phf_mh_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, phf_k_log, phf_k_sincos, z);
+      log_u = phf_mh_draws(d, run->chain_id, run->problem_id, (uint32_t)t, run->seed_lo, run->seed_hi, phf_k_log, z);
       for (int i = 0; i < d; ++i) {
         double yv = L[i * (i + 1) / 2 + i] * z[i];
         for (int k = i - 1; k >= 0; --k) yv = phf_fma(L[i * (i + 1) / 2 + k], z[k], yv);
@@ -280,6 +280,10 @@ void phfo_vec_log_ndtr_nonpos_x2(int64_t n, const double* x, double* out) {
   for (int64_t i = 0; i + 1 < n; i += 2) phf_log_ndtr_nonpos_x2(x[i], x[i + 1], &out[i], &out[i + 1]);
 }
 
+void phfo_vec_normal_u32(int64_t n, const uint32_t* w, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = phf_normal_u32(w[i]);
+}
+
 void phfo_vec_sincos(int64_t n, const uint32_t* w, double* sn, double* cs) {
   for (int64_t i = 0; i < n; ++i) phf_sincos_2pi_u32(w[i], &sn[i], &cs[i]);
 }
@@ -295,7 +299,7 @@ void phfo_philox(int64_t n, const uint32_t* ctr_key /* [n][6] */, uint32_t* out 
 /* the normals and log(u) of iteration t of a chain, exactly as the samplers draw them */
 void phfo_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
                 double* z /* [4] */, double* log_u) {
-  *log_u = phf_mh_draws(d, chain_id, problem_id, t, seed_lo, seed_hi, phf_k_log, phf_k_sincos, z);
+  *log_u = phf_mh_draws(d, chain_id, problem_id, t, seed_lo, seed_hi, phf_k_log, z);
 }
 
 /* ---- posterior-predictive curves: twin of phf_predictive_accumulate (python/construct_hierarchical_cdfs.py:32-58) ----

@@ -626,6 +626,174 @@ PHF_HD void phf_sincos_2pi_u32_k(uint32_t w, double* sn, double* cs, phf_ktab k)
 
 PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) { PHF_KFETCH_V(k, phf_k_sincos, 12); phf_sincos_2pi_u32_k(w, sn, cs, k); }
 
+/* ------------------------------------------------------------------------------------------------ standard normal
+ * One standard normal from one 32-bit word by a piecewise inverse CDF (the single-level sampler's proposals; the hierarchical
+ * sampler keeps Box-Muller, its LDS is full): w = the low 31 bits, p = (w + 1/2) / 2^32 in (0, 1/2), |z| = -Phi^-1(p), the sign
+ * is the top bit — so v and v ^ 2^31 give +-z: the proposal is exactly symmetric, which is all Metropolis needs, and |z| <= 6.34.
+ * a = 2 w + 1 = 2^E m converts to a double exactly; its exponent and two mantissa bits select one of 128 intervals, on which
+ * |z| = P(m - 1), degree 5 (max error 4.4e-9 over all intervals: tools/gen_math_coeffs.py normal) — 6 fp64 operations and three
+ * 16-byte LDS reads where Box-Muller spent a logarithm, a square root and half a sine/cosine pair (~21).  The table (6 KB) goes
+ * to LDS with PHF_NORMAL_TABLE_TO_LDS() in the kernels that draw with it. */
+#define PHF_NORMAL_TAB_N 128
+typedef struct { double c[6]; } phf_normtab;
+static const phf_normtab phf_t_normal[PHF_NORMAL_TAB_N] = {
+    {{0x1.95a1198e14418p+2, -0x1.3b9fc1bb6c69dp-3, 0x1.34339dd030bf6p-4, -0x1.93529ba159b71p-5, 0x1.14a12e05662a6p-5, -0x1.0f87a210ea2d9p-6}},
+    {{0x1.95a0ea99ed462p+2, -0x1.3b378d5c7917cp-3, 0x1.2e2ee0317a3efp-4, -0x1.64651173421bbp-5, 0x1.6692ddc48b0f5p-6, -0x1.8e2ff230dbf1cp-8}},
+    {{0x1.959f3f3705db7p+2, -0x1.392b531249d00p-3, 0x1.1de00cce9c160p-4, -0x1.227a51efdc39dp-5, 0x1.bea74476fe4f6p-7, -0x1.59ceaad6c8bf8p-9}},
+    {{0x1.959a43173ca3bp+2, -0x1.3507773278c54p-3, 0x1.07b9666c037dcp-4, -0x1.cda6d95bebc0cp-6, 0x1.1cf37cb5a91ffp-7, -0x1.52ad7da7e8973p-10}},
+    {{0x1.8ebc9502cd7a4p+2, -0x1.40d4cfa4f89e1p-3, 0x1.390b37ac7a2e8p-4, -0x1.9984d4d0849e0p-5, 0x1.18d2af06be7ddp-5, -0x1.139d799332a2ep-6}},
+    {{0x1.8ebc655a2d3e3p+2, -0x1.406b0ae695bb6p-3, 0x1.32ef5d3fb4d49p-4, -0x1.69e330dc6ee31p-5, 0x1.6c0b3c404b895p-6, -0x1.943ae460d0061p-8}},
+    {{0x1.8ebab381c7c8bp+2, -0x1.3e56e4fcf3f57p-3, 0x1.22617adc92731p-4, -0x1.26f9a1c762b1ep-5, 0x1.c582add5dbf21p-7, -0x1.5f17d55f7c365p-9}},
+    {{0x1.8eb5a3fa32222p+2, -0x1.3a22ebdfc4315p-3, 0x1.0be4a07da11c8p-4, -0x1.d4d543d1e74a1p-6, 0x1.2159d2d9336a5p-7, -0x1.57e3014eb2484p-10}},
+    {{0x1.87ba7890f9ceep+2, -0x1.464d16df6892dp-3, 0x1.3e1e2289f4ba3p-4, -0x1.a0013696fdd19p-5, 0x1.1d35b0aa58d42p-5, -0x1.17e32c8f65e3fp-6}},
+    {{0x1.87ba482ba2c5cp+2, -0x1.45e1af7b73392p-3, 0x1.37ea1d63d7223p-4, -0x1.6fa342e5866b4p-5, 0x1.71c498298afadp-6, -0x1.9a8d3ea1bb200p-8}},
+    {{0x1.87b88f91bf93dp+2, -0x1.43c540c6d6f5bp-3, 0x1.271a466f12271p-4, -0x1.2baf308ca813ep-5, 0x1.ccb0143ca5837p-7, -0x1.649feb01386ecp-9}},
+    {{0x1.87b36bbc993f8p+2, -0x1.3f806ba821cc5p-3, 0x1.10433bbdefad0p-4, -0x1.dc5ab67fe0a71p-6, 0x1.25f512826d1dcp-7, -0x1.5d56ea0004446p-10}},
+    {{0x1.80993fb0b3d6cp+2, -0x1.4c0e633209b13p-3, 0x1.4371333d3a2ddp-4, -0x1.a6cda638eb47bp-5, 0x1.21ce142dba020p-5, -0x1.1c5c73aacb877p-6}},
+    {{0x1.80990e85c4cbdp+2, -0x1.4ba1457795a46p-3, 0x1.3d23e086a6646p-4, -0x1.75aa8a0193539p-5, 0x1.77c411f7c2d2ep-6, -0x1.a12c9afcc8f5bp-8}},
+    {{0x1.80974ed874a4fp+2, -0x1.497c29861e0bdp-3, 0x1.2c0ef58c2659bp-4, -0x1.309f56ed8acc4p-5, 0x1.d435fa28f1dfep-7, -0x1.6a6be4b03be3cp-9}},
+    {{0x1.809215bdea211p+2, -0x1.4525aaa3db7e9p-3, 0x1.14d96e0715c4fp-4, -0x1.e43e332c9fc20p-6, 0x1.2ac975849e679p-7, -0x1.630e2e29270c6p-10}},
+    {{0x1.795743c3d603bp+2, -0x1.521f38c41f661p-3, 0x1.4909cf05c29dbp-4, -0x1.adf0b4cbbc3afp-5, 0x1.26a02a3993665p-5, -0x1.210d7188f03e3p-6}},
+    {{0x1.795711c9b7ef4p+2, -0x1.51b04f6f36c6dp-3, 0x1.42a1f4a9db3f9p-4, -0x1.7bfee269d75edp-5, 0x1.7e0f5e5542b72p-6, -0x1.a81f3479b0c9ap-8}},
+    {{0x1.79554ab072446p+2, -0x1.4f8219b898ef4p-3, 0x1.314495dbb082fp-4, -0x1.35ceed43fd765p-5, 0x1.dc1b9f81fdf9bp-7, -0x1.70814b5e0e985p-9}},
+    {{0x1.794ffb4498c7fp+2, -0x1.4b1912a344c3dp-3, 0x1.19abebd15b67dp-4, -0x1.ec878a724c0ffp-6, 0x1.2fdbb16521462p-7, -0x1.690e54da913c5p-10}},
+    {{0x1.71f2b7c5ea520p+2, -0x1.5886f282ded58p-3, 0x1.4eee01c9318c5p-4, -0x1.b571b8f8217cfp-5, 0x1.2bb0c35501662p-5, -0x1.25fac250189a9p-6}},
+    {{0x1.71f284f23b888p+2, -0x1.5816268e61b58p-3, 0x1.486a4bccc8fe0p-4, -0x1.82a6d93e52ff7p-5, 0x1.84acdc25f8303p-6, -0x1.af6bfee7e17f1p-8}},
+    {{0x1.71f0b60d1bab6p+2, -0x1.55de618541356p-3, 0x1.36c0d198d324cp-4, -0x1.3b435ee0d8970p-5, 0x1.e4691defbf005p-7, -0x1.76e64d6950bb0p-9}},
+    {{0x1.71eb4f2d9c2a3p+2, -0x1.5161e13060b5dp-3, 0x1.1ebffbcf209a8p-4, -0x1.f53f7b26938e3p-6, 0x1.353109fa113b6p-7, -0x1.6f5d8b74d199fp-10}},
+    {{0x1.6a69a342a06e0p+2, -0x1.5f4de6dd1124ep-3, 0x1.552498997416bp-4, -0x1.bd58ed9258543p-5, 0x1.31054363428f8p-5, -0x1.2b298e05a7feap-6}},
+    {{0x1.6a696f8a1cab4p+2, -0x1.5edb1f4da2322p-3, 0x1.4e83960c03a11p-4, -0x1.89a9c801bdd8dp-5, 0x1.8ba3aea79a607p-6, -0x1.b71ac30dea28ep-8}},
+    {{0x1.6a67987101752p+2, -0x1.5c994b4cb2bbdp-3, 0x1.3c8a08919d414p-4, -0x1.4102c0fd968aep-5, 0x1.ed278a81460e0p-7, -0x1.7da1d80c731dcp-9}},
+    {{0x1.6a6218e26868bp+2, -0x1.58084bd3a6053p-3, 0x1.241b8e57d657fp-4, -0x1.fe6fd7bc5f74dp-6, 0x1.3acf678b9144cp-7, -0x1.7602bf66b4f05p-10}},
+    {{0x1.62b9dc6b60b9bp+2, -0x1.667d947223dfdp-3, 0x1.5bb54187003e3p-4, -0x1.c5af962285045p-5, 0x1.36a3b8da28e99p-5, -0x1.309f9e63fa1efp-6}},
+    {{0x1.62b9a7c1c571dp+2, -0x1.6608b618d29aep-3, 0x1.54f560f9d5b0fp-4, -0x1.910ff56f895bdp-5, 0x1.92fbdc97b8bf4p-6, -0x1.bf34403b53865p-8}},
+    {{0x1.62b7c8034dba9p+2, -0x1.63bc4824e0ed3p-3, 0x1.42a76e28d0e4dp-4, -0x1.4713ee2b6300fp-5, 0x1.f6611dd6e4454p-7, -0x1.84bbb5b238713p-9}},
+    {{0x1.62b22e6dee3a3p+2, -0x1.5f15ac3583569p-3, 0x1.29c55987a5cb2p-4, -0x1.0411d97fcfc79p-5, 0x1.40bd7144d0991p-7, -0x1.7d05bce940a57p-10}},
+    {{0x1.5ae1011a4f28ep+2, -0x1.6e20d8d0e2d6ap-3, 0x1.62a8b207d6364p-4, -0x1.ce802ac2a4a65p-5, 0x1.3c92f88da0f08p-5, -0x1.366378f583583p-6}},
+    {{0x1.5ae0cb723b640p+2, -0x1.6da9c603f7216p-3, 0x1.5bc83d73bdc36p-4, -0x1.98e2bcef3c061p-5, 0x1.9abe758b2a328p-6, -0x1.c7c2547bdcae3p-8}},
+    {{0x1.5adee29298602p+2, -0x1.6b52265a6238dp-3, 0x1.49212d916712dp-4, -0x1.4d7ea7500ac0bp-5, 0x1.0010b22b9af45p-6, -0x1.8c3cb25472870p-9}},
+    {{0x1.5ad92d7eed065p+2, -0x1.6694b633a1f9fp-3, 0x1.2fc4fb3977bd2p-4, -0x1.0933caf5e31efp-5, 0x1.4702acf953a7cp-7, -0x1.846f53e5a444dp-10}},
+    {{0x1.52dc6e83992dap+2, -0x1.7644340e16b73p-3, 0x1.6a08d59a26fa9p-4, -0x1.d7d68d1b0f81dp-5, 0x1.42dabf28e8f35p-5, -0x1.3c7c7e7840986p-6}},
+    {{0x1.52dc37ce68086p+2, -0x1.75cacc560035fp-3, 0x1.6305ed963d83fp-4, -0x1.a12cbe42ab8cdp-5, 0x1.a2f5bef4cdd49p-6, -0x1.d0d02d0246241p-8}},
+    {{0x1.52da4545fcfe4p+2, -0x1.736754bd28056p-3, 0x1.500095d51960cp-4, -0x1.544bbb8dc4ea2p-5, 0x1.053abc31562f6p-6, -0x1.942ec75a0f022p-9}},
+    {{0x1.52d473186bf26p+2, -0x1.6e91baab7685bp-3, 0x1.36232255caad7p-4, -0x1.0ea4e06dfe8fcp-5, 0x1.4da7a58bb6fc9p-7, -0x1.8c49848496594p-10}},
+    {{0x1.4aa937440fcf2p+2, -0x1.7ef61ce7ea822p-3, 0x1.71e106c723edfp-4, -0x1.e1c048ca0aa0bp-5, 0x1.4983d9bd6c76ep-5, -0x1.42f310d50a39dp-6}},
+    {{0x1.4aa8ff71ac822p+2, -0x1.7e7a3c9dd9caep-3, 0x1.6ab99cec54b82p-4, -0x1.a9fa178405c59p-5, 0x1.abad6ac654a9bp-6, -0x1.da6a80d3b7368p-8}},
+    {{0x1.4aa702ab712bdp+2, -0x1.7c0a366a74236p-3, 0x1.57504faeca5d9p-4, -0x1.5b8538d81483fp-5, 0x1.0ab624843de32p-6, -0x1.9c9d50d3ebce2p-9}},
+    {{0x1.4aa1119f52088p+2, -0x1.771afaa673876p-3, 0x1.3ce9c161de3f1p-4, -0x1.146d3d7dec318p-5, 0x1.54b619a354ab6p-7, -0x1.949fb554b376cp-10}},
+    {{0x1.4244176422a21p+2, -0x1.88476a74a2810p-3, 0x1.7a3e55535f0d6p-4, -0x1.ec4ce2324dcabp-5, 0x1.50985738923b7p-5, -0x1.49d0c15673eeap-6}},
+    {{0x1.4243de62d4a81p+2, -0x1.87c8ea4fb1a5ap-3, 0x1.72f0259ed579ap-4, -0x1.b358ac27f933cp-5, 0x1.b4f2da2678847p-6, -0x1.e49fd85552174p-8}},
+    {{0x1.4241d6ba6cdf2p+2, -0x1.854b8c0ea1103p-3, 0x1.5f1c9fe2817e4p-4, -0x1.6336a77f55d12p-5, 0x1.108b783f5f7ddp-6, -0x1.a5954e8579b8fp-9}},
+    {{0x1.423bc4dc269f1p+2, -0x1.80410fdb5aee3p-3, 0x1.44244cd2fdff7p-4, -0x1.1a9639dfdfd32p-5, 0x1.5c3934de96012p-7, -0x1.9d7ef5883fb87p-10}},
+    {{0x1.39a965c5dfb40p+2, -0x1.924bda2c954dap-3, 0x1.832fdd4f3af36p-4, -0x1.f78e379856222p-5, 0x1.5823c51edf1d7p-5, -0x1.5120894b3ce16p-6}},
+    {{0x1.39a92b820d4b0p+2, -0x1.91ca8eb994e41p-3, 0x1.7bb8664a14ab7p-4, -0x1.bd587c8ee1a37p-5, 0x1.bed56f7a17d39p-6, -0x1.ef80e529cb880p-8}},
+    {{0x1.39a71841850d8p+2, -0x1.8f3ef96987426p-3, 0x1.6773b9970b56ap-4, -0x1.6b6d53b2f83ccp-5, 0x1.16c48f501de7fp-6, -0x1.af25b3e426506p-9}},
+    {{0x1.39a0e3678f039p+2, -0x1.8a177146380b4p-3, 0x1.4be008788e788p-4, -0x1.212a9dad9add3p-5, 0x1.643dd65c8b576p-7, -0x1.a6f64e8ffe48bp-10}},
+    {{0x1.30d502480e701p+2, -0x1.9d1abbb9f8380p-3, 0x1.8cc733f3870e7p-4, -0x1.01cc7cdb4f1f7p-4, 0x1.60337aa96342ap-5, -0x1.58ef0fed41a22p-6}},
+    {{0x1.30d4c6abf3339p+2, -0x1.9c9674b8e50a9p-3, 0x1.8523ad5660c7fp-4, -0x1.c80c12d35b425p-5, 0x1.c966f404560d9p-6, -0x1.fb20eee0c54bdp-8}},
+    {{0x1.30d2a70909702p+2, -0x1.99fbb0794f297p-3, 0x1.706625607462cp-4, -0x1.7438a8f288e36p-5, 0x1.1d6cce870d044p-6, -0x1.b95fcb39acb88p-9}},
+    {{0x1.30cc4ccb8ba0fp+2, -0x1.94b51d2ea7f4ap-3, 0x1.542c686b16a5cp-4, -0x1.2836ec63e498fp-5, 0x1.6cd2e8631b911p-7, -0x1.b117296475aa1p-10}},
+    {{0x1.27c23faa6e3aep+2, -0x1.a8cfcfc31f088p-3, 0x1.9718f0e7b0e44p-4, -0x1.0842a153c20e2p-4, 0x1.68d6f6662f67dp-5, -0x1.614b0150fbb9cp-6}},
+    {{0x1.27c2029dc2f48p+2, -0x1.a8485763dbe95p-3, 0x1.8f46405beb774p-4, -0x1.d3890b1441db1p-5, 0x1.d4bc16c899116p-6, -0x1.03cb2d38e38a2p-7}},
+    {{0x1.27bfd5b6a75e1p+2, -0x1.a59d4f775eaf6p-3, 0x1.7a07434833b62p-4, -0x1.7daaa4ba56817p-5, 0x1.24917a37f8622p-6, -0x1.c457b174bd91cp-9}},
+    {{0x1.27b9536563205p+2, -0x1.a03575b7fca71p-3, 0x1.5d1b8b76e8db1p-4, -0x1.2fc9c31359dacp-5, 0x1.7609ce28da071p-7, -0x1.bbf5cd3d4eb8bp-10}},
+    {{0x1.1e6bc7e762f2dp+2, -0x1.b58c6c7ff7466p-3, 0x1.a23d5ceb0ecefp-4, -0x1.0f37aa3116dfbp-4, 0x1.722053e1faaa3p-5, -0x1.6a457b642f73dp-6}},
+    {{0x1.1e6b894ef2e3ap+2, -0x1.b5018676059f5p-3, 0x1.9a38087005d65p-4, -0x1.dfe8bfa129739p-5, 0x1.e0ed0c47b95adp-6, -0x1.0a7daa41139f4p-7}},
+    {{0x1.1e694e2652d78p+2, -0x1.b245046c38d80p-3, 0x1.846df060f3a89p-4, -0x1.87d867907a628p-5, 0x1.2c421e6f09986p-6, -0x1.d024f217dda55p-9}},
+    {{0x1.1e62a0bc62921p+2, -0x1.acb962aa77f00p-3, 0x1.66c2d71cf5dc3p-4, -0x1.37f44fad1fbe9p-5, 0x1.7ff6ee86b8e03p-7, -0x1.c7a9ff709ef33p-10}},
+    {{0x1.14cb7939300c4p+2, -0x1.c37903625ce85p-3, 0x1.ae51522c35df0p-4, -0x1.16bc45ab10e08p-4, 0x1.7c24e0d17a8c4p-5, -0x1.73f297c129c0ap-6}},
+    {{0x1.14cb38f656cd1p+2, -0x1.c2ea6bc4c76cdp-3, 0x1.a6156f816eb8fp-4, -0x1.ed492474c25a8p-5, 0x1.ee165961c15dfp-6, -0x1.11b754a1e747ap-7}},
+    {{0x1.14c8ee6e8a3b8p+2, -0x1.c01b1191d2eadp-3, 0x1.8fb55b9fe6eb6p-4, -0x1.92daee2b27aacp-5, 0x1.3491138b520e8p-6, -0x1.dce34d589cb2fp-9}},
+    {{0x1.14c2128363e50p+2, -0x1.ba68d38ff04fdp-3, 0x1.713bc047c81d1p-4, -0x1.40cae9811878cp-5, 0x1.8ab264c372736p-7, -0x1.d44fcef5bdbc6p-10}},
+    {{0x1.0ada39481eebap+2, -0x1.d2c73023187a8p-3, 0x1.bb775f4c4915ap-4, -0x1.1ee44b2c75cf5p-4, 0x1.86fddbe892b49p-5, -0x1.7e6a1b8c6c972p-6}},
+    {{0x1.0ad9f7382874bp+2, -0x1.d2349a0a53eeap-3, 0x1.b3007f8f17c60p-4, -0x1.fbcde1a8f141fp-5, 0x1.fc59d76ba8c28p-6, -0x1.198a6c54f3a18p-7}},
+    {{0x1.0ad79c0d409fcp+2, -0x1.cf50dac042ff3p-3, 0x1.9bfe1a343e81cp-4, -0x1.9ed0000c577d8p-5, 0x1.3d942893af14bp-6, -0x1.eab3b634522d2p-9}},
+    {{0x1.0ad08dc236972p+2, -0x1.c974ca37ed590p-3, 0x1.7ca4d01871434p-4, -0x1.4a65d60d9c7e5p-5, 0x1.9658e4166927dp-7, -0x1.e20899e873356p-10}},
+    {{0x1.008fbaeac432bp+2, -0x1.e3b48e146e8f4p-3, 0x1.c9d944bbc4c48p-4, -0x1.27c785da28c6bp-4, 0x1.92c96b64efa0cp-5, -0x1.89c85a0361b2ep-6}},
+    {{0x1.008f76e626796p+2, -0x1.e31da1e33de73p-3, 0x1.c1225b218fd37p-4, -0x1.05d0e14d08c79p-4, 0x1.05f00270413b6p-5, -0x1.220cbda03677fp-7}},
+    {{0x1.008d09a68b95dp+2, -0x1.e023b8a78d0c9p-3, 0x1.a96f91fb1149fp-4, -0x1.abdb661aca18bp-5, 0x1.4765802d746a5p-6, -0x1.f9bd9b7d22aa2p-9}},
+    {{0x1.0085c48fc5385p+2, -0x1.da1a2a2f1c407p-3, 0x1.8922fa44898cep-4, -0x1.54e249947f029p-5, 0x1.a30cdf5beabacp-7, -0x1.f0fc60ea8c7dbp-10}},
+    {{0x1.ebc46276b7335p+1, -0x1.f68eb1ddcba88p-3, 0x1.d9a9eda073442p-4, -0x1.3182be496a255p-4, 0x1.9fabdeca6f163p-5, -0x1.962f5b46c9b3bp-6}},
+    {{0x1.ebc3d6297c7bep+1, -0x1.f5f30b1bad300p-3, 0x1.d0ad2fd6b96acp-4, -0x1.0e7c4c07b30e4p-4, 0x1.0e6cdeda742fdp-5, -0x1.2b5889f00debap-7}},
+    {{0x1.ebbed42fd84eep+1, -0x1.f2e0efd047d73p-3, 0x1.b839d9c72899ap-4, -0x1.ba2883254f8b8p-5, 0x1.5224b2364b9d4p-6, -0x1.05184b2e30d58p-8}},
+    {{0x1.ebafd23ee6e3dp+1, -0x1.eca5aad77cef0p-3, 0x1.96e36324ef7e4p-4, -0x1.6063b91a2781fp-5, 0x1.b0f80d678adb1p-7, -0x1.00adc20fa18d6p-9}},
+    {{0x1.d58bd05df59dbp+1, -0x1.05dc6e93b219fp-2, 0x1.eb2812d5e616cp-4, -0x1.3c391ac5e39c8p-4, 0x1.add15725e3fb6p-5, -0x1.a3c85feb0981ep-6}},
+    {{0x1.d58b3f63fa645p+1, -0x1.058c03e4f67fep-2, 0x1.e1ded10af6055p-4, -0x1.1808dc0d6e8b8p-4, 0x1.17c140a017a8fp-5, -0x1.358dbae931193p-7}},
+    {{0x1.d58612198df87p+1, -0x1.03f5b057b2d15p-2, 0x1.c8983bff8006cp-4, -0x1.c9ec72d5a02f7p-5, 0x1.5df84b53a44e7p-6, -0x1.0e2351c0267a1p-8}},
+    {{0x1.d5768c9b8eae4p+1, -0x1.00bcc0813d62ep-2, 0x1.a61dbfbc1ce4ap-4, -0x1.6d159c5288953p-5, 0x1.c04d6c5913cb5p-7, -0x1.09b088623aea4p-9}},
+    {{0x1.be596d5cf4928p+1, -0x1.11da30851d0b6p-2, 0x1.fea1c8d5d0ec0p-4, -0x1.4815f72ea4b9fp-4, 0x1.bd6ffc6828cafp-5, -0x1.b2c5e3e39bbd1p-6}},
+    {{0x1.be58d73c452c5p+1, -0x1.1186eafef51b2p-2, 0x1.f5043ab0255c3p-4, -0x1.229dac0396585p-4, 0x1.2211bdac7b657p-5, -0x1.40d37ba1ff25dp-7}},
+    {{0x1.be537a2757880p+1, -0x1.0fe1f2a781574p-2, 0x1.dad4997b7524bp-4, -0x1.db68e2b43cd56p-5, 0x1.6b0fce45ab78ap-6, -0x1.18238dc68644dp-8}},
+    {{0x1.be4363568f590p+1, -0x1.0c8ad9fbca41cp-2, 0x1.b7178a7352f59p-4, -0x1.7b2dcaa24191fp-5, 0x1.d14bf49d54696p-7, -0x1.13aaeb4d57952p-9}},
+    {{0x1.a60a6e7475412p+1, -0x1.1f96a727f246bp-2, 0x1.0a3ca80cc14cep-3, -0x1.554f6307f57bcp-4, 0x1.cecaf672b10bap-5, -0x1.c36651bf79046p-6}},
+    {{0x1.a609d29de01e2p+1, -0x1.1f40377f65db7p-2, 0x1.053f296c15994p-3, -0x1.2e6b8abc6af72p-4, 0x1.2d8bce45cbb32p-5, -0x1.4d5a5f9472a8dp-7}},
+    {{0x1.a604407a72ff4p+1, -0x1.1d8afd91530afp-2, 0x1.ef4c00127b603p-4, -0x1.eeefee0bcd45dp-5, 0x1.79a669a9e5b55p-6, -0x1.23455aa7e6114p-8}},
+    {{0x1.a5f3881ab4798p+1, -0x1.1a125dd3d8671p-2, 0x1.ca285b8beb7a8p-4, -0x1.8aefaffdef59ap-5, 0x1.e442406ef1ec5p-7, -0x1.1eca49a134f96p-9}},
+    {{0x1.8c735024f2e0cp+1, -0x1.2f8727f3cf328p-2, 0x1.1695ca66bf3d9p-3, -0x1.642986d34cd78p-4, 0x1.e23676d7f8b8cp-5, -0x1.d5f7ab7a13c11p-6}},
+    {{0x1.8c72adeec0d22p+1, -0x1.2f2d303131d9bp-2, 0x1.11642aa88f0f2p-3, -0x1.3bb012b7a504fp-4, 0x1.3a68962346e54p-5, -0x1.5b5f4f28ebdf3p-7}},
+    {{0x1.8c6ce07ba99a9p+1, -0x1.2d65ca6382119p-2, 0x1.033a6df43cea0p-3, -0x1.0274b0f286de2p-4, 0x1.8a06a95781c9ap-6, -0x1.2fc07d554aa08p-8}},
+    {{0x1.8c5b7339d465fp+1, -0x1.29c7a14f35e09p-2, 0x1.dfbfc5fcfc334p-4, -0x1.9cb0ade62f3a8p-5, 0x1.f993883a41e09p-7, -0x1.2b47d0b1b43afp-9}},
+    {{0x1.715c7c16567bfp+1, -0x1.42507d01d3016p-2, 0x1.24ac61df41040p-3, -0x1.74fb48bedb4b9p-4, 0x1.f81d3e292a62fp-5, -0x1.eadc89d08b6bbp-6}},
+    {{0x1.715bd2b553423p+1, -0x1.41f28ca6acb42p-2, 0x1.1f4026933df94p-3, -0x1.4ab9e498af632p-4, 0x1.48f0b437404d3p-5, -0x1.6b2f878fdf37cp-7}},
+    {{0x1.7155c270eb5b3p+1, -0x1.4016ae9c6d158p-2, 0x1.1073909dc7d13p-3, -0x1.0eecf85edc4c3p-4, 0x1.9c8f84d8ffdbap-6, -0x1.3ddbe09cf0a4dp-8}},
+    {{0x1.7143890e3fc45p+1, -0x1.3c4e29cbd938ap-2, 0x1.f86d0db7df36ep-4, -0x1.b0de18814ec53p-5, 0x1.08df3b7c200e9p-6, -0x1.396c61236beb7p-9}},
+    {{0x1.547d1738f1e96p+1, -0x1.58e272f9795fdp-2, 0x1.34e769b72fc0fp-3, -0x1.88349fcd30139p-4, 0x1.0884156a4de26p-4, -0x1.01497ad08b873p-5}},
+    {{0x1.547c65b724e04p+1, -0x1.588001df5165cp-2, 0x1.2f38bc0f42577p-3, -0x1.5bee68b066e29p-4, 0x1.598179d114fa5p-5, -0x1.7d2e15b61ccc8p-7}},
+    {{0x1.547609857a6c7p+1, -0x1.568ce1aeb61a0p-2, 0x1.1fb3214c4e517p-3, -0x1.1d367e963a5ffp-4, 0x1.b1bb48ae89937p-6, -0x1.4df2b299f8c4ep-8}},
+    {{0x1.5462e7bb67715p+1, -0x1.529423b0a0029p-2, 0x1.0a743fbc7c744p-3, -0x1.c805576b0fbc8p-5, 0x1.16b33e25d56e6p-6, -0x1.4995e23644b5fp-9}},
+    {{0x1.357292e09f5b7p+1, -0x1.74a99db6a509ep-2, 0x1.47c9b60a12b51p-3, -0x1.9e670ea731380p-4, 0x1.16d43d90bfd04p-4, -0x1.0edee05239852p-5}},
+    {{0x1.3571d810db0f8p+1, -0x1.7442052e981bfp-2, 0x1.41cefdaa1e025p-3, -0x1.6fd182ad17913p-4, 0x1.6c93f84dcba51p-5, -0x1.91db49bbb3b67p-7}},
+    {{0x1.356b24c331db0p+1, -0x1.7234368552d26p-2, 0x1.3175282fa5f3ep-3, -0x1.2dc0d42c2787fp-4, 0x1.ca28e44306ac3p-6, -0x1.607b517a3404dp-8}},
+    {{0x1.3556f7c5dcbc1p+1, -0x1.6e0407c6be3cbp-2, 0x1.1b0ddc6b1ef31p-3, -0x1.e2deb0dd65f01p-5, 0x1.26b02443c4dc1p-6, -0x1.5c3e6ee97c9cbp-9}},
+    {{0x1.13b22a7622494p+1, -0x1.97efe3d04a1cdp-2, 0x1.5df05fd924be5p-3, -0x1.b850bb11a8b1ep-4, 0x1.2772a90a88a14p-4, -0x1.1e9883147697bp-5}},
+    {{0x1.13b164e354efbp+1, -0x1.978255698a22ap-2, 0x1.579dbb17dd256p-3, -0x1.870f9d230af3cp-4, 0x1.82c6359e32ea4p-5, -0x1.a9de934c7a3ffp-7}},
+    {{0x1.13aa4c96b6510p+1, -0x1.9555982a66973p-2, 0x1.464de258f1989p-3, -0x1.411de345a2465p-4, 0x1.e6a7e89063369p-6, -0x1.76105b236947fp-8}},
+    {{0x1.1394e916c55dfp+1, -0x1.90e4fd2ea5c93p-2, 0x1.2e8e2b74161f4p-3, -0x1.012d9f870a887p-4, 0x1.3960d6860ca96p-6, -0x1.72059db2ea4e8p-9}},
+    {{0x1.dcdbfed47d6d0p+0, -0x1.c6a9cd60b6c89p-2, 0x1.77f045721a1f7p-3, -0x1.d6ebd894f229dp-4, 0x1.3af610580db83p-4, -0x1.3101064838134p-5}},
+    {{0x1.dcda5a82a1c7ap+0, -0x1.c63546abbb3bdp-2, 0x1.7136d53471961p-3, -0x1.a28bbb83d09d8p-4, 0x1.9ce60674696cdp-5, -0x1.c612b8a72f8bcp-7}},
+    {{0x1.dccb3d131192fp+0, -0x1.c3e445c1b60b8p-2, 0x1.5ec6982dd84e9p-3, -0x1.580e06e8f305dp-4, 0x1.04231071351d8p-5, -0x1.8f7b9f9973f51p-8}},
+    {{0x1.dc9d9c2dff856p+0, -0x1.bf27f460e58b8p-2, 0x1.4572214c8d3ffp-3, -0x1.13dcb501feaa7p-4, 0x1.4f7961e84a1eep-6, -0x1.8bbb72bd11b43p-9}},
+    {{0x1.88bc1fadc1d1dp+0, -0x1.04322d101845fp-1, 0x1.959c18d1761e4p-3, -0x1.fb972d0d84299p-4, 0x1.521edd6cf8cfbp-4, -0x1.46ccba7400e5cp-5}},
+    {{0x1.88ba5d94cc7f6p+0, -0x1.03f3ca8219704p-1, 0x1.8e6919b66d316p-3, -0x1.c3867392d1d3fp-4, 0x1.bbf7bca210740p-5, -0x1.e7939a7019970p-7}},
+    {{0x1.88aa274b43f67p+0, -0x1.02b5ca1b2c46cp-1, 0x1.7aa2f198216f8p-3, -0x1.73a4e013ffe97p-4, 0x1.182a1164d0613p-5, -0x1.adc2fc15322cdp-8}},
+    {{0x1.887922eb0c3fep+0, -0x1.002aa41373486p-1, 0x1.5f6d7d2c91613p-3, -0x1.2a656fcb70361p-4, 0x1.69d682c1fdde6p-6, -0x1.aa6f1c69a5fd0p-9}},
+    {{0x1.267d4bf612409p+0, -0x1.36e66a695b88dp-1, 0x1.b23a75f8c9f8cp-3, -0x1.14ab2a56e3b4ap-3, 0x1.6db045c70243ep-4, -0x1.60ec374968867p-5}},
+    {{0x1.267b664c4648ap+0, -0x1.36a31ba63064ap-1, 0x1.aa764e224df42p-3, -0x1.ecddbfccc6256p-4, 0x1.e0e614bc6710bp-5, -0x1.07ff8ad8775cfp-6}},
+    {{0x1.2669e08420c49p+0, -0x1.354b6c3e2e00fp-1, 0x1.9517ae61898b4p-3, -0x1.968baf5849910p-4, 0x1.2fe75792349c0p-5, -0x1.d2b89dbe18dddp-8}},
+    {{0x1.2634d38077555p+0, -0x1.328ab5da09f17p-1, 0x1.77a578c2fe7f6p-3, -0x1.4746fa57b3105p-4, 0x1.890223f97e316p-6, -0x1.d0c8b8cd2c01dp-9}},
+    {{0x1.5956b84f073e7p-1, -0x1.92cc4e91aff80p-1, 0x1.ab59fa2fcf973p-3, -0x1.3b3bd220e7704p-3, 0x1.8937eee82009dp-4, -0x1.844145a20f41dp-5}},
+    {{0x1.5952a76a2d221p-1, -0x1.92841ea5f28fbp-1, 0x1.a30389d55d5b0p-3, -0x1.1abc4ae46ba6bp-3, 0x1.0270d6ec0079fp-4, -0x1.2c74d7ec6925fp-6}},
+    {{0x1.592ee34ead63fp-1, -0x1.912437023f679p-1, 0x1.8d0f1d2101bb3p-3, -0x1.dc7c0cd26dadcp-4, 0x1.4dcf9502fc6a9p-5, -0x1.27313253e40f7p-7}},
+    {{0x1.58da7fade0131p-1, -0x1.8eec6703bde81p-1, 0x1.7506af3887551p-3, -0x1.9af78b95237c4p-4, 0x1.e7e5ff36ae1c7p-6, -0x1.8801800bb2926p-8}},
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+static __shared__ __attribute__((aligned(16))) phf_normtab phf_lds_normal[PHF_NORMAL_TAB_N];
+#define PHF_T_NORMAL(j) phf_lds_normal[j]
+#define PHF_NORMAL_TABLE_TO_LDS()                                                                                   \
+  do {                                                                                                              \
+    for (int phf_i_ = threadIdx.x; phf_i_ < PHF_NORMAL_TAB_N * 6; phf_i_ += blockDim.x)                             \
+      (&phf_lds_normal[0].c[0])[phf_i_] = (&phf_t_normal[0].c[0])[phf_i_];                                          \
+    __syncthreads();                                                                                                \
+  } while (0)
+#else
+#define PHF_T_NORMAL(j) phf_t_normal[j]
+#define PHF_NORMAL_TABLE_TO_LDS() do { } while (0)
+#endif
+
+PHF_HD double phf_normal_u32(uint32_t v) {
+  const uint64_t ab = phf_bits((double)((v << 1) | 1u));             /* a = 2 w + 1 in [1, 2^32): exact */
+  const uint32_t hi = (uint32_t)(ab >> 32);
+  const int j = (int)(hi >> 18) - (0x3ff << 2);                       /* 4 E + the top two mantissa bits: 0..127 */
+  const double sft = phf_from_bits((ab & 0x000fffffffffffffull) | 0x3ff0000000000000ull) - 1.0;   /* m - 1 in [0, 1) */
+  const phf_normtab e = PHF_T_NORMAL(j);
+  double z = phf_fma(e.c[5], sft, e.c[4]);
+  z = phf_fma(z, sft, e.c[3]);
+  z = phf_fma(z, sft, e.c[2]);
+  z = phf_fma(z, sft, e.c[1]);
+  z = phf_fma(z, sft, e.c[0]);
+  return phf_from_bits(phf_bits(z) | ((uint64_t)(v & 0x80000000u) << 32));   /* z > 0: the sign bit comes from v */
+}
+
 /* 53-bit uniform on [0,1) from two words — numpy's random_sample() construction
  * (the reference's npr.rand(), python/PyHillFit.py:834).                                       */
 PHF_HD double phf_uniform53(uint32_t w1, uint32_t w2) {

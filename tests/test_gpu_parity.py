@@ -76,6 +76,8 @@ def test_device_math_bit_identical_to_host_build(gpu):
     s, c = co.sincos(w.astype(np.uint32))
     assert np.array_equal(debug_math(7, w.astype(np.float64), gpu), s)
     assert np.array_equal(debug_math(8, w.astype(np.float64), gpu), c)
+    w[:8] = [0, 1, 2 ** 31 - 1, 2 ** 31, 2 ** 31 + 1, 2 ** 32 - 1, 2 ** 30, 3 * 2 ** 29]
+    assert np.array_equal(debug_math(17, w.astype(np.float64), gpu), co.normal_u32(w.astype(np.uint32))), "phf_normal_u32"
 
 
 def test_device_philox_known_answers(gpu):

@@ -89,24 +89,32 @@ def test_sincos_octants():
     assert s[0] == 0 and c[0] == 1 and abs(c[4] - np.sqrt(0.5)) < 2e-16 and s[5] == 0 and c[5] == -1
 
 
+def test_normal_from_a_word_is_the_inverse_cdf():
+    """phf_normal_u32: the piecewise inverse CDF against scipy's, interval ends and a dense sample; exact symmetry"""
+    from scipy import stats
+    w = np.concatenate([np.arange(0, 2 ** 31, 2 ** 31 // 40000, dtype=np.uint64), (2 ** np.arange(0, 31, dtype=np.uint64)) - 1, 2 ** np.arange(0, 31, dtype=np.uint64),
+                        [0, 1, 2, 3, 2 ** 31 - 1]]).astype(np.uint32)
+    z = co.normal_u32(w)
+    want = stats.norm.ppf((w.astype(np.float64) + 0.5) / 2.0 ** 32)          # low half: negative quantiles ...
+    assert np.max(np.abs(-z - want)) < 1e-8                                   # ... the table holds |z|; word w (top bit clear) is +|z|
+    assert np.array_equal(co.normal_u32(w | np.uint32(0x80000000)), -z)        # the top bit is the sign: exactly symmetric
+    assert z.max() < 6.34 and z.min() >= 0 and np.all(np.diff(z[:40000]) <= 1e-8)   # |z| falls as w rises
+
+
 def test_draw_distributions():
-    """Box-Muller normals and the accept uniform drawn exactly as the sampler draws them."""
+    """The normals (inverse CDF of one word each) and the accept uniform drawn exactly as the sampler draws them."""
     z = np.array([co.draws(3, 0, 0, t)[0] for t in range(1, 20001)])
     u = np.exp(np.array([co.draws(3, 0, 0, t)[1] for t in range(1, 20001)]))       # draws() returns log u
     zz = z[:, :3].ravel()
     assert abs(zz.mean()) < 0.02 and abs(zz.std() - 1) < 0.02 and abs((zz ** 3).mean()) < 0.06 and abs((zz ** 4).mean() - 3) < 0.15
     assert np.abs(np.corrcoef(z[:, :3].T) - np.eye(3)).max() < 0.03
     assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.003 and u.min() >= 0 and u.max() < 1
-    z2 = np.array([co.draws(2, 5, 9, t)[0] for t in range(1, 20001)])       # d = 2: 32-bit fields, 53-bit accept uniform
+    z2 = np.array([co.draws(2, 5, 9, t)[0] for t in range(1, 20001)])       # d = 2: 53-bit accept uniform
     assert np.all(z2[:, 2:] == 0) and abs(z2[:, :2].std() - 1) < 0.02 and abs(z2[:, :2].mean()) < 0.02
-    assert np.abs(zz).max() < 5.9 and np.abs(z2).max() < 6.7                 # documented truncation of the normals
-    # d = 3: one Box-Muller pair B serves two iterations — cosine half = z2 of the even iteration, sine half = z2 of the odd one after
-    # it (phf_model.h) — so consecutive z2 must be uncorrelated (also in their squares: they share a radius only within a pair, whose
-    # two halves are independent normals), uncorrelated with z0, z1 of both iterations, and z2(t)^2 + z2(t+1)^2 of a pair is chi^2_2
+    assert np.abs(zz).max() < 6.34 and np.abs(z2).max() < 6.34               # documented truncation of the normals
+    from scipy import stats
+    assert stats.kstest(zz, "norm").pvalue > 1e-3 and stats.kstest(u, "uniform").pvalue > 1e-3
+    # consecutive iterations are independent blocks: no correlation along t, in values or squares
     zc = z[:, 2]
-    even, odd = zc[1::2][:-1], zc[2::2]                                       # t = 2, 4, ...  and  t = 3, 5, ...: halves of the same pair
-    assert len(even) == len(odd) and abs(np.corrcoef(even, odd)[0, 1]) < 0.03 and abs(np.corrcoef(even ** 2, odd ** 2)[0, 1]) < 0.03
-    r2 = even ** 2 + odd ** 2
-    assert abs(r2.mean() - 2) < 0.06 and abs(r2.var() - 4) < 0.35             # exponential with mean 2
-    assert abs(np.corrcoef(zc[:-1], zc[1:])[0, 1]) < 0.02 and abs(np.corrcoef(zc[1:], z[:-1, 0])[0, 1]) < 0.02
-    assert co.draws(3, 7, 3, 9)[0][2] != co.draws(3, 7, 3, 8)[0][2] and np.all(z[:, 3] == 0)
+    assert abs(np.corrcoef(zc[:-1], zc[1:])[0, 1]) < 0.02 and abs(np.corrcoef(zc[1:] ** 2, zc[:-1] ** 2)[0, 1]) < 0.03
+    assert abs(np.corrcoef(zc[1:], z[:-1, 0])[0, 1]) < 0.02 and np.all(z[:, 3] == 0)

@@ -148,7 +148,28 @@ def gen_sincos():
     show("cos: C(z)", to_double(cheb_fit(C, mp.mpf(0), a * a, 4)))
 
 
+def gen_normal():
+    """Standard normal from 32 random bits by a piecewise inverse CDF: w = the low 31 bits, p = (w + 1/2) / 2^32 in (0, 1/2),
+    |z| = -Phi^-1(p), sign = the top bit.  a = 2 w + 1 = 2^E m (E = 0..31, m in [1, 2)); interval 4 E + k, k = floor(4 (m - 1));
+    on it |z| = P(s), s = m - 1, degree 5, coefficients of s^0..s^5 (monomials about s = 0: the loss to cancellation is ~4
+    digits of 16).  128 x 6 doubles."""
+    def z_of(E, s):
+        p = mp.mpf(2) ** (E - 33) * (1 + s)
+        return -mp.sqrt(2) * mp.erfinv(2 * p - 1)
+    worst = mp.mpf(0)
+    print("/* |z| on interval 4 E + k: coefficients of s^0 .. s^5 */")
+    for E in range(32):
+        for k in range(4):
+            a, b = mp.mpf(k) / 4, mp.mpf(k + 1) / 4
+            cf = to_double(cheb_fit(lambda s: z_of(E, s), a, b, 5))
+            print("    {{%s}}," % ", ".join(float(v).hex() for v in cf))
+            for i in range(21):
+                s = a + (b - a) * i / 20
+                worst = max(worst, abs(horner(cf, s) - z_of(E, s)))
+    print("normal: max abs error", mp.nstr(worst, 3))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["exp", "log", "erfcx", "sincos"]
+    which = sys.argv[1:] or ["exp", "log", "erfcx", "sincos", "normal"]
     for w in which:
         globals()["gen_" + w]()
