@@ -50,7 +50,7 @@ typedef struct {
 /* ---------------------------------------------------------------- model library (shared source: phf_model.h) */
 static void target_parts(const phfo_problem* pb, const double* th, double* lik, double* prior, double* ll1) {
   phf_sl_log_target(pb->model, pb->ln_conc, pb->response, pb->weight, pb->n_other, pb->n_zero + pb->n_hundred,
-                    pb->n_other_points, pb->ss_within, pb->pi_bit, pb->temperature, th, phf_k_exp, phf_k_log, 0, 0, lik, prior, ll1);
+                    pb->n_other_points, pb->ss_within, pb->pi_bit, pb->temperature, th, phf_k_exp, phf_k_log, lik, prior, ll1);
 }
 
 double phfo_log_prior(const phfo_problem* pb, const double* th) { double l, p, a; target_parts(pb, th, &l, &p, &a); return p; }
@@ -275,6 +275,8 @@ VEC1(phfo_vec_sqrt, phf_sqrt)
 VEC1(phfo_vec_exp_fast, phf_exp_fast)
 VEC1(phfo_vec_log_fast, phf_log_fast)
 VEC1(phfo_vec_log_ndtr_nonpos, phf_log_ndtr_nonpos)
+static inline double log_ndtr_tab1(double x) { return phf_log_ndtr_tab(x, -x * PHF_INV_SQRT2); }
+VEC1(phfo_vec_log_ndtr_tab, log_ndtr_tab1)
 
 void phfo_vec_log_ndtr_nonpos_x2(int64_t n, const double* x, double* out) {
   for (int64_t i = 0; i + 1 < n; i += 2) phf_log_ndtr_nonpos_x2(x[i], x[i + 1], &out[i], &out[i + 1]);

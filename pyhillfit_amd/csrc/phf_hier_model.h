@@ -69,11 +69,6 @@ PHF_HD void phf_batch_recip(double* v, int n) {
  * tests its own).  On the Crumb posteriors the upper tails (100 - pred >= 8.5 sigma) are negligible on all 64 chains for two
  * thirds of the point pairs (tools/diag_hier_tails.py), the lower ones almost never: those are computed unconditionally.        */
 #define PHF_TAIL_CUT 6.0
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PHF_ANY_LANE(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
-#else
-#define PHF_ANY_LANE(c) (c)
-#endif
 
 /* The two points' lower tails Phi(a) (always needed) and upper arguments b — first part of phf_trunc_terms_x2_core. */
 PHF_HD void phf_trunc_lower_x2(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab ke, int kv,

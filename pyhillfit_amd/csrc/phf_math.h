@@ -110,6 +110,13 @@ typedef const double __attribute__((address_space(4))) * phf_ktab4;
 #define PHF_FMA_K(p, t, c) __builtin_fma((p), (t), (c))
 #define PHF_FMA_KV(p, t, c) __builtin_fma((p), (t), (c))
 #endif
+/* a wave-uniform "does any lane ...": rare, expensive alternatives run under a scalar branch (and every lane then selects by its
+ * OWN condition, so a chain's value never depends on the other chains of its wavefront); on the host: the one value itself */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PHF_ANY_LANE(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#else
+#define PHF_ANY_LANE(c) (c)
+#endif
 #define PHF_KTABLE static const double   /* internal linkage: addressed pc-relatively (a __constant__ symbol goes through the GOT: one more dependent load per fetch) */
 
 #define PHF_INF (__builtin_inf())
@@ -568,6 +575,187 @@ PHF_HD double phf_log_ndtr_nonpos_kx(double x, phf_ktab ke, int ke_in_vgpr, phf_
 
 PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab ke, phf_ktab kl) { return phf_log_ndtr_nonpos_kx(x, ke, 0, kl); }
 
+/* log Phi(x) for x <= 0 through a table — the single-level censored likelihood's form: log Phi(x) = -x^2/2 + g(y), y = -x/sqrt2,
+ * g(y) = log(erfcx(y)/2), smooth and slowly varying, so a degree-9 polynomial per interval does it: v = y + 1 = 2^E m, interval
+ * 8 E + floor(8 (m - 1)), E = 0..16, i.e. 0 <= y < 131071, g = P(m - 1) to 9.4e-16 absolute (tools/gen_math_coeffs.py logphi):
+ * 12 fp64 operations and five 16-byte LDS reads where erfcx + log took ~50, and no branch.  The range holds every argument
+ * the likelihood can produce while it is not -inf anyway: |pred - y| <= 100 and sigma above its floor of 1e-3 give y <= 70 711.
+ * (The index is clamped, so any other argument is safe to evaluate; its value is meaningless.)  The table (10.6 KB) goes to
+ * LDS with PHF_LOGPHI_TABLE_TO_LDS(). */
+#define PHF_LOGPHI_TAB_N 136
+#define PHF_LOGPHI_Y_MAX 131071.0
+typedef struct { double c[10]; } phf_logphitab;
+static const phf_logphitab phf_t_logphi[PHF_LOGPHI_TAB_N] = {
+    {{-0x1.62e42fefa39efp-1, -0x1.20dd750429b6dp+0, 0x1.7419f246c6d8cp-2, -0x1.a4f4e2a190066p-4, 0x1.3966857717addp-6, 0x1.b6b8432d6421cp-13, -0x1.bcaa6f2438639p-10, 0x1.35bf16dc0c7f7p-11, -0x1.ff599d624e3e7p-16, -0x1.88e331ca07a8ep-15}},
+    {{-0x1.62e42fefa5645p-1, -0x1.20dd7503f75c2p+0, 0x1.7419f232c1a25p-2, -0x1.a4f4ddf04ee85p-4, 0x1.3965cd982361fp-6, 0x1.b91eb89e87a43p-13, -0x1.be0c36d42cde1p-10, 0x1.3e5072c5af549p-11, -0x1.035c87f6930d4p-14, -0x1.308cf66baa915p-16}},
+    {{-0x1.62e42ff087942p-1, -0x1.20dd74f56e9fap+0, 0x1.7419eed90a817p-2, -0x1.a4f46962ddcbap-4, 0x1.395b7f78acabbp-6, 0x1.ccd332a4f6608p-13, -0x1.c46c54b5c72e8p-10, 0x1.53e16a9767452p-11, -0x1.b088988fa343fp-14, 0x1.3db8124b73b12p-21}},
+    {{-0x1.62e42ffe7b78ap-1, -0x1.20dd74542078ap+0, 0x1.7419d4c9a8926p-2, -0x1.a4f1f084775cbp-4, 0x1.3934a25d79307p-6, 0x1.000e0f732f135p-12, -0x1.cfc9983a87eecp-10, 0x1.6dfb46dad24aap-11, -0x1.1ebf3f534f905p-13, 0x1.68cd3bd227726p-17}},
+    {{-0x1.62e4303cd0ae1p-1, -0x1.20dd7227890d5p+0, 0x1.74198f7a7af5fp-2, -0x1.a4ece24f01dfdp-4, 0x1.38f7b14aa23f8p-6, 0x1.1ecb289b943b0p-12, -0x1.da2ad70f2ea41p-10, 0x1.80153f472f079p-11, -0x1.43ba081ee8a61p-13, 0x1.efa5113553381p-17}},
+    {{-0x1.62e4302aac17ap-1, -0x1.20dd72831fa7ep+0, 0x1.741994c5b0119p-2, -0x1.a4ecf7fb6f253p-4, 0x1.38f65b65aa28fp-6, 0x1.20307d8fa6ad7p-12, -0x1.dac55c202a788p-10, 0x1.813b4efbe6f87p-11, -0x1.461601cff1039p-13, 0x1.f7de2b2edf5b0p-17}},
+    {{-0x1.62e42b2cf92ffp-1, -0x1.20dd8fc8f2095p+0, 0x1.741bf818ca4d5p-2, -0x1.a50a1a6178d73p-4, 0x1.39db36b5e53e3p-6, 0x1.aa54aa246936dp-13, -0x1.ca590b0ae5886p-10, 0x1.6eb62e0b4a0b2p-11, -0x1.2dadc3f2f856ep-13, 0x1.be959fccd8842p-17}},
+    {{-0x1.62e410cb964a6p-1, -0x1.20de15ccdcb9bp+0, 0x1.74256fd719a43p-2, -0x1.a56e1ddae6590p-4, 0x1.3c834acd93edap-6, 0x1.438c7bcb87f50p-16, -0x1.a5ce1d389c867p-10, 0x1.4b119e50eecffp-11, -0x1.05102f0c68050p-13, 0x1.6c30bc6636b9cp-17}},
+    {{-0x1.8af1d71f7bf99p+0, -0x1.4726c001b090cp+0, 0x1.4150fb975f3f8p-1, -0x1.5477f09f1b56cp-2, 0x1.48c9d50ae8ec5p-3, -0x1.033fa53e03d02p-4, 0x1.f1d6cb39f635cp-7, 0x1.b2b5f5a9c1652p-9, -0x1.b2978cb5dd1eap-8, 0x1.e2d7494e23338p-9}},
+    {{-0x1.8af1d71f45a4fp+0, -0x1.4726c00dc7e87p+0, 0x1.4150fe002c137p-1, -0x1.5478391edb593p-2, 0x1.48cf66e565d6bp-3, -0x1.038a77035b933p-4, 0x1.fcad5efd0aef5p-7, 0x1.2b3de27d6d2a8p-9, -0x1.2f5fbe13cebd5p-8, 0x1.e08f1ba41e943p-10}},
+    {{-0x1.8af1d7072c11cp+0, -0x1.4726c328ca635p+0, 0x1.415159ea9e5fbp-1, -0x1.547e7d7256f79p-2, 0x1.49169ac039d5fp-3, -0x1.05ad6ce5e0027p-4, 0x1.149046d6d3645p-6, -0x1.7e09cb03dcb82p-16, -0x1.2dd2ab32287b6p-9, 0x1.947875cef17d3p-11}},
+    {{-0x1.8af1d5a031bacp+0, -0x1.4726e39848600p+0, 0x1.4153f8f9e1a8fp-1, -0x1.549e562c9c087p-2, 0x1.4a1114f52a8eep-3, -0x1.0ad873d847c63p-4, 0x1.393cc67ac9d65p-6, -0x1.542d98de19d68p-9, -0x1.27ff01b1f8aecp-11, 0x1.016856f0e2620p-12}},
+    {{-0x1.8af1ce3c54ea2p+0, -0x1.472766996d692p+0, 0x1.415c1196b112ep-1, -0x1.54e95d8073a9ep-2, 0x1.4bd1f6710b1dep-3, -0x1.11de8c609751cp-4, 0x1.5eea1c26f4b16p-6, -0x1.2c948c019841dp-8, 0x1.d319b65d03660p-12, 0x1.19e4d0805e98ap-16}},
+    {{-0x1.8af1bb8a0c788p+0, -0x1.472873263fd0cp+0, 0x1.41697fb2a222fp-1, -0x1.554df024b137ap-2, 0x1.4db776b068cf8p-3, -0x1.17fd4db435c22p-4, 0x1.7951f538044b7p-6, -0x1.7604ae18f0ccap-8, 0x1.d877bd0bf88d3p-11, -0x1.13e2a71f66badp-14}},
+    {{-0x1.8af1a98cf0659p+0, -0x1.47294f4116e70p+0, 0x1.4172dd34b4d7ap-1, -0x1.55898868019cep-2, 0x1.4eab9a57c428ep-3, -0x1.1a99035bac12fp-4, 0x1.82d82c2273807p-6, -0x1.8c67ed75bccc0p-8, 0x1.0af8954a8f90cp-10, -0x1.5f0095d8aba0ep-14}},
+    {{-0x1.8af1d65024631p+0, -0x1.47278f5dc0344p+0, 0x1.41634b14c4574p-1, -0x1.5538a47d66dcbp-2, 0x1.4d9d46396d843p-3, -0x1.183e509ebe33cp-4, 0x1.7bd7439c115e4p-6, -0x1.7f00b256cb359p-8, 0x1.f7fe58c59ecfbp-11, -0x1.413cfdfec11e5p-14}},
+    {{-0x1.34ede72930114p+1, -0x1.370b35013b9b7p+0, 0x1.5d06cc9bbcb42p-1, -0x1.e5bee8cd2b547p-2, 0x1.62c31d10063c7p-2, -0x1.01a01a4fc16eep-2, 0x1.6957b207fbe27p-3, -0x1.dc4c758cdb037p-4, 0x1.16c9a96e6be47p-4, -0x1.cbdb7ef9940b3p-6}},
+    {{-0x1.34ede729e8e6ep+1, -0x1.370b34aefd973p+0, 0x1.5d06bc3a28b96p-1, -0x1.e5bcfc2ad3d00p-2, 0x1.62b0347e60d67p-2, -0x1.01213e09378edp-2, 0x1.64c16b11c3e03p-3, -0x1.bfb179c736365p-4, 0x1.bf0df10c3f612p-5, -0x1.003b81957a387p-6}},
+    {{-0x1.34ede77e6e38bp+1, -0x1.370b1eec87d72p+0, 0x1.5d0438f370eb1p-1, -0x1.e5912ece59e59p-2, 0x1.61b7b94d9b6ccp-2, -0x1.fad09d8cb5078p-3, 0x1.516d0e917cc8cp-3, -0x1.7e16b912b19bbp-4, 0x1.3ae500cb75b6cp-5, -0x1.0f99610fba29ep-7}},
+    {{-0x1.34edecde3d9b1p+1, -0x1.370a26fe07469p+0, 0x1.5cf03e860eac9p-1, -0x1.e49f35f923ebap-2, 0x1.5e032db23d983p-2, -0x1.e74eb96ab0c30p-3, 0x1.2eeefa5acfed1p-3, -0x1.2f118731e3fd6p-4, 0x1.a0efbaf25055fp-6, -0x1.1e641be48a96ep-8}},
+    {{-0x1.34ee0f59cbdbdp+1, -0x1.3705668aa5b34p+0, 0x1.5ca573aed3473p-1, -0x1.e1edb7608de7fp-2, 0x1.55ff8f8b8e561p-2, -0x1.c7606e64f5c81p-3, 0x1.045797e8a8b39p-3, -0x1.cb69b3018cbf4p-5, 0x1.0cde12e63b71ep-6, -0x1.31fb1d6e4a4b4p-9}},
+    {{-0x1.34ee916e33e37p+1, -0x1.36f6eea16469fp+0, 0x1.5bedde84d9ed0p-1, -0x1.dc9b3f5f096ebp-2, 0x1.494480220b3aep-2, -0x1.9ea950292c13fp-3, 0x1.b1a1c0d2857d6p-4, -0x1.536d393f84226p-5, 0x1.58410a16f8cf0p-7, -0x1.4ddde7553e49ap-10}},
+    {{-0x1.34eff099b2641p+1, -0x1.36d63bbcd4f1ep+0, 0x1.5a92cc7d34296p-1, -0x1.d4323e82408c8p-2, 0x1.38774ebb2bc13p-2, -0x1.71d227ea60339p-3, 0x1.61b237a2c5389p-4, -0x1.ef4912a413bd8p-6, 0x1.ba20846976e9ap-8, -0x1.75399b563b9d3p-11}},
+    {{-0x1.34f2e58dcca11p+1, -0x1.3699aa53620f2p+0, 0x1.586a9e6fc43b5p-1, -0x1.c8b5946abc3c2p-2, 0x1.24c664686be23p-2, -0x1.44c032e428b15p-3, 0x1.1cd34dec068e2p-4, -0x1.67c8d9c5e9fc5p-6, 0x1.1e64dba39da90p-8, -0x1.abcdf22f37757p-12}},
+    {{-0x1.9c561f90047a9p+1, -0x1.1ee25c5c3261ep+0, 0x1.3b7909241c425p-1, -0x1.c61be51c78652p-2, 0x1.69164984575a3p-2, -0x1.2cc8642b84059p-2, 0x1.00215fcc5e2b3p-2, -0x1.b4b7d1baf2898p-3, 0x1.5cb933c19bd71p-3, -0x1.8692f96ce3cbep-4}},
+    {{-0x1.9c561f92b358dp+1, -0x1.1ee25b280c5c3p+0, 0x1.3b78cb1ec2916p-1, -0x1.c61482991147ap-2, 0x1.68cc6b3693086p-2, -0x1.2accd1bd9a4fdp-2, 0x1.ed50a66ac17a8p-3, -0x1.772c92df3c782p-3, 0x1.bfa26e98eafabp-4, -0x1.27597d6304776p-5}},
+    {{-0x1.9c56206cc81c1p+1, -0x1.1ee2228b581f0p+0, 0x1.3b72318d8ff93p-1, -0x1.c5a0388c32996p-2, 0x1.6630c297a570ap-2, -0x1.20aa43d88a14cp-2, 0x1.b7ee6455b76f9p-3, -0x1.1b35e72610f6dp-3, 0x1.037d825fb4cfap-4, -0x1.e4e6a403d9f24p-7}},
+    {{-0x1.9c562b23de7fep+1, -0x1.1ee031939b626p+0, 0x1.3b49eb6eccff6p-1, -0x1.c3b57c850ab26p-2, 0x1.5ea0dd9825073p-2, -0x1.0ca0b526c9f80p-2, 0x1.7097e1652efedp-3, -0x1.91de2b7fcb766p-4, 0x1.27d3e505cca35p-5, -0x1.aba4e864b6681p-8}},
+    {{-0x1.9c5663f814304p+1, -0x1.1ed8565586617p+0, 0x1.3acdd8af4f157p-1, -0x1.bf39bd1b66f3cp-2, 0x1.513da3beec5a8p-2, -0x1.e3b930517de38p-3, 0x1.28edde51ed2a3p-3, -0x1.15fa5d888e70ep-4, 0x1.54b1204c37ef7p-6, -0x1.917258bd4b90bp-9}},
+    {{-0x1.9c571dd58ca27p+1, -0x1.1ec39f5eddb3bp+0, 0x1.39c6782675962p-1, -0x1.b792fffd8b7b7p-2, 0x1.3ee665823c8bfp-2, -0x1.a8f0e189210ecp-3, 0x1.d3e86108869c5p-4, -0x1.7dfbbed43663bp-5, 0x1.903faace0be3dp-7, -0x1.8df3e5da2738cp-10}},
+    {{-0x1.9c58e0128273ep+1, -0x1.1e99a51e9ae33p+0, 0x1.38085471e487bp-1, -0x1.acbfc675a4edfp-2, 0x1.293ec317b84cbp-2, -0x1.6f12078b35a68p-3, 0x1.6c9aed0e14227p-4, -0x1.0735b6b3861f8p-5, 0x1.e13d5d6c7a4b4p-8, -0x1.9dc6ed2148913p-11}},
+    {{-0x1.9c5c5cfb27e81p+1, -0x1.1e52231552b56p+0, 0x1.357bd9308f421p-1, -0x1.9f29e9c91ad6ap-2, 0x1.11efbde9f870ap-2, -0x1.39ac50dcb9977p-3, 0x1.1af01a4a93434p-4, -0x1.6d99bc5fce16cp-6, 0x1.283eec126647ap-8, -0x1.c0b50f39ae25ep-12}},
+    {{-0x1.fce61b9c38f4dp+1, -0x1.0fddc62427210p+0, 0x1.1f75329552839p-1, -0x1.9380d57467359p-2, 0x1.3d393b153296ep-2, -0x1.08dd26f91f501p-2, 0x1.ca5f46826f02cp-3, -0x1.92362160c47d7p-3, 0x1.4d2485258a67bp-3, -0x1.81d81dabce0cdp-4}},
+    {{-0x1.fce61b9edf659p+1, -0x1.0fddc4f375c4ap+0, 0x1.1f74f52cb913ep-1, -0x1.9379824f4944ep-2, 0x1.3cefcad4e9fe7p-2, -0x1.06e2f7886d3bdp-2, 0x1.b766a1c67860cp-3, -0x1.5444217276ca9p-3, 0x1.9d53aa98ff8cbp-4, -0x1.14a678e08e9edp-5}},
+    {{-0x1.fce61c6cbca3ep+1, -0x1.0fdd8f73993e4p+0, 0x1.1f6eb680d9ea3p-1, -0x1.930b5207b1652p-2, 0x1.3a762a6ed9aa2p-2, -0x1.fa80e03810210p-3, 0x1.848ee21c1a620p-3, -0x1.f90644fbaf1d8p-4, 0x1.d2e3d7dc322cap-5, -0x1.b76764ad6f4fap-7}},
+    {{-0x1.fce62638f82bdp+1, -0x1.0fdbc8bb45763p+0, 0x1.1f49d6330e4d7p-1, -0x1.9149a6fa4c27cp-2, 0x1.3386e46ce373ep-2, -0x1.d5b9616489051p-3, 0x1.43084d17786a6p-3, -0x1.61c083d0ff1fbp-4, 0x1.0593811c96bf7p-5, -0x1.7b9424ff607c2p-8}},
+    {{-0x1.fce6590d05bdbp+1, -0x1.0fd4c134912e7p+0, 0x1.1edac8570b573p-1, -0x1.8d45f12a5658bp-2, 0x1.2788e47445c97p-2, -0x1.a5c0a572bde87p-3, 0x1.02c94657efe63p-3, -0x1.e54812afa9680p-5, 0x1.29fbb5ab0857bp-6, -0x1.5fcc753214f45p-9}},
+    {{-0x1.fce6fcd70c83fp+1, -0x1.0fc27f2dd1c26p+0, 0x1.1df29884a16e7p-1, -0x1.8686d05d87468p-2, 0x1.175bfb873c51bp-2, -0x1.71e637fbeb28cp-3, 0x1.96720e3b41170p-4, -0x1.4bc09d2ccf98fp-5, 0x1.5bd0d16197b43p-7, -0x1.5a17afde03a72p-10}},
+    {{-0x1.fce885c8ab180p+1, -0x1.0f9ddb7022347p+0, 0x1.1c6d2586230cap-1, -0x1.7d1376bde6dd9p-2, 0x1.0473b8c9382f3p-2, -0x1.3f5da7ae71af8p-3, 0x1.3c3aef92b5b27p-4, -0x1.c807886769148p-6, 0x1.a0c24ba3271eap-8, -0x1.665bd1eeee105p-11}},
+    {{-0x1.fceb8c66db335p+1, -0x1.0f5fd1b0e2d0cp+0, 0x1.1a370b03b3cb3p-1, -0x1.7149d9082e738p-2, 0x1.e0742185de7ccp-3, -0x1.11079e0e63a0dp-3, 0x1.eab79e1e8222dp-5, -0x1.3c761e1a37915p-6, 0x1.0033a4782b8b8p-8, -0x1.83e55878cbd42p-12}},
+    {{-0x1.2ccd1c4217f06p+2, -0x1.07fbd9f912100p+0, 0x1.0fef440ececb3p-1, -0x1.751d18eccdb71p-2, 0x1.1faae85a6c99dp-2, -0x1.d8a4f64b005b4p-3, 0x1.93ba0f7a6ea53p-3, -0x1.5ee54483d0e07p-3, 0x1.20e0ed865197bp-3, -0x1.4d90f9e50b7cdp-4}},
+    {{-0x1.2ccd1c433cc5cp+2, -0x1.07fbd8f20c571p+0, 0x1.0fef0f0c7f1b5p-1, -0x1.7516c64eb173fp-2, 0x1.1f6b848924757p-2, -0x1.d53b249100a05p-3, 0x1.835a3c36bb8c0p-3, -0x1.296e7f9bf51b4p-3, 0x1.67706155216f2p-4, -0x1.dfc8f289b2723p-6}},
+    {{-0x1.2ccd1c9c4daddp+2, -0x1.07fbaaa81f502p+0, 0x1.0fe9a7f8d1d68p-1, -0x1.74b77497f2f45p-2, 0x1.1d4774a770135p-2, -0x1.c490bdb4973f7p-3, 0x1.5762d33328dcep-3, -0x1.bb1c899986b50p-4, 0x1.97d97de8b288cp-5, -0x1.7ed331b896189p-7}},
+    {{-0x1.2ccd20dd8d362p+2, -0x1.07fa1fc11cad2p+0, 0x1.0fc9a263a36d1p-1, -0x1.733106561f87ap-2, 0x1.174239ffbf863p-2, -0x1.a4a381f440887p-3, 0x1.1e833185f2557p-3, -0x1.37d4426b584f6p-4, 0x1.cb608f244ed78p-6, -0x1.4c7ebaba492e5p-8}},
+    {{-0x1.2ccd370a20d2bp+2, -0x1.07f3fdcb8cb20p+0, 0x1.0f68c1bb01a67p-1, -0x1.6fb09837f8ee7p-2, 0x1.0ccca8626c863p-2, -0x1.7acdad780004fp-3, 0x1.ccfaf08bc57f3p-4, -0x1.ade6b12acbb8dp-5, 0x1.07121a4360315p-6, -0x1.35e2082e985f2p-9}},
+    {{-0x1.2ccd7ed8bb148p+2, -0x1.07e3fbd4c3fc4p+0, 0x1.0e9d33fb3867bp-1, -0x1.69c6947f50c7ep-2, 0x1.fd3e03448b372p-3, -0x1.4d5b2909f68a6p-3, 0x1.6b970c900fb33p-4, -0x1.275c8cd33e765p-5, 0x1.34b3a883162f0p-7, -0x1.328824b43c3d0p-10}},
+    {{-0x1.2cce2bfba9931p+2, -0x1.07c3b2b447e52p+0, 0x1.0d460e6e775ddp-1, -0x1.617304e40ad2cp-2, 0x1.dbed9c54346dfp-3, -0x1.20d7062266397p-3, 0x1.1c1f682d86b8fp-4, -0x1.97fa71deeefe9p-6, 0x1.73ca0301bf51cp-8, -0x1.3f11ad0719289p-11}},
+    {{-0x1.2ccf82f9b51ecp+2, -0x1.078cc2f8edfebp+0, 0x1.0b50c8d104275p-1, -0x1.5703243a50986p-2, 0x1.b81d44f51ecf3p-3, -0x1.efa28ad431cc9p-4, 0x1.bac38e43154f9p-5, -0x1.1c6df5d3eabb2p-6, 0x1.cb56326b3c13ep-9, -0x1.5b1753c561467p-12}},
+    {{-0x1.5a2955556c61ep+2, -0x1.03ff7d8ee4366p+0, 0x1.07fdf3d9d0e7ap-1, -0x1.654e79fb5984ap-2, 0x1.0ff599b1d1605p-2, -0x1.b97842a7129fdp-3, 0x1.74decda57c75fp-3, -0x1.40c33460c0746p-3, 0x1.05d0099be78c3p-3, -0x1.2c84a2b7ee0d0p-4}},
+    {{-0x1.5a29555673f2fp+2, -0x1.03ff7ca2301d6p+0, 0x1.07fdc42772f64p-1, -0x1.6548c9e374485p-2, 0x1.0fbc976dc319dp-2, -0x1.b666b20d7b67cp-3, 0x1.66282b2250db2p-3, -0x1.10c01ff1c8410p-3, 0x1.47b492c7bf9f7p-4, -0x1.b3cea865e58d0p-6}},
+    {{-0x1.5a2955a7290bap+2, -0x1.03ff52b24b092p+0, 0x1.07f8df5c139a1p-1, -0x1.64f277d75374dp-2, 0x1.0dcc655f7def0p-2, -0x1.a7511db2874edp-3, 0x1.3e5fbab0fe622p-3, -0x1.983afd287ecc3p-4, 0x1.762649fd6a5fbp-5, -0x1.5e39cd4eecdc2p-7}},
+    {{-0x1.5a29598862b58p+2, -0x1.03fdeaa8cdc92p+0, 0x1.07dbaeafe0a4cp-1, -0x1.638e9f024b844p-2, 0x1.084fecc2186f3p-2, -0x1.8a3a6c20f8e1dp-3, 0x1.0a90b59025e5ep-3, -0x1.20a9376a20f05p-4, 0x1.a7d381e3e6979p-6, -0x1.321541ab28b85p-8}},
+    {{-0x1.5a296dde77569p+2, -0x1.03f84afac32c9p+0, 0x1.0782da9556d70p-1, -0x1.6058c3b33504cp-2, 0x1.fd72c6447bc05p-3, -0x1.63e1d6df1602fp-3, 0x1.ae716c9f9a030p-4, -0x1.8fc470072941fp-5, 0x1.e7e9d24364c97p-7, -0x1.1ed49cbbb870cp-9}},
+    {{-0x1.5a29b011c87dep+2, -0x1.03e98947d6bc8p+0, 0x1.06c7393e742cbp-1, -0x1.5ae54d833582fp-2, 0x1.e3507612456cdp-3, -0x1.3a00259a10409p-3, 0x1.54b3969339ba7p-4, -0x1.13cdeca65361cp-5, 0x1.1f959421fb88dp-7, -0x1.1d19841972fb0p-10}},
+    {{-0x1.5a2a5070ee531p+2, -0x1.03cba1faa3376p+0, 0x1.05896a31dad69p-1, -0x1.532f4220482c6p-2, 0x1.c476c6fbd6086p-3, -0x1.10c77907ac57fp-3, 0x1.0b1ed1fce7d52p-4, -0x1.7e6923ebe0c1ap-6, 0x1.5bc67fed79d86p-8, -0x1.2a08312f1549cp-11}},
+    {{-0x1.5a2b8f7ef796cp+2, -0x1.039888601d06bp+0, 0x1.03b72bc11c5c3p-1, -0x1.497a34a877e4cp-2, 0x1.a327eba52c074p-3, -0x1.d541f02d295b3p-4, 0x1.a18cd51e2469bp-5, -0x1.0b85da83f8d14p-6, 0x1.af3f618c1fec5p-9, -0x1.45720f8eeee00p-12}},
+    {{-0x1.8705d1d942782p+2, -0x1.01ffefd8735f4p+0, 0x1.03ffbf3a51c6ap-1, -0x1.5d547c99c36d7p-2, 0x1.07fea99fdc5d9p-2, -0x1.a9920338a98bfp-3, 0x1.650600f23c5e7p-3, -0x1.312a5caa6c79fp-3, 0x1.ef6344bb8ea87p-4, -0x1.1b2c251acaa19p-4}},
+    {{-0x1.8705d1da3aae7p+2, -0x1.01ffeef98ed1dp+0, 0x1.03ff9251c1305p-1, -0x1.5d4f21d6f4f5dp-2, 0x1.07c901681e264p-2, -0x1.a6aed4a7edaddp-3, 0x1.572efedee6042p-3, -0x1.040602811f4dfp-3, 0x1.3745774a159f6p-4, -0x1.9cf691bcd7c2bp-6}},
+    {{-0x1.8705d22696a74p+2, -0x1.01ffc74d4e7b6p+0, 0x1.03faf1544e237p-1, -0x1.5cfd7f0d2b777p-2, 0x1.05f3d1c1a5554p-2, -0x1.986c21f077a6fp-3, 0x1.3194a647502a9p-3, -0x1.865354d637f82p-4, 0x1.64ce1a52ac20dp-5, -0x1.4d6a98ae3a9e8p-7}},
+    {{-0x1.8705d5d631f57p+2, -0x1.01fe7148a57f9p+0, 0x1.03df375bdaae0p-1, -0x1.5bab87436e294p-2, 0x1.00be0fbf91264p-2, -0x1.7ccd2d403d3b6p-3, 0x1.00644ea430369p-3, -0x1.14d0d4b901ad9p-4, 0x1.959e065507222p-6, -0x1.24899bea3c760p-8}},
+    {{-0x1.8705e93a6ef8ap+2, -0x1.01f91493683c7p+0, 0x1.038a869d173e5p-1, -0x1.589c03c312bcbp-2, 0x1.ef346b95023f4p-3, -0x1.583ff66654cbdp-3, 0x1.9ee8a72f7c28ep-4, -0x1.8069346dabf20p-5, 0x1.d468212b062a4p-7, -0x1.130e6eb7b9faap-9}},
+    {{-0x1.8706288f106b4p+2, -0x1.01eaf6d2891b1p+0, 0x1.02d70c23e8765p-1, -0x1.53653f9a7e513p-2, 0x1.d6356e3683824p-3, -0x1.3031aae6c27a1p-3, 0x1.491578c141d88p-4, -0x1.09dd4448fb703p-5, 0x1.14d72e161d7eap-7, -0x1.1230179cd8b0dp-10}},
+    {{-0x1.8706c26b11624p+2, -0x1.01ce46a6ce90bp+0, 0x1.01a62a9e09757p-1, -0x1.4bff933219c9bp-2, 0x1.b89d93adb05b3p-3, -0x1.08a76587f2959p-3, 0x1.0281aa7dba503p-4, -0x1.71719a27caddcp-6, 0x1.4f9648aa23c58p-8, -0x1.1f5927d6d929dp-11}},
+    {{-0x1.8707f54b1b36ap+2, -0x1.019d20c79b7bdp+0, 0x1.ffcb7e10f3e75p-2, -0x1.42a996cfeaea9p-2, 0x1.989526db88f4bp-3, -0x1.c7ee19485bff6p-4, 0x1.94cbc65d1cfd8p-5, -0x1.02f6ad423be29p-6, 0x1.a1049f7b58418p-9, -0x1.3a799aa3a6463p-12}},
+    {{-0x1.b3a256aa39d39p+2, -0x1.00fffdfd835e1p+0, 0x1.01fff7f331bd0p-1, -0x1.59553a28e7147p-2, 0x1.03ffc73d2fd65p-2, -0x1.a19546b66b750p-3, 0x1.5d0cc0c353b09p-3, -0x1.294db3e42c29ep-3, 0x1.e121166050c02p-4, -0x1.1266d8dbf7362p-4}},
+    {{-0x1.b3a256ab2a468p+2, -0x1.00fffd259a73dp+0, 0x1.01ffcc738f94ep-1, -0x1.59500a8cc3e56p-2, 0x1.03cbd0f6171efp-2, -0x1.9ec98df0234dfp-3, 0x1.4fa6df2cdaa87p-3, -0x1.fb3a35d376275p-4, 0x1.2efc8c4f54e9ep-4, -0x1.91705de0e8663p-6}},
+    {{-0x1.b3a256f55485fp+2, -0x1.00ffd69de0536p+0, 0x1.01fb4dae7dca2p-1, -0x1.5900c50debd74p-2, 0x1.0204436843689p-2, -0x1.90f14eea87f5ep-3, 0x1.2b264562e916dp-3, -0x1.7d513c07e1cdep-4, 0x1.5c12d53813bb7p-5, -0x1.44f35b6acc81cp-7}},
+    {{-0x1.b3a25a8bef63ap+2, -0x1.00fe89ad98f38p+0, 0x1.01e0508740e82p-1, -0x1.57b7cfc8c365cp-2, 0x1.f9e4487770321p-3, -0x1.760fb6b23dfbdp-3, 0x1.f68fe3e28823bp-4, -0x1.0edc986b7f577p-4, 0x1.8c75f29e339e6p-6, -0x1.1db9587773842p-8}},
+    {{-0x1.b3a26d7676005p+2, -0x1.00f94ead0be1ap+0, 0x1.018db4f3bcd97p-1, -0x1.54bb98a2177e0p-2, 0x1.e81007000a931p-3, -0x1.5269b685f84a1p-3, 0x1.971c0faaa6f12p-4, -0x1.78b2a7dbca186p-5, 0x1.ca9b2d775f192p-7, -0x1.0d23b36a4c6a2p-9}},
+    {{-0x1.b3a2ab59b2d45p+2, -0x1.00eb835a98e49p+0, 0x1.00de53c390cecp-1, -0x1.4fa3592cca60ep-2, 0x1.cfa38545ad197p-3, -0x1.2b46701481810p-3, 0x1.43410c6072b56p-4, -0x1.04dff1c758e33p-5, 0x1.0f7243a58d30bp-7, -0x1.0cb55598f95a5p-10}},
+    {{-0x1.b3a341f01f78fp+2, -0x1.00cf6f7f706b8p+0, 0x1.ff67e1fb5e48dp-2, -0x1.48660e02644fcp-2, 0x1.b2ad5ca4282d9p-3, -0x1.049469d26c0e9p-3, 0x1.fc5f30599b846p-5, -0x1.6af029073151dp-6, 0x1.49788eb8a13d1p-8, -0x1.19fc864d8ea9ap-11}},
+    {{-0x1.b3a46eb2a4b5bp+2, -0x1.009f4489cd922p+0, 0x1.fbf8f0cf7402bp-2, -0x1.3f3fcd4bb83f2p-2, 0x1.9348d6eb55292p-3, -0x1.c13fdda93a37fp-4, 0x1.8e66acc039fe3p-5, -0x1.fd579a43c3c24p-7, 0x1.99e182187a3c1p-9, -0x1.34f8cba87af56p-12}},
+    {{-0x1.e01edc82b39e2p+2, -0x1.007fffbfd7ecep+0, 0x1.00fffefed6c9ep-1, -0x1.575551ae29af6p-2, 0x1.01ffead9900c0p-2, -0x1.9d95bb81240a6p-3, 0x1.590e8f47769e1p-3, -0x1.255d656e9f9f5p-3, 0x1.d9fba62dc1f02p-4, -0x1.0e01285ac39cdp-4}},
+    {{-0x1.e01edc83a02cbp+2, -0x1.007ffeeb6f3d9p+0, 0x1.00ffd43429187p-1, -0x1.575037b46d40ep-2, 0x1.01ccce2389225p-2, -0x1.9ad5c5f8b1ca0p-3, 0x1.4be166bca4a3bp-3, -0x1.f4ce6acf38b9fp-4, 0x1.2ad5f983a0e1bp-4, -0x1.8baa1512ed433p-6}},
+    {{-0x1.e01edcccb0eeap+2, -0x1.007fd8f64c62dp+0, 0x1.00fb66952f750p-1, -0x1.5702218b672d2p-2, 0x1.000c15a23c3eep-2, -0x1.8d32e047e13e7p-3, 0x1.27ee005d63bfap-3, -0x1.78ce719f420e0p-4, 0x1.57b35899f46d3p-5, -0x1.40b5d49acdb02p-7}},
+    {{-0x1.e01ee056c592ep+2, -0x1.007e909266746p+0, 0x1.00e0c8044d7c4p-1, -0x1.55bdafba06f96p-2, 0x1.f617a1305e5ecp-3, -0x1.72b024da05318p-3, 0x1.f172051799c7ap-4, -0x1.0be17e7579e44p-4, 0x1.87e047779463fp-6, -0x1.1a4ff031c4354p-8}},
+    {{-0x1.e01ef304583f5p+2, -0x1.0079667310f31p+0, 0x1.008f37737d849p-1, -0x1.52cb22b65e799p-2, 0x1.e47d30ba52559p-3, -0x1.4f7defcfe6f98p-3, 0x1.9334c2731e292p-4, -0x1.74d6497fa26dfp-5, 0x1.c5b33835c24b7p-7, -0x1.0a2d6658c2180p-9}},
+    {{-0x1.e01f302ea2969p+2, -0x1.006bc4662f64cp+0, 0x1.ffc3c73e11fa1p-2, -0x1.4dc22af252ff9p-2, 0x1.cc5a068731327p-3, -0x1.28d0553f9e354p-3, 0x1.40562daae8ecap-4, -0x1.0260abc25dc92p-5, 0x1.0cbf1b073231ap-7, -0x1.09f736e6ec1fap-10}},
+    {{-0x1.e01fc521c76f9p+2, -0x1.004ffecace041p+0, 0x1.fd75826710ee8p-2, -0x1.4699167ea2003p-2, 0x1.afb4cf4b5a494p-3, -0x1.028a8f4ddc067p-3, 0x1.f80c42470d87ep-5, -0x1.67aebe2a38897p-6, 0x1.4669013773899p-8, -0x1.174d94ed9a953p-11}},
+    {{-0x1.e020eed4bdc03p+2, -0x1.0020516acc4fep+0, 0x1.fa0f86938b93bp-2, -0x1.3d8ab9e27f6ccp-2, 0x1.90a252ae55e87p-3, -0x1.bde8380653f18p-4, 0x1.8b3390113199ap-5, -0x1.f90beb4bd4e87p-7, 0x1.964f3efd90569p-9, -0x1.3237d4224cacep-12}},
+    {{-0x1.0645b13dfd885p+3, -0x1.003ffff7fd520p+0, 0x1.007fffdf92895p-1, -0x1.5655549c76a12p-2, 0x1.00ffef643fae0p-2, -0x1.9b95d0b6cb325p-3, 0x1.570f4501eee1fp-3, -0x1.2364ffd5e605bp-3, 0x1.d668650fd1205p-4, -0x1.0bcdf05a05eefp-4}},
+    {{-0x1.0645b13e72d66p+3, -0x1.003fff25550c1p+0, 0x1.007fd56f6e7c1p-1, -0x1.56504575c8178p-2, 0x1.00cd3f898bff1p-2, -0x1.98dbbdd415318p-3, 0x1.49fe7e01a3d34p-3, -0x1.f1982a1b12ae4p-4, 0x1.28c26d6589260p-4, -0x1.88c68c462903dp-6}},
+    {{-0x1.0645b162b4ce1p+3, -0x1.003fd97988328p+0, 0x1.007b7064b9426p-1, -0x1.5602c70d63edbp-2, 0x1.fe1fe41953b58p-3, -0x1.8b5388ae5d250p-3, 0x1.2651bbb09dd31p-3, -0x1.768cd55b8351dp-4, 0x1.55835fcadcc37p-5, -0x1.3e96d4f9477c8p-7}},
+    {{-0x1.0645b3249d331p+3, -0x1.003e935c18216p+0, 0x1.00610124a9157p-1, -0x1.54c0973b26567p-2, 0x1.f431364e244c5p-3, -0x1.710041636eb9dp-3, 0x1.eee2e5f7aaf66p-4, -0x1.0a63d25d195e1p-4, 0x1.85953e584d23ep-6, -0x1.189b13bada6b0p-8}},
+    {{-0x1.0645bc6c28065p+3, -0x1.003971ae379eap+0, 0x1.000ff622aa73ap-1, -0x1.51d2dfc632278p-2, 0x1.e2b3b1484e7ebp-3, -0x1.4e07f7d0c355bp-3, 0x1.9140fbfde6d47p-4, -0x1.72e7f7aedf5a5p-5, 0x1.c33f0eac97272p-7, -0x1.08b22237abc08p-9}},
+    {{-0x1.0645dad30c9bbp+3, -0x1.002be445e4ea7p+0, 0x1.fec7522569dddp-2, -0x1.4cd18c83c2ae7p-2, 0x1.cab53605f20fdp-3, -0x1.2795384d0aabep-3, 0x1.3ee0a973c28bep-4, -0x1.0120f5595ccd3p-5, 0x1.0b657085a43a7p-7, -0x1.0898101684faep-10}},
+    {{-0x1.064624e3c550bp+3, -0x1.001045cd4ec59p+0, 0x1.fc7c4de6b65b9p-2, -0x1.45b2942c4a090p-2, 0x1.ae387a82c6c2ep-3, -0x1.0185969064bdfp-3, 0x1.f5e2b0059b883p-5, -0x1.660df2a770aa8p-6, 0x1.44e1249b8aa99p-8, -0x1.15f6085bc387bp-11}},
+    {{-0x1.0646b8f95014ep+3, -0x1.ffc1ae785c610p-1, 0x1.f91acd09bb232p-2, -0x1.3cb02a63ff95cp-2, 0x1.8f4f051e98b52p-3, -0x1.bc3c545e8d33fp-4, 0x1.8999efe51c186p-5, -0x1.f6e5fa2f0c2b0p-7, 0x1.948607167d946p-9, -0x1.30d74687d4e27p-12}},
+    {{-0x1.1c77f43cad04ep+3, -0x1.001ffffeffa96p+0, 0x1.003ffffb9eae1p-1, -0x1.55d554fa5666bp-2, 0x1.007ff0035d0f2p-2, -0x1.9a95d6b2b6152p-3, 0x1.560f99b8be440p-3, -0x1.2268c54c64fccp-3, 0x1.d49eb382db521p-4, -0x1.0ab4487b0b669p-4}},
+    {{-0x1.1c77f43d21d64p+3, -0x1.001fff2d37a19p+0, 0x1.003fd5b8c15bfp-1, -0x1.55d04b3d69a2fp-2, 0x1.004d7698a74eap-2, -0x1.97deb543726f1p-3, 0x1.490d041cf4f6fp-3, -0x1.effcfe6ee481ep-4, 0x1.27b89f0ee560ep-4, -0x1.8754bb6afca80p-6}},
+    {{-0x1.1c77f46140981p+3, -0x1.001fd9a61711ep+0, 0x1.003b74f855169p-1, -0x1.558318b808491p-2, 0x1.fd23bd5b41991p-3, -0x1.8a63d8de6ae05p-3, 0x1.2583951ba00ebp-3, -0x1.756c0062f9711p-4, 0x1.546b5c1fafe68p-5, -0x1.3d874dae5b4d5p-7}},
+    {{-0x1.1c77f62197facp+3, -0x1.001e94abea84bp+0, 0x1.00211d61611a0p-1, -0x1.544209edf46a1p-2, 0x1.f33dfdf8da6adp-3, -0x1.70284c5b61bd7p-3, 0x1.ed9b507912b5fp-4, -0x1.09a4f873207bep-4, 0x1.846fb3612fa74p-6, -0x1.17c0a07ce02d0p-8}},
+    {{-0x1.1c77ff61835bfp+3, -0x1.00197736df7b9p+0, 0x1.ffa0aa50ee95cp-2, -0x1.5156bd4fe70d5p-2, 0x1.e1ceef08769a1p-3, -0x1.4d4cf94005043p-3, 0x1.904714cd8579ep-4, -0x1.71f0ca783c715p-5, 0x1.c204f41363410p-7, -0x1.07f47c797e233p-9}},
+    {{-0x1.1c781db147281p+3, -0x1.000bf4210ca2dp+0, 0x1.fe4916fb22c8fp-2, -0x1.4c593c6344e31p-2, 0x1.c9e2cba386b7bp-3, -0x1.26f7a7e51a863p-3, 0x1.3e25e4bff3a0ep-4, -0x1.008117bb380fbp-5, 0x1.0ab8988245ab7p-7, -0x1.07e879c35f2cdp-10}},
+    {{-0x1.1c78678d920a2p+3, -0x1.ffe0d274711d0p-1, 0x1.fbffb31048a7ap-2, -0x1.453f5231e20a5p-2, 0x1.ad7a4e5ce2d64p-3, -0x1.010318c3e957dp-3, 0x1.f4cde381ebb87p-5, -0x1.653d8a26e3d7cp-6, 0x1.441d339593ec8p-8, -0x1.154a3f99c09bdp-11}},
+    {{-0x1.1c78fb4123094p+3, -0x1.ff82342213dd9p-1, 0x1.f8a06fb7d12d0p-2, -0x1.3c42e1ec353c6p-2, 0x1.8ea55cea0ccb2p-3, -0x1.bb66607227f89p-4, 0x1.88cd1d96ff556p-5, -0x1.f5d2fe703bd3dp-7, 0x1.93a1685b047d9p-9, -0x1.3026fd8250ffap-12}},
+    {{-0x1.32a8373b9de85p+3, -0x1.000fffffdfcefp+0, 0x1.001fffff1fa26p-1, -0x1.5595550631d34p-2, 0x1.003ff01e48115p-2, -0x1.9a15d91d404b9p-3, 0x1.558fc35002676p-3, -0x1.21eaa710ec14bp-3, 0x1.d3b9d89ed09f2p-4, -0x1.0a2773115627fp-4}},
+    {{-0x1.32a8373c127b6p+3, -0x1.000fff2e87e76p+0, 0x1.001fd5d2e5eabp-1, -0x1.55904dfe2d44fp-2, 0x1.000d91ebdb81bp-2, -0x1.9760306bc3eddp-3, 0x1.4894467a4bff6p-3, -0x1.ef2f672fcf9ccp-4, 0x1.2733b6db9a134p-4, -0x1.869bd170503a9p-6}},
+    {{-0x1.32a837601fa22p+3, -0x1.000fd9b9bda5bp+0, 0x1.001b7737a2f29p-1, -0x1.5543416aa3395p-2, 0x1.fca5a9976b523p-3, -0x1.89ec007669d8ep-3, 0x1.251c8149b91acp-3, -0x1.74db950c950cbp-4, 0x1.53df59626d35cp-5, -0x1.3cff891a7292cp-7}},
+    {{-0x1.32a8391fae822p+3, -0x1.000e955133ec1p+0, 0x1.00012b7553634p-1, -0x1.5402c325b64aep-2, 0x1.f2c46171eadf2p-3, -0x1.6fbc516e0c6efp-3, 0x1.ecf784fc7e7cdp-4, -0x1.09458b02c9f32p-4, 0x1.83dced1953603p-6, -0x1.1753663e13506p-8}},
+    {{-0x1.32a8425bca244p+3, -0x1.000979f896fc6p+0, 0x1.ff61094252ac1p-2, -0x1.5118abf50c4e2p-2, 0x1.e15c8d97e12d6p-3, -0x1.4cef79a5b61bfp-3, 0x1.8fca20b6f347dp-4, -0x1.7175335384da1p-5, 0x1.c167e60cbd684p-7, -0x1.0795a9250a331p-9}},
+    {{-0x1.32a8609ffd7c1p+3, -0x1.fff7f81816335p-1, 0x1.fe09f95249fa3p-2, -0x1.4c1d1435eeaf5p-2, 0x1.c979962e3f18fp-3, -0x1.26a8df7373c62p-3, 0x1.3dc882133a1a2p-4, -0x1.0031289f2448fp-5, 0x1.0a622c287f27fp-7, -0x1.0790ae3cae140p-10}},
+    {{-0x1.32a8aa621155dp+3, -0x1.ffc0f5dc47276p-1, 0x1.fbc16592522c7p-2, -0x1.4505b11a93cb2p-2, 0x1.ad1b3811dc80bp-3, -0x1.00c1d9b00e398p-3, 0x1.f4437cd3f64bdp-5, -0x1.64d5558eeeb6dp-6, 0x1.43bb3abbcf220p-8, -0x1.14f45ae9ced54p-11}},
+    {{-0x1.32a93de4a5402p+3, -0x1.ff6276f1fc210p-1, 0x1.f86340fd43a05p-2, -0x1.3c0c3d9949f14p-2, 0x1.8e5088a248f4ap-3, -0x1.bafb663909e01p-4, 0x1.8866b42916f47p-5, -0x1.f549802b016a1p-7, 0x1.932f18a47e903p-9, -0x1.2fced8b8b0952p-12}},
+    {{-0x1.48d77a3a96f78p+3, -0x1.0007fffffbd15p+0, 0x1.000fffff8fca9p-1, -0x1.55755507be41ep-2, 0x1.001ff0252b58cp-2, -0x1.99d5da401f24dp-3, 0x1.554fd8032ab4dp-3, -0x1.21ab97d4676a0p-3, 0x1.d3476ae93c7bdp-4, -0x1.09e1082d4e675p-4}},
+    {{-0x1.48d77a3b0b6b6p+3, -0x1.0007ff2edbfa0p+0, 0x1.000fd5dea7e7bp-1, -0x1.55704f5a2eb81p-2, 0x1.ffdb3f1dd9475p-3, -0x1.9720edee07e75p-3, 0x1.4857e792f6a17p-3, -0x1.eec89b6339e2dp-4, 0x1.26f142a104ec4p-4, -0x1.863f5c416f8c7p-6}},
+    {{-0x1.48d77a5f0fc49p+3, -0x1.0007d9c33ce47p+0, 0x1.000b7855fa304p-1, -0x1.552355bf9b0b0p-2, 0x1.fc669fa8eab77p-3, -0x1.89b014326e40ap-3, 0x1.24e8f74fdf5a5p-3, -0x1.74935f462a56bp-4, 0x1.539957e6e2e1ap-5, -0x1.3cbba6b2bd18dp-7}},
+    {{-0x1.48d77c1e3a631p+3, -0x1.000695a384b6dp+0, 0x1.ffe264fbff421p-2, -0x1.53e31fbd63c7dp-2, 0x1.f2879322ed792p-3, -0x1.6f8653ea3c888p-3, 0x1.eca59f2694260p-4, -0x1.0915d43b3961cp-4, 0x1.839389dbe5b19p-6, -0x1.171cc90abb01ep-8}},
+    {{-0x1.48d785586e24fp+3, -0x1.00017b591f3f2p+0, 0x1.ff4138b87839ep-2, -0x1.50f9a343a95fep-2, 0x1.e1235cd5845eap-3, -0x1.4cc0b9ce540ffp-3, 0x1.8f8ba69be3766p-4, -0x1.713767b002709p-5, 0x1.c1195ef23185ep-7, -0x1.07663f6c2a0f2p-9}},
+    {{-0x1.48d7a396d9409p+3, -0x1.ffe800026f706p-1, 0x1.fdea6a7b677c7p-2, -0x1.4bff001ba1a2dp-2, 0x1.c944fb6b1b85ap-3, -0x1.26817b32ecf47p-3, 0x1.3d99d0b2866dep-4, -0x1.000931077d6d6p-5, 0x1.0a36f5f09cbd7p-7, -0x1.0764c86db5c67p-10}},
+    {{-0x1.48d7ed4bd1926p+3, -0x1.ffb1078f8fd34p-1, 0x1.fba23ed0ff81dp-2, -0x1.44e8e08baa382p-2, 0x1.acebace558b9dp-3, -0x1.00a13a206ea71p-3, 0x1.f3fe496f7bfd8p-5, -0x1.64a13b3801b89p-6, 0x1.438a3e4417000p-8, -0x1.14c96887fb144p-11}},
+    {{-0x1.48d880b5e6ec0p+3, -0x1.ff52985951f0ap-1, 0x1.f844a99dca428p-2, -0x1.3bf0eb6cf43b5p-2, 0x1.8e261e78b8cadp-3, -0x1.bac5e9141fb24p-4, 0x1.88337f694a0a0p-5, -0x1.f504c0fbada45p-7, 0x1.92f5f0be25b93p-9, -0x1.2fa2c64b073b5p-12}},
+    {{-0x1.5f063d39910c1p+3, -0x1.0003ffffff518p+0, 0x1.0007ffff9dd98p-1, -0x1.55655507f864ap-2, 0x1.000ff027cad91p-2, -0x1.99b5dacf423bcp-3, 0x1.552fe259b04e3p-3, -0x1.218c10324cfbcp-3, 0x1.d30e340602c58p-4, -0x1.09bdd2b56681ep-4}},
+    {{-0x1.5f063d3a05706p+3, -0x1.0003ff2efb826p+0, 0x1.0007d5e45ee20p-1, -0x1.55605007a37a5p-2, 0x1.ffbb4cbf48727p-3, -0x1.97014cacedb98p-3, 0x1.4839b81c8c6b8p-3, -0x1.ee9535774ee4ep-4, 0x1.26d0087f9d643p-4, -0x1.861121a3cf6c7p-6}},
+    {{-0x1.5f063d5e0562dp+3, -0x1.0003d9c7f2037p+0, 0x1.000378e4fbde3p-1, -0x1.55135fe98c532p-2, 0x1.fc471ab017fe5p-3, -0x1.89921e0e71709p-3, 0x1.24cf3250d61d4p-3, -0x1.746f445f8ea24p-4, 0x1.5376572581615p-5, -0x1.3c99b57b2b0c3p-7}},
+    {{-0x1.5f063f1cfde08p+3, -0x1.000295cca2a01p+0, 0x1.ffd26c0458502p-2, -0x1.53d34e08b42afp-2, 0x1.f2692bf9fe4d8p-3, -0x1.6f6b5526b0373p-3, 0x1.ec7cac38ab803p-4, -0x1.08fdf8d584cf0p-4, 0x1.836ed839ff8b9p-6, -0x1.17017a6e91206p-8}},
+    {{-0x1.5f0648563db22p+3, -0x1.fffaf812b1e3bp-1, 0x1.ff315073397aep-2, -0x1.50ea1eea79486p-2, 0x1.e106c47313e5bp-3, -0x1.4ca959e15bed0p-3, 0x1.8f6c698c630e5p-4, -0x1.711881dc1ccabp-5, 0x1.c0f21b6204fe9p-7, -0x1.074e8a8de58f5p-9}},
+    {{-0x1.5f066691c4af8p+3, -0x1.ffe003f78769bp-1, 0x1.fddaa30fa783fp-2, -0x1.4beff60e06edbp-2, 0x1.c92aae0879eb3p-3, -0x1.266dc911b343bp-3, 0x1.3d827800e1f05p-4, -0x1.ffea6a74ed27fp-6, 0x1.0a215ad34bdf2p-7, -0x1.074ed584c5e7fp-10}},
+    {{-0x1.5f06b0402f3cdp+3, -0x1.ffa910691fdffp-1, 0x1.fb92ab700b476p-2, -0x1.44da7843cd2d8p-2, 0x1.acd3e74e36e1fp-3, -0x1.0090ea57e8b82p-3, 0x1.f3dbafbb8f250p-5, -0x1.64872e0b2d225p-6, 0x1.4371c006e06e8p-8, -0x1.14b3ef55d60afp-11}},
+    {{-0x1.5f07439e054d5p+3, -0x1.ff4aa90ce90ffp-1, 0x1.f8355dedc7485p-2, -0x1.3be342566d698p-2, 0x1.8e10e9633b05fp-3, -0x1.baab2a809f5c1p-4, 0x1.8819e50848a60p-5, -0x1.f4e261626d2aep-7, 0x1.92d95cc996c67p-9, -0x1.2f8cbd1317948p-12}},
+    {{-0x1.7534c0388b416p+3, -0x1.0001ffffffc18p+0, 0x1.0003ffff9fa0bp-1, -0x1.555d550803f4cp-2, 0x1.0007f02900570p-2, -0x1.99a5db168a43ap-3, 0x1.551fe7849153fp-3, -0x1.217c4c60c4d06p-3, 0x1.d2f1989358191p-4, -0x1.09ac37f8b6288p-4}},
+    {{-0x1.7534c038ff9dep+3, -0x1.0001ff2f09f67p+0, 0x1.0003d5e7351efp-1, -0x1.5558505e4c5ddp-2, 0x1.ffab538fcbcd9p-3, -0x1.96f17c0c19242p-3, 0x1.482aa060ff690p-3, -0x1.ee7b8280a5764p-4, 0x1.26bf6b6e66115p-4, -0x1.85fa0454397bcp-6}},
+    {{-0x1.7534c05cfd5cep+3, -0x1.0001d9ca4b42fp+0, 0x1.fffef258eeeecp-2, -0x1.550b64fe73a46p-2, 0x1.fc3758337c587p-3, -0x1.898322fc332e0p-3, 0x1.24c24fd10df9ep-3, -0x1.745d36ebd4085p-4, 0x1.5364d6c45d230p-5, -0x1.3c88bcdeeb293p-7}},
+    {{-0x1.7534c21bdcca4p+3, -0x1.000095e130454p+0, 0x1.ffca6f887a71dp-2, -0x1.53cb652e4b925p-2, 0x1.f259f86558ac4p-3, -0x1.6f5dd5c4b5876p-3, 0x1.ec6832c158c6dp-4, -0x1.08f20b226d026p-4, 0x1.835c7f68a698fp-6, -0x1.16f3d3202c808p-8}},
+    {{-0x1.7534cb54a2a3bp+3, -0x1.fff6f8c2e8fadp-1, 0x1.ff295c508feb3p-2, -0x1.50e25cbdd169cp-2, 0x1.e0f87841b36a2p-3, -0x1.4c9da9eab6fb5p-3, 0x1.8f5ccb0463cfdp-4, -0x1.71090ef1e56fcp-5, 0x1.c0de799991f0bp-7, -0x1.0742b01e88c73p-9}},
+    {{-0x1.7534e98eb791ep+3, -0x1.ffdc05f210d1cp-1, 0x1.fdd2bf59bdb10p-2, -0x1.4be871072b0e4p-2, 0x1.c91d875707266p-3, -0x1.2663f000f7a4bp-3, 0x1.3d76cba7e65ffp-4, -0x1.ffd66ea7997a1p-6, 0x1.0a168d44777eap-7, -0x1.0743dc101f85cp-10}},
+    {{-0x1.75353339db3cep+3, -0x1.ffa514d5e55d4p-1, 0x1.fb8ae1bf87ce0p-2, -0x1.44d3441fd1a0ep-2, 0x1.acc8048289f96p-3, -0x1.0088c2738efdap-3, 0x1.f3ca62e162c6bp-5, -0x1.647a27749717cp-6, 0x1.436580e819d93p-8, -0x1.14a932bc9c246p-11}},
+    {{-0x1.7535c69191a8bp+3, -0x1.ff46b166b226bp-1, 0x1.f82db815bd025p-2, -0x1.3bdc6dcb1e827p-2, 0x1.8e064ed8656f0p-3, -0x1.ba9dcb36bdcb6p-4, 0x1.880d17d7a498bp-5, -0x1.f4d131959a1f1p-7, 0x1.92cb12cf22ff8p-9, -0x1.2f81b876fc649p-12}},
+    {{-0x1.8b632337857abp+3, -0x1.0000ffffffcf9p+0, 0x1.0001ffff9fdc4p-1, -0x1.55595508078ccp-2, 0x1.0003f02997cdep-2, -0x1.999ddb3a2517ap-3, 0x1.5517ea19f59eap-3, -0x1.21746a77f15d2p-3, 0x1.d2e34ad9e10aep-4, -0x1.09a36a9a4670ap-4}},
+    {{-0x1.8b632337f9d35p+3, -0x1.0000ff2f11068p+0, 0x1.0001d5e89f957p-1, -0x1.555450899e9ffp-2, 0x1.ffa356f806f41p-3, -0x1.96e993bba5ea1p-3, 0x1.482314832deb6p-3, -0x1.ee6ea9053a425p-4, 0x1.26b71ce5b9f70p-4, -0x1.85ee75ac55c8ep-6}},
+    {{-0x1.8b63235bf678ap+3, -0x1.0000d9cb77b8bp+0, 0x1.fffaf2a069388p-2, -0x1.55076788e522bp-2, 0x1.fc2f76f5283cap-3, -0x1.897ba5730c11dp-3, 0x1.24bbde9121780p-3, -0x1.74543031e9242p-4, 0x1.535c1693bc94dp-5, -0x1.3c804090bc5cfp-7}},
+    {{-0x1.8b63251ac95ddp+3, -0x1.ffff2bd6eddbdp-1, 0x1.ffc6714a8a360p-2, -0x1.53c770c1152cdp-2, 0x1.f2525e9b001a8p-3, -0x1.6f571613b19eep-3, 0x1.ec5df605a39ddp-4, -0x1.08ec1448d96c0p-4, 0x1.835352ffed645p-6, -0x1.16ecff78f03b2p-8}},
+    {{-0x1.8b632e53523b3p+3, -0x1.fff4f91b0432fp-1, 0x1.ff25623f39dd7p-2, -0x1.50de7ba77b801p-2, 0x1.e0f15228fe24bp-3, -0x1.4c97d1ef5f66bp-3, 0x1.8f54fbc05c4f9p-4, -0x1.7101557cc131bp-5, 0x1.c0d4a8b54cd10p-7, -0x1.073cc2e6d3127p-9}},
+    {{-0x1.8b634c8cae21cp+3, -0x1.ffda06ef55334p-1, 0x1.fdcecd7ec78cdp-2, -0x1.4be4ae83bb4dfp-2, 0x1.c916f3fe49853p-3, -0x1.265f037895fc9p-3, 0x1.3d70f57b636dcp-4, -0x1.ffcc70c0e6090p-6, 0x1.0a11267d07d06p-7, -0x1.073e5f55c6869p-10}},
+    {{-0x1.8b6396362e5bap+3, -0x1.ffa3170c47cacp-1, 0x1.fb86fce744e5dp-2, -0x1.44cfaa0dd239bp-2, 0x1.acc2131cb005ap-3, -0x1.0084ae815f481p-3, 0x1.f3c1bc7445d99p-5, -0x1.6473a429469acp-6, 0x1.435f6158b1253p-8, -0x1.14a3d46ffa451p-11}},
+    {{-0x1.8b64298ad4f52p+3, -0x1.ff44b5939662fp-1, 0x1.f829e529b6c64p-2, -0x1.3bd90385759f3p-2, 0x1.8e010192f7cd2p-3, -0x1.ba971b91c8d67p-4, 0x1.8806b13f4e26cp-5, -0x1.f4c899af2a3f8p-7, 0x1.92c3edd1e3928p-9, -0x1.2f7c3628ea613p-12}},
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+static __shared__ __attribute__((aligned(16))) phf_logphitab phf_lds_logphi[PHF_LOGPHI_TAB_N];
+#define PHF_T_LOGPHI(j) phf_lds_logphi[j]
+#define PHF_LOGPHI_TABLE_TO_LDS()                                                                                   \
+  do {                                                                                                              \
+    for (int phf_i_ = threadIdx.x; phf_i_ < PHF_LOGPHI_TAB_N * 10; phf_i_ += blockDim.x)                            \
+      (&phf_lds_logphi[0].c[0])[phf_i_] = (&phf_t_logphi[0].c[0])[phf_i_];                                          \
+    __syncthreads();                                                                                                \
+  } while (0)
+#else
+#define PHF_T_LOGPHI(j) phf_t_logphi[j]
+#define PHF_LOGPHI_TABLE_TO_LDS() do { } while (0)
+#endif
+
+/* y = -x/sqrt2 in [0, PHF_LOGPHI_Y_MAX): log Phi(x).  Any other y: some finite or NaN value, no out-of-table access. */
+PHF_HD double phf_log_ndtr_tab(double x, double y) {
+  const uint64_t vb = phf_bits(y + 1.0);
+  const uint32_t jr = (uint32_t)(vb >> 49) - (0x3ffu << 3);           /* 8 E + the top three mantissa bits */
+  const uint32_t j = jr < (uint32_t)PHF_LOGPHI_TAB_N ? jr : (uint32_t)(PHF_LOGPHI_TAB_N - 1);
+  const double sft = phf_from_bits((vb & 0x000fffffffffffffull) | 0x3ff0000000000000ull) - 1.0;
+  const phf_logphitab e = PHF_T_LOGPHI(j);
+  double g = phf_fma(e.c[9], sft, e.c[8]);
+  g = phf_fma(g, sft, e.c[7]);
+  g = phf_fma(g, sft, e.c[6]);
+  g = phf_fma(g, sft, e.c[5]);
+  g = phf_fma(g, sft, e.c[4]);
+  g = phf_fma(g, sft, e.c[3]);
+  g = phf_fma(g, sft, e.c[2]);
+  g = phf_fma(g, sft, e.c[1]);
+  g = phf_fma(g, sft, e.c[0]);
+  return phf_fma(-0.5 * x, x, g);
+}
+
 /* log Phi(x), any x.  x > 0: log(1 - q), q = erfcx(x/sqrt2) exp(-x^2/2)/2, with the log1p correction term. */
 PHF_HD double phf_log_ndtr(double x) {
   if (x <= 0.0) {
@@ -630,141 +818,77 @@ PHF_HD void phf_sincos_2pi_u32(uint32_t w, double* sn, double* cs) { PHF_KFETCH_
  * One standard normal from one 32-bit word by a piecewise inverse CDF (the single-level sampler's proposals; the hierarchical
  * sampler keeps Box-Muller, its LDS is full): w = the low 31 bits, p = (w + 1/2) / 2^32 in (0, 1/2), |z| = -Phi^-1(p), the sign
  * is the top bit — so v and v ^ 2^31 give +-z: the proposal is exactly symmetric, which is all Metropolis needs, and |z| <= 6.34.
- * a = 2 w + 1 = 2^E m converts to a double exactly; its exponent and two mantissa bits select one of 128 intervals, on which
- * |z| = P(m - 1), degree 5 (max error 4.4e-9 over all intervals: tools/gen_math_coeffs.py normal) — 6 fp64 operations and three
- * 16-byte LDS reads where Box-Muller spent a logarithm, a square root and half a sine/cosine pair (~21).  The table (6 KB) goes
- * to LDS with PHF_NORMAL_TABLE_TO_LDS() in the kernels that draw with it. */
-#define PHF_NORMAL_TAB_N 128
+ * a = 2 w + 1 = 2^E m converts to a double exactly; its exponent and top mantissa bit select one of 64 intervals, on which
+ * |z| = P(m - 1), degree 5 (max error 1.7e-7 over all intervals: tools/gen_math_coeffs.py normal — a proposal need not be more normal
+ * than that) — 6 fp64 operations and three 16-byte LDS reads where Box-Muller spent a logarithm, a square root and half a
+ * sine/cosine pair (~21).  The table (3 KB) goes to LDS with PHF_NORMAL_TABLE_TO_LDS() in the kernels that draw with it. */
+#define PHF_NORMAL_TAB_N 64
 typedef struct { double c[6]; } phf_normtab;
 static const phf_normtab phf_t_normal[PHF_NORMAL_TAB_N] = {
-    {{0x1.95a1198e14418p+2, -0x1.3b9fc1bb6c69dp-3, 0x1.34339dd030bf6p-4, -0x1.93529ba159b71p-5, 0x1.14a12e05662a6p-5, -0x1.0f87a210ea2d9p-6}},
-    {{0x1.95a0ea99ed462p+2, -0x1.3b378d5c7917cp-3, 0x1.2e2ee0317a3efp-4, -0x1.64651173421bbp-5, 0x1.6692ddc48b0f5p-6, -0x1.8e2ff230dbf1cp-8}},
-    {{0x1.959f3f3705db7p+2, -0x1.392b531249d00p-3, 0x1.1de00cce9c160p-4, -0x1.227a51efdc39dp-5, 0x1.bea74476fe4f6p-7, -0x1.59ceaad6c8bf8p-9}},
-    {{0x1.959a43173ca3bp+2, -0x1.3507773278c54p-3, 0x1.07b9666c037dcp-4, -0x1.cda6d95bebc0cp-6, 0x1.1cf37cb5a91ffp-7, -0x1.52ad7da7e8973p-10}},
-    {{0x1.8ebc9502cd7a4p+2, -0x1.40d4cfa4f89e1p-3, 0x1.390b37ac7a2e8p-4, -0x1.9984d4d0849e0p-5, 0x1.18d2af06be7ddp-5, -0x1.139d799332a2ep-6}},
-    {{0x1.8ebc655a2d3e3p+2, -0x1.406b0ae695bb6p-3, 0x1.32ef5d3fb4d49p-4, -0x1.69e330dc6ee31p-5, 0x1.6c0b3c404b895p-6, -0x1.943ae460d0061p-8}},
-    {{0x1.8ebab381c7c8bp+2, -0x1.3e56e4fcf3f57p-3, 0x1.22617adc92731p-4, -0x1.26f9a1c762b1ep-5, 0x1.c582add5dbf21p-7, -0x1.5f17d55f7c365p-9}},
-    {{0x1.8eb5a3fa32222p+2, -0x1.3a22ebdfc4315p-3, 0x1.0be4a07da11c8p-4, -0x1.d4d543d1e74a1p-6, 0x1.2159d2d9336a5p-7, -0x1.57e3014eb2484p-10}},
-    {{0x1.87ba7890f9ceep+2, -0x1.464d16df6892dp-3, 0x1.3e1e2289f4ba3p-4, -0x1.a0013696fdd19p-5, 0x1.1d35b0aa58d42p-5, -0x1.17e32c8f65e3fp-6}},
-    {{0x1.87ba482ba2c5cp+2, -0x1.45e1af7b73392p-3, 0x1.37ea1d63d7223p-4, -0x1.6fa342e5866b4p-5, 0x1.71c498298afadp-6, -0x1.9a8d3ea1bb200p-8}},
-    {{0x1.87b88f91bf93dp+2, -0x1.43c540c6d6f5bp-3, 0x1.271a466f12271p-4, -0x1.2baf308ca813ep-5, 0x1.ccb0143ca5837p-7, -0x1.649feb01386ecp-9}},
-    {{0x1.87b36bbc993f8p+2, -0x1.3f806ba821cc5p-3, 0x1.10433bbdefad0p-4, -0x1.dc5ab67fe0a71p-6, 0x1.25f512826d1dcp-7, -0x1.5d56ea0004446p-10}},
-    {{0x1.80993fb0b3d6cp+2, -0x1.4c0e633209b13p-3, 0x1.4371333d3a2ddp-4, -0x1.a6cda638eb47bp-5, 0x1.21ce142dba020p-5, -0x1.1c5c73aacb877p-6}},
-    {{0x1.80990e85c4cbdp+2, -0x1.4ba1457795a46p-3, 0x1.3d23e086a6646p-4, -0x1.75aa8a0193539p-5, 0x1.77c411f7c2d2ep-6, -0x1.a12c9afcc8f5bp-8}},
-    {{0x1.80974ed874a4fp+2, -0x1.497c29861e0bdp-3, 0x1.2c0ef58c2659bp-4, -0x1.309f56ed8acc4p-5, 0x1.d435fa28f1dfep-7, -0x1.6a6be4b03be3cp-9}},
-    {{0x1.809215bdea211p+2, -0x1.4525aaa3db7e9p-3, 0x1.14d96e0715c4fp-4, -0x1.e43e332c9fc20p-6, 0x1.2ac975849e679p-7, -0x1.630e2e29270c6p-10}},
-    {{0x1.795743c3d603bp+2, -0x1.521f38c41f661p-3, 0x1.4909cf05c29dbp-4, -0x1.adf0b4cbbc3afp-5, 0x1.26a02a3993665p-5, -0x1.210d7188f03e3p-6}},
-    {{0x1.795711c9b7ef4p+2, -0x1.51b04f6f36c6dp-3, 0x1.42a1f4a9db3f9p-4, -0x1.7bfee269d75edp-5, 0x1.7e0f5e5542b72p-6, -0x1.a81f3479b0c9ap-8}},
-    {{0x1.79554ab072446p+2, -0x1.4f8219b898ef4p-3, 0x1.314495dbb082fp-4, -0x1.35ceed43fd765p-5, 0x1.dc1b9f81fdf9bp-7, -0x1.70814b5e0e985p-9}},
-    {{0x1.794ffb4498c7fp+2, -0x1.4b1912a344c3dp-3, 0x1.19abebd15b67dp-4, -0x1.ec878a724c0ffp-6, 0x1.2fdbb16521462p-7, -0x1.690e54da913c5p-10}},
-    {{0x1.71f2b7c5ea520p+2, -0x1.5886f282ded58p-3, 0x1.4eee01c9318c5p-4, -0x1.b571b8f8217cfp-5, 0x1.2bb0c35501662p-5, -0x1.25fac250189a9p-6}},
-    {{0x1.71f284f23b888p+2, -0x1.5816268e61b58p-3, 0x1.486a4bccc8fe0p-4, -0x1.82a6d93e52ff7p-5, 0x1.84acdc25f8303p-6, -0x1.af6bfee7e17f1p-8}},
-    {{0x1.71f0b60d1bab6p+2, -0x1.55de618541356p-3, 0x1.36c0d198d324cp-4, -0x1.3b435ee0d8970p-5, 0x1.e4691defbf005p-7, -0x1.76e64d6950bb0p-9}},
-    {{0x1.71eb4f2d9c2a3p+2, -0x1.5161e13060b5dp-3, 0x1.1ebffbcf209a8p-4, -0x1.f53f7b26938e3p-6, 0x1.353109fa113b6p-7, -0x1.6f5d8b74d199fp-10}},
-    {{0x1.6a69a342a06e0p+2, -0x1.5f4de6dd1124ep-3, 0x1.552498997416bp-4, -0x1.bd58ed9258543p-5, 0x1.31054363428f8p-5, -0x1.2b298e05a7feap-6}},
-    {{0x1.6a696f8a1cab4p+2, -0x1.5edb1f4da2322p-3, 0x1.4e83960c03a11p-4, -0x1.89a9c801bdd8dp-5, 0x1.8ba3aea79a607p-6, -0x1.b71ac30dea28ep-8}},
-    {{0x1.6a67987101752p+2, -0x1.5c994b4cb2bbdp-3, 0x1.3c8a08919d414p-4, -0x1.4102c0fd968aep-5, 0x1.ed278a81460e0p-7, -0x1.7da1d80c731dcp-9}},
-    {{0x1.6a6218e26868bp+2, -0x1.58084bd3a6053p-3, 0x1.241b8e57d657fp-4, -0x1.fe6fd7bc5f74dp-6, 0x1.3acf678b9144cp-7, -0x1.7602bf66b4f05p-10}},
-    {{0x1.62b9dc6b60b9bp+2, -0x1.667d947223dfdp-3, 0x1.5bb54187003e3p-4, -0x1.c5af962285045p-5, 0x1.36a3b8da28e99p-5, -0x1.309f9e63fa1efp-6}},
-    {{0x1.62b9a7c1c571dp+2, -0x1.6608b618d29aep-3, 0x1.54f560f9d5b0fp-4, -0x1.910ff56f895bdp-5, 0x1.92fbdc97b8bf4p-6, -0x1.bf34403b53865p-8}},
-    {{0x1.62b7c8034dba9p+2, -0x1.63bc4824e0ed3p-3, 0x1.42a76e28d0e4dp-4, -0x1.4713ee2b6300fp-5, 0x1.f6611dd6e4454p-7, -0x1.84bbb5b238713p-9}},
-    {{0x1.62b22e6dee3a3p+2, -0x1.5f15ac3583569p-3, 0x1.29c55987a5cb2p-4, -0x1.0411d97fcfc79p-5, 0x1.40bd7144d0991p-7, -0x1.7d05bce940a57p-10}},
-    {{0x1.5ae1011a4f28ep+2, -0x1.6e20d8d0e2d6ap-3, 0x1.62a8b207d6364p-4, -0x1.ce802ac2a4a65p-5, 0x1.3c92f88da0f08p-5, -0x1.366378f583583p-6}},
-    {{0x1.5ae0cb723b640p+2, -0x1.6da9c603f7216p-3, 0x1.5bc83d73bdc36p-4, -0x1.98e2bcef3c061p-5, 0x1.9abe758b2a328p-6, -0x1.c7c2547bdcae3p-8}},
-    {{0x1.5adee29298602p+2, -0x1.6b52265a6238dp-3, 0x1.49212d916712dp-4, -0x1.4d7ea7500ac0bp-5, 0x1.0010b22b9af45p-6, -0x1.8c3cb25472870p-9}},
-    {{0x1.5ad92d7eed065p+2, -0x1.6694b633a1f9fp-3, 0x1.2fc4fb3977bd2p-4, -0x1.0933caf5e31efp-5, 0x1.4702acf953a7cp-7, -0x1.846f53e5a444dp-10}},
-    {{0x1.52dc6e83992dap+2, -0x1.7644340e16b73p-3, 0x1.6a08d59a26fa9p-4, -0x1.d7d68d1b0f81dp-5, 0x1.42dabf28e8f35p-5, -0x1.3c7c7e7840986p-6}},
-    {{0x1.52dc37ce68086p+2, -0x1.75cacc560035fp-3, 0x1.6305ed963d83fp-4, -0x1.a12cbe42ab8cdp-5, 0x1.a2f5bef4cdd49p-6, -0x1.d0d02d0246241p-8}},
-    {{0x1.52da4545fcfe4p+2, -0x1.736754bd28056p-3, 0x1.500095d51960cp-4, -0x1.544bbb8dc4ea2p-5, 0x1.053abc31562f6p-6, -0x1.942ec75a0f022p-9}},
-    {{0x1.52d473186bf26p+2, -0x1.6e91baab7685bp-3, 0x1.36232255caad7p-4, -0x1.0ea4e06dfe8fcp-5, 0x1.4da7a58bb6fc9p-7, -0x1.8c49848496594p-10}},
-    {{0x1.4aa937440fcf2p+2, -0x1.7ef61ce7ea822p-3, 0x1.71e106c723edfp-4, -0x1.e1c048ca0aa0bp-5, 0x1.4983d9bd6c76ep-5, -0x1.42f310d50a39dp-6}},
-    {{0x1.4aa8ff71ac822p+2, -0x1.7e7a3c9dd9caep-3, 0x1.6ab99cec54b82p-4, -0x1.a9fa178405c59p-5, 0x1.abad6ac654a9bp-6, -0x1.da6a80d3b7368p-8}},
-    {{0x1.4aa702ab712bdp+2, -0x1.7c0a366a74236p-3, 0x1.57504faeca5d9p-4, -0x1.5b8538d81483fp-5, 0x1.0ab624843de32p-6, -0x1.9c9d50d3ebce2p-9}},
-    {{0x1.4aa1119f52088p+2, -0x1.771afaa673876p-3, 0x1.3ce9c161de3f1p-4, -0x1.146d3d7dec318p-5, 0x1.54b619a354ab6p-7, -0x1.949fb554b376cp-10}},
-    {{0x1.4244176422a21p+2, -0x1.88476a74a2810p-3, 0x1.7a3e55535f0d6p-4, -0x1.ec4ce2324dcabp-5, 0x1.50985738923b7p-5, -0x1.49d0c15673eeap-6}},
-    {{0x1.4243de62d4a81p+2, -0x1.87c8ea4fb1a5ap-3, 0x1.72f0259ed579ap-4, -0x1.b358ac27f933cp-5, 0x1.b4f2da2678847p-6, -0x1.e49fd85552174p-8}},
-    {{0x1.4241d6ba6cdf2p+2, -0x1.854b8c0ea1103p-3, 0x1.5f1c9fe2817e4p-4, -0x1.6336a77f55d12p-5, 0x1.108b783f5f7ddp-6, -0x1.a5954e8579b8fp-9}},
-    {{0x1.423bc4dc269f1p+2, -0x1.80410fdb5aee3p-3, 0x1.44244cd2fdff7p-4, -0x1.1a9639dfdfd32p-5, 0x1.5c3934de96012p-7, -0x1.9d7ef5883fb87p-10}},
-    {{0x1.39a965c5dfb40p+2, -0x1.924bda2c954dap-3, 0x1.832fdd4f3af36p-4, -0x1.f78e379856222p-5, 0x1.5823c51edf1d7p-5, -0x1.5120894b3ce16p-6}},
-    {{0x1.39a92b820d4b0p+2, -0x1.91ca8eb994e41p-3, 0x1.7bb8664a14ab7p-4, -0x1.bd587c8ee1a37p-5, 0x1.bed56f7a17d39p-6, -0x1.ef80e529cb880p-8}},
-    {{0x1.39a71841850d8p+2, -0x1.8f3ef96987426p-3, 0x1.6773b9970b56ap-4, -0x1.6b6d53b2f83ccp-5, 0x1.16c48f501de7fp-6, -0x1.af25b3e426506p-9}},
-    {{0x1.39a0e3678f039p+2, -0x1.8a177146380b4p-3, 0x1.4be008788e788p-4, -0x1.212a9dad9add3p-5, 0x1.643dd65c8b576p-7, -0x1.a6f64e8ffe48bp-10}},
-    {{0x1.30d502480e701p+2, -0x1.9d1abbb9f8380p-3, 0x1.8cc733f3870e7p-4, -0x1.01cc7cdb4f1f7p-4, 0x1.60337aa96342ap-5, -0x1.58ef0fed41a22p-6}},
-    {{0x1.30d4c6abf3339p+2, -0x1.9c9674b8e50a9p-3, 0x1.8523ad5660c7fp-4, -0x1.c80c12d35b425p-5, 0x1.c966f404560d9p-6, -0x1.fb20eee0c54bdp-8}},
-    {{0x1.30d2a70909702p+2, -0x1.99fbb0794f297p-3, 0x1.706625607462cp-4, -0x1.7438a8f288e36p-5, 0x1.1d6cce870d044p-6, -0x1.b95fcb39acb88p-9}},
-    {{0x1.30cc4ccb8ba0fp+2, -0x1.94b51d2ea7f4ap-3, 0x1.542c686b16a5cp-4, -0x1.2836ec63e498fp-5, 0x1.6cd2e8631b911p-7, -0x1.b117296475aa1p-10}},
-    {{0x1.27c23faa6e3aep+2, -0x1.a8cfcfc31f088p-3, 0x1.9718f0e7b0e44p-4, -0x1.0842a153c20e2p-4, 0x1.68d6f6662f67dp-5, -0x1.614b0150fbb9cp-6}},
-    {{0x1.27c2029dc2f48p+2, -0x1.a8485763dbe95p-3, 0x1.8f46405beb774p-4, -0x1.d3890b1441db1p-5, 0x1.d4bc16c899116p-6, -0x1.03cb2d38e38a2p-7}},
-    {{0x1.27bfd5b6a75e1p+2, -0x1.a59d4f775eaf6p-3, 0x1.7a07434833b62p-4, -0x1.7daaa4ba56817p-5, 0x1.24917a37f8622p-6, -0x1.c457b174bd91cp-9}},
-    {{0x1.27b9536563205p+2, -0x1.a03575b7fca71p-3, 0x1.5d1b8b76e8db1p-4, -0x1.2fc9c31359dacp-5, 0x1.7609ce28da071p-7, -0x1.bbf5cd3d4eb8bp-10}},
-    {{0x1.1e6bc7e762f2dp+2, -0x1.b58c6c7ff7466p-3, 0x1.a23d5ceb0ecefp-4, -0x1.0f37aa3116dfbp-4, 0x1.722053e1faaa3p-5, -0x1.6a457b642f73dp-6}},
-    {{0x1.1e6b894ef2e3ap+2, -0x1.b5018676059f5p-3, 0x1.9a38087005d65p-4, -0x1.dfe8bfa129739p-5, 0x1.e0ed0c47b95adp-6, -0x1.0a7daa41139f4p-7}},
-    {{0x1.1e694e2652d78p+2, -0x1.b245046c38d80p-3, 0x1.846df060f3a89p-4, -0x1.87d867907a628p-5, 0x1.2c421e6f09986p-6, -0x1.d024f217dda55p-9}},
-    {{0x1.1e62a0bc62921p+2, -0x1.acb962aa77f00p-3, 0x1.66c2d71cf5dc3p-4, -0x1.37f44fad1fbe9p-5, 0x1.7ff6ee86b8e03p-7, -0x1.c7a9ff709ef33p-10}},
-    {{0x1.14cb7939300c4p+2, -0x1.c37903625ce85p-3, 0x1.ae51522c35df0p-4, -0x1.16bc45ab10e08p-4, 0x1.7c24e0d17a8c4p-5, -0x1.73f297c129c0ap-6}},
-    {{0x1.14cb38f656cd1p+2, -0x1.c2ea6bc4c76cdp-3, 0x1.a6156f816eb8fp-4, -0x1.ed492474c25a8p-5, 0x1.ee165961c15dfp-6, -0x1.11b754a1e747ap-7}},
-    {{0x1.14c8ee6e8a3b8p+2, -0x1.c01b1191d2eadp-3, 0x1.8fb55b9fe6eb6p-4, -0x1.92daee2b27aacp-5, 0x1.3491138b520e8p-6, -0x1.dce34d589cb2fp-9}},
-    {{0x1.14c2128363e50p+2, -0x1.ba68d38ff04fdp-3, 0x1.713bc047c81d1p-4, -0x1.40cae9811878cp-5, 0x1.8ab264c372736p-7, -0x1.d44fcef5bdbc6p-10}},
-    {{0x1.0ada39481eebap+2, -0x1.d2c73023187a8p-3, 0x1.bb775f4c4915ap-4, -0x1.1ee44b2c75cf5p-4, 0x1.86fddbe892b49p-5, -0x1.7e6a1b8c6c972p-6}},
-    {{0x1.0ad9f7382874bp+2, -0x1.d2349a0a53eeap-3, 0x1.b3007f8f17c60p-4, -0x1.fbcde1a8f141fp-5, 0x1.fc59d76ba8c28p-6, -0x1.198a6c54f3a18p-7}},
-    {{0x1.0ad79c0d409fcp+2, -0x1.cf50dac042ff3p-3, 0x1.9bfe1a343e81cp-4, -0x1.9ed0000c577d8p-5, 0x1.3d942893af14bp-6, -0x1.eab3b634522d2p-9}},
-    {{0x1.0ad08dc236972p+2, -0x1.c974ca37ed590p-3, 0x1.7ca4d01871434p-4, -0x1.4a65d60d9c7e5p-5, 0x1.9658e4166927dp-7, -0x1.e20899e873356p-10}},
-    {{0x1.008fbaeac432bp+2, -0x1.e3b48e146e8f4p-3, 0x1.c9d944bbc4c48p-4, -0x1.27c785da28c6bp-4, 0x1.92c96b64efa0cp-5, -0x1.89c85a0361b2ep-6}},
-    {{0x1.008f76e626796p+2, -0x1.e31da1e33de73p-3, 0x1.c1225b218fd37p-4, -0x1.05d0e14d08c79p-4, 0x1.05f00270413b6p-5, -0x1.220cbda03677fp-7}},
-    {{0x1.008d09a68b95dp+2, -0x1.e023b8a78d0c9p-3, 0x1.a96f91fb1149fp-4, -0x1.abdb661aca18bp-5, 0x1.4765802d746a5p-6, -0x1.f9bd9b7d22aa2p-9}},
-    {{0x1.0085c48fc5385p+2, -0x1.da1a2a2f1c407p-3, 0x1.8922fa44898cep-4, -0x1.54e249947f029p-5, 0x1.a30cdf5beabacp-7, -0x1.f0fc60ea8c7dbp-10}},
-    {{0x1.ebc46276b7335p+1, -0x1.f68eb1ddcba88p-3, 0x1.d9a9eda073442p-4, -0x1.3182be496a255p-4, 0x1.9fabdeca6f163p-5, -0x1.962f5b46c9b3bp-6}},
-    {{0x1.ebc3d6297c7bep+1, -0x1.f5f30b1bad300p-3, 0x1.d0ad2fd6b96acp-4, -0x1.0e7c4c07b30e4p-4, 0x1.0e6cdeda742fdp-5, -0x1.2b5889f00debap-7}},
-    {{0x1.ebbed42fd84eep+1, -0x1.f2e0efd047d73p-3, 0x1.b839d9c72899ap-4, -0x1.ba2883254f8b8p-5, 0x1.5224b2364b9d4p-6, -0x1.05184b2e30d58p-8}},
-    {{0x1.ebafd23ee6e3dp+1, -0x1.eca5aad77cef0p-3, 0x1.96e36324ef7e4p-4, -0x1.6063b91a2781fp-5, 0x1.b0f80d678adb1p-7, -0x1.00adc20fa18d6p-9}},
-    {{0x1.d58bd05df59dbp+1, -0x1.05dc6e93b219fp-2, 0x1.eb2812d5e616cp-4, -0x1.3c391ac5e39c8p-4, 0x1.add15725e3fb6p-5, -0x1.a3c85feb0981ep-6}},
-    {{0x1.d58b3f63fa645p+1, -0x1.058c03e4f67fep-2, 0x1.e1ded10af6055p-4, -0x1.1808dc0d6e8b8p-4, 0x1.17c140a017a8fp-5, -0x1.358dbae931193p-7}},
-    {{0x1.d58612198df87p+1, -0x1.03f5b057b2d15p-2, 0x1.c8983bff8006cp-4, -0x1.c9ec72d5a02f7p-5, 0x1.5df84b53a44e7p-6, -0x1.0e2351c0267a1p-8}},
-    {{0x1.d5768c9b8eae4p+1, -0x1.00bcc0813d62ep-2, 0x1.a61dbfbc1ce4ap-4, -0x1.6d159c5288953p-5, 0x1.c04d6c5913cb5p-7, -0x1.09b088623aea4p-9}},
-    {{0x1.be596d5cf4928p+1, -0x1.11da30851d0b6p-2, 0x1.fea1c8d5d0ec0p-4, -0x1.4815f72ea4b9fp-4, 0x1.bd6ffc6828cafp-5, -0x1.b2c5e3e39bbd1p-6}},
-    {{0x1.be58d73c452c5p+1, -0x1.1186eafef51b2p-2, 0x1.f5043ab0255c3p-4, -0x1.229dac0396585p-4, 0x1.2211bdac7b657p-5, -0x1.40d37ba1ff25dp-7}},
-    {{0x1.be537a2757880p+1, -0x1.0fe1f2a781574p-2, 0x1.dad4997b7524bp-4, -0x1.db68e2b43cd56p-5, 0x1.6b0fce45ab78ap-6, -0x1.18238dc68644dp-8}},
-    {{0x1.be4363568f590p+1, -0x1.0c8ad9fbca41cp-2, 0x1.b7178a7352f59p-4, -0x1.7b2dcaa24191fp-5, 0x1.d14bf49d54696p-7, -0x1.13aaeb4d57952p-9}},
-    {{0x1.a60a6e7475412p+1, -0x1.1f96a727f246bp-2, 0x1.0a3ca80cc14cep-3, -0x1.554f6307f57bcp-4, 0x1.cecaf672b10bap-5, -0x1.c36651bf79046p-6}},
-    {{0x1.a609d29de01e2p+1, -0x1.1f40377f65db7p-2, 0x1.053f296c15994p-3, -0x1.2e6b8abc6af72p-4, 0x1.2d8bce45cbb32p-5, -0x1.4d5a5f9472a8dp-7}},
-    {{0x1.a604407a72ff4p+1, -0x1.1d8afd91530afp-2, 0x1.ef4c00127b603p-4, -0x1.eeefee0bcd45dp-5, 0x1.79a669a9e5b55p-6, -0x1.23455aa7e6114p-8}},
-    {{0x1.a5f3881ab4798p+1, -0x1.1a125dd3d8671p-2, 0x1.ca285b8beb7a8p-4, -0x1.8aefaffdef59ap-5, 0x1.e442406ef1ec5p-7, -0x1.1eca49a134f96p-9}},
-    {{0x1.8c735024f2e0cp+1, -0x1.2f8727f3cf328p-2, 0x1.1695ca66bf3d9p-3, -0x1.642986d34cd78p-4, 0x1.e23676d7f8b8cp-5, -0x1.d5f7ab7a13c11p-6}},
-    {{0x1.8c72adeec0d22p+1, -0x1.2f2d303131d9bp-2, 0x1.11642aa88f0f2p-3, -0x1.3bb012b7a504fp-4, 0x1.3a68962346e54p-5, -0x1.5b5f4f28ebdf3p-7}},
-    {{0x1.8c6ce07ba99a9p+1, -0x1.2d65ca6382119p-2, 0x1.033a6df43cea0p-3, -0x1.0274b0f286de2p-4, 0x1.8a06a95781c9ap-6, -0x1.2fc07d554aa08p-8}},
-    {{0x1.8c5b7339d465fp+1, -0x1.29c7a14f35e09p-2, 0x1.dfbfc5fcfc334p-4, -0x1.9cb0ade62f3a8p-5, 0x1.f993883a41e09p-7, -0x1.2b47d0b1b43afp-9}},
-    {{0x1.715c7c16567bfp+1, -0x1.42507d01d3016p-2, 0x1.24ac61df41040p-3, -0x1.74fb48bedb4b9p-4, 0x1.f81d3e292a62fp-5, -0x1.eadc89d08b6bbp-6}},
-    {{0x1.715bd2b553423p+1, -0x1.41f28ca6acb42p-2, 0x1.1f4026933df94p-3, -0x1.4ab9e498af632p-4, 0x1.48f0b437404d3p-5, -0x1.6b2f878fdf37cp-7}},
-    {{0x1.7155c270eb5b3p+1, -0x1.4016ae9c6d158p-2, 0x1.1073909dc7d13p-3, -0x1.0eecf85edc4c3p-4, 0x1.9c8f84d8ffdbap-6, -0x1.3ddbe09cf0a4dp-8}},
-    {{0x1.7143890e3fc45p+1, -0x1.3c4e29cbd938ap-2, 0x1.f86d0db7df36ep-4, -0x1.b0de18814ec53p-5, 0x1.08df3b7c200e9p-6, -0x1.396c61236beb7p-9}},
-    {{0x1.547d1738f1e96p+1, -0x1.58e272f9795fdp-2, 0x1.34e769b72fc0fp-3, -0x1.88349fcd30139p-4, 0x1.0884156a4de26p-4, -0x1.01497ad08b873p-5}},
-    {{0x1.547c65b724e04p+1, -0x1.588001df5165cp-2, 0x1.2f38bc0f42577p-3, -0x1.5bee68b066e29p-4, 0x1.598179d114fa5p-5, -0x1.7d2e15b61ccc8p-7}},
-    {{0x1.547609857a6c7p+1, -0x1.568ce1aeb61a0p-2, 0x1.1fb3214c4e517p-3, -0x1.1d367e963a5ffp-4, 0x1.b1bb48ae89937p-6, -0x1.4df2b299f8c4ep-8}},
-    {{0x1.5462e7bb67715p+1, -0x1.529423b0a0029p-2, 0x1.0a743fbc7c744p-3, -0x1.c805576b0fbc8p-5, 0x1.16b33e25d56e6p-6, -0x1.4995e23644b5fp-9}},
-    {{0x1.357292e09f5b7p+1, -0x1.74a99db6a509ep-2, 0x1.47c9b60a12b51p-3, -0x1.9e670ea731380p-4, 0x1.16d43d90bfd04p-4, -0x1.0edee05239852p-5}},
-    {{0x1.3571d810db0f8p+1, -0x1.7442052e981bfp-2, 0x1.41cefdaa1e025p-3, -0x1.6fd182ad17913p-4, 0x1.6c93f84dcba51p-5, -0x1.91db49bbb3b67p-7}},
-    {{0x1.356b24c331db0p+1, -0x1.7234368552d26p-2, 0x1.3175282fa5f3ep-3, -0x1.2dc0d42c2787fp-4, 0x1.ca28e44306ac3p-6, -0x1.607b517a3404dp-8}},
-    {{0x1.3556f7c5dcbc1p+1, -0x1.6e0407c6be3cbp-2, 0x1.1b0ddc6b1ef31p-3, -0x1.e2deb0dd65f01p-5, 0x1.26b02443c4dc1p-6, -0x1.5c3e6ee97c9cbp-9}},
-    {{0x1.13b22a7622494p+1, -0x1.97efe3d04a1cdp-2, 0x1.5df05fd924be5p-3, -0x1.b850bb11a8b1ep-4, 0x1.2772a90a88a14p-4, -0x1.1e9883147697bp-5}},
-    {{0x1.13b164e354efbp+1, -0x1.978255698a22ap-2, 0x1.579dbb17dd256p-3, -0x1.870f9d230af3cp-4, 0x1.82c6359e32ea4p-5, -0x1.a9de934c7a3ffp-7}},
-    {{0x1.13aa4c96b6510p+1, -0x1.9555982a66973p-2, 0x1.464de258f1989p-3, -0x1.411de345a2465p-4, 0x1.e6a7e89063369p-6, -0x1.76105b236947fp-8}},
-    {{0x1.1394e916c55dfp+1, -0x1.90e4fd2ea5c93p-2, 0x1.2e8e2b74161f4p-3, -0x1.012d9f870a887p-4, 0x1.3960d6860ca96p-6, -0x1.72059db2ea4e8p-9}},
-    {{0x1.dcdbfed47d6d0p+0, -0x1.c6a9cd60b6c89p-2, 0x1.77f045721a1f7p-3, -0x1.d6ebd894f229dp-4, 0x1.3af610580db83p-4, -0x1.3101064838134p-5}},
-    {{0x1.dcda5a82a1c7ap+0, -0x1.c63546abbb3bdp-2, 0x1.7136d53471961p-3, -0x1.a28bbb83d09d8p-4, 0x1.9ce60674696cdp-5, -0x1.c612b8a72f8bcp-7}},
-    {{0x1.dccb3d131192fp+0, -0x1.c3e445c1b60b8p-2, 0x1.5ec6982dd84e9p-3, -0x1.580e06e8f305dp-4, 0x1.04231071351d8p-5, -0x1.8f7b9f9973f51p-8}},
-    {{0x1.dc9d9c2dff856p+0, -0x1.bf27f460e58b8p-2, 0x1.4572214c8d3ffp-3, -0x1.13dcb501feaa7p-4, 0x1.4f7961e84a1eep-6, -0x1.8bbb72bd11b43p-9}},
-    {{0x1.88bc1fadc1d1dp+0, -0x1.04322d101845fp-1, 0x1.959c18d1761e4p-3, -0x1.fb972d0d84299p-4, 0x1.521edd6cf8cfbp-4, -0x1.46ccba7400e5cp-5}},
-    {{0x1.88ba5d94cc7f6p+0, -0x1.03f3ca8219704p-1, 0x1.8e6919b66d316p-3, -0x1.c3867392d1d3fp-4, 0x1.bbf7bca210740p-5, -0x1.e7939a7019970p-7}},
-    {{0x1.88aa274b43f67p+0, -0x1.02b5ca1b2c46cp-1, 0x1.7aa2f198216f8p-3, -0x1.73a4e013ffe97p-4, 0x1.182a1164d0613p-5, -0x1.adc2fc15322cdp-8}},
-    {{0x1.887922eb0c3fep+0, -0x1.002aa41373486p-1, 0x1.5f6d7d2c91613p-3, -0x1.2a656fcb70361p-4, 0x1.69d682c1fdde6p-6, -0x1.aa6f1c69a5fd0p-9}},
-    {{0x1.267d4bf612409p+0, -0x1.36e66a695b88dp-1, 0x1.b23a75f8c9f8cp-3, -0x1.14ab2a56e3b4ap-3, 0x1.6db045c70243ep-4, -0x1.60ec374968867p-5}},
-    {{0x1.267b664c4648ap+0, -0x1.36a31ba63064ap-1, 0x1.aa764e224df42p-3, -0x1.ecddbfccc6256p-4, 0x1.e0e614bc6710bp-5, -0x1.07ff8ad8775cfp-6}},
-    {{0x1.2669e08420c49p+0, -0x1.354b6c3e2e00fp-1, 0x1.9517ae61898b4p-3, -0x1.968baf5849910p-4, 0x1.2fe75792349c0p-5, -0x1.d2b89dbe18dddp-8}},
-    {{0x1.2634d38077555p+0, -0x1.328ab5da09f17p-1, 0x1.77a578c2fe7f6p-3, -0x1.4746fa57b3105p-4, 0x1.890223f97e316p-6, -0x1.d0c8b8cd2c01dp-9}},
-    {{0x1.5956b84f073e7p-1, -0x1.92cc4e91aff80p-1, 0x1.ab59fa2fcf973p-3, -0x1.3b3bd220e7704p-3, 0x1.8937eee82009dp-4, -0x1.844145a20f41dp-5}},
-    {{0x1.5952a76a2d221p-1, -0x1.92841ea5f28fbp-1, 0x1.a30389d55d5b0p-3, -0x1.1abc4ae46ba6bp-3, 0x1.0270d6ec0079fp-4, -0x1.2c74d7ec6925fp-6}},
-    {{0x1.592ee34ead63fp-1, -0x1.912437023f679p-1, 0x1.8d0f1d2101bb3p-3, -0x1.dc7c0cd26dadcp-4, 0x1.4dcf9502fc6a9p-5, -0x1.27313253e40f7p-7}},
-    {{0x1.58da7fade0131p-1, -0x1.8eec6703bde81p-1, 0x1.7506af3887551p-3, -0x1.9af78b95237c4p-4, 0x1.e7e5ff36ae1c7p-6, -0x1.8801800bb2926p-8}},
+    {{0x1.95a1194d4d6d3p+2, -0x1.3b9b4c25fb156p-3, 0x1.3368aac04ead2p-4, -0x1.867b02d30c867p-5, 0x1.d253900d225bfp-6, -0x1.4b2805f73d8e9p-7}},
+    {{0x1.959dad4d74622p+2, -0x1.37a742beff387p-3, 0x1.1493d85521b8ap-4, -0x1.062ab62b937d1p-5, 0x1.6906ac6fba8e7p-7, -0x1.e5b848eb35130p-10}},
+    {{0x1.8ebc94c10e998p+2, -0x1.40d048fbe0de4p-3, 0x1.383d3b76ff2d4p-4, -0x1.8c7c106522c03p-5, 0x1.d969c61a0a9cep-6, -0x1.5028a621e6d0fp-7}},
+    {{0x1.8eb91b7e3baaap+2, -0x1.3cccf08a6f25cp-3, 0x1.18f1248186ef9p-4, -0x1.0a3c016600325p-5, 0x1.6e9557dce92d6p-7, -0x1.ed2a8d3954477p-10}},
+    {{0x1.87ba784e37994p+2, -0x1.46487e5bcd01ep-3, 0x1.3d4cf9d533f46p-4, -0x1.92c50a0c323aap-5, 0x1.e0d3db2b42d39p-6, -0x1.55641d1c23cc4p-7}},
+    {{0x1.87b6f12c19cfcp+2, -0x1.4235229320c7fp-3, 0x1.1d84232009183p-4, -0x1.0e7e7737f4138p-5, 0x1.7466a3aaeb832p-7, -0x1.f4f5b8237c502p-10}},
+    {{0x1.80993f6ce224ap+2, -0x1.4c09b7fdae55fp-3, 0x1.429cb7f426e93p-4, -0x1.995ba8cf23060p-5, 0x1.e8986668e76f6p-6, -0x1.5adf02fc683b5p-7}},
+    {{0x1.8095a9c2ed885p+2, -0x1.47e5967893047p-3, 0x1.225138b4939dbp-4, -0x1.12f60a49a8267p-5, 0x1.7a7fddcd72fd3p-7, -0x1.fd20d5c0df71bp-10}},
+    {{0x1.7957437ee7b56p+2, -0x1.521a79f7b6ab9p-3, 0x1.4831d80a9d70cp-4, -0x1.a0464ca22ca09p-5, 0x1.f0bebcbbf07fdp-6, -0x1.609e73409fe04p-7}},
+    {{0x1.79539e96f6c20p+2, -0x1.4de4c0a4decafp-3, 0x1.275d4da1cbbcep-4, -0x1.17a7217b22e11p-5, 0x1.80e6eefe3e557p-7, -0x1.02d9df6ddc42fp-9}},
+    {{0x1.71f2b77fd133bp+2, -0x1.58821f24173b0p-3, 0x1.4e12629cf66dfp-4, -0x1.a78c1572ba8cep-5, 0x1.f94f0ce528a9bp-6, -0x1.66a8202010165p-7}},
+    {{0x1.71ef029492a9bp+2, -0x1.5439ea7708b63p-3, 0x1.2cade28c30881p-4, -0x1.1c96a97dd50b1p-5, 0x1.87a271f624107p-7, -0x1.075b9bc1b82d0p-9}},
+    {{0x1.6a69a2fb4d174p+2, -0x1.5f48fddc5821dp-3, 0x1.544520f5fd32ep-4, -0x1.af3500e87fdfap-5, 0x1.012940647d431p-5, -0x1.6d02696b7fe42p-7}},
+    {{0x1.6a65dd3674a24p+2, -0x1.5aed56b7fb312p-3, 0x1.324928b12af59p-4, -0x1.21ca29c503a8ep-5, 0x1.8eb9cf032c45bp-7, -0x1.0c1a89ab18806p-9}},
+    {{0x1.62b9dc22c267cp+2, -0x1.667894a80fec5p-3, 0x1.5ad1bce95e008p-4, -0x1.b74a0dee29f1ep-5, 0x1.05e9b28d9d6abp-5, -0x1.73b477c67b10cp-7}},
+    {{0x1.62b6049af0753p+2, -0x1.62086df57cfc7p-3, 0x1.38361f200405ep-4, -0x1.2747dd917899bp-5, 0x1.96355cf9ec2e6p-7, -0x1.111c3066a1ce1p-9}},
+    {{0x1.5ae100d053933p+2, -0x1.6e1bc0fb3357cp-3, 0x1.61c0e727cb74ap-4, -0x1.bfd5675e06793p-5, 0x1.0aeeac72b8a6cp-5, -0x1.7ac65d39ecf5fp-7}},
+    {{0x1.5add1686a6023p+2, -0x1.6995f4dc46663p-3, 0x1.3e7cb604f0016p-4, -0x1.2d16d21258439p-5, 0x1.9e1e88c4b4a75p-7, -0x1.1666ce982055bp-9}},
+    {{0x1.52dc6e382c531p+2, -0x1.763f02cc347dep-3, 0x1.691c85caff800p-4, -0x1.c8e2978fe987fp-5, 0x1.103ec364f3a8fp-5, -0x1.82413c6606c4fp-7}},
+    {{0x1.52d87015663d4p+2, -0x1.71a24f557f6dap-3, 0x1.4525f98dfa5c9p-4, -0x1.333f0adb33cb1p-5, 0x1.a680052cd6b68p-7, -0x1.1c0179a3a4f2ep-9}},
+    {{0x1.4aa936f71bba5p+2, -0x1.7ef0d0b6ce5bep-3, 0x1.70efed3d2fa63p-4, -0x1.d27ec705e6d2bp-5, 0x1.15e17537434b7p-5, -0x1.8a2f77f519d4fp-7}},
+    {{0x1.4aa523c84e323p+2, -0x1.7a3bd4177bcbep-3, 0x1.4c3c46667ff56p-4, -0x1.39c9ae4c8a9c0p-5, 0x1.af6604f0dd4bdp-7, -0x1.21f443befaa2ap-9}},
+    {{0x1.424417158f237p+2, -0x1.884201aa00abap-3, 0x1.794826482c345p-4, -0x1.dcb909208dbc3p-5, 0x1.1bdf529823e5ep-5, -0x1.929cec6aab3d3p-7}},
+    {{0x1.423fed88271b7p+2, -0x1.837335a1b97e2p-3, 0x1.53cb8a633150bp-4, -0x1.40c13c086b76fp-5, 0x1.b8de81d8c26a0p-7, -0x1.28486a7a71080p-9}},
+    {{0x1.39a96575920e7p+2, -0x1.924652f123f48p-3, 0x1.823444fd1f4e7p-4, -0x1.e7a2baa9927c2p-5, 0x1.22423319b7f9fp-5, -0x1.9b97370ca74edp-7}},
+    {{0x1.39a52412a83e1p+2, -0x1.8d5c076b9442ep-3, 0x1.5be194ce2de79p-4, -0x1.4831d034ced45p-5, 0x1.c2f9944dd9e73p-7, -0x1.2f0890092c2d7p-9}},
+    {{0x1.30d501f5e8f5fp+2, -0x1.9d1514029bc81p-3, 0x1.8bc5d55f042d1p-4, -0x1.f34ff73c5e791p-5, 0x1.2915759703362p-5, -0x1.a52e0d7fff132p-7}},
+    {{0x1.30d0a71ca6e23p+2, -0x1.980d68a51911cp-3, 0x1.648e7ae77e67cp-4, -0x1.50297731ccf11p-5, 0x1.cdc9e01cce51cp-7, -0x1.3641024b129cep-9}},
+    {{0x1.27c23f564fd6ep+2, -0x1.a8ca0548b8309p-3, 0x1.9611646a96434p-4, -0x1.ffd82c40422e6p-5, 0x1.306650857cb3dp-5, -0x1.af73aadc9cc5ep-7}},
+    {{0x1.27bdc93530526p+2, -0x1.a3a2e1afd5436p-3, 0x1.6de516c30bc61p-4, -0x1.58b896a3be685p-5, 0x1.d9651c9353d87p-7, -0x1.3e001398aaf2ep-9}},
+    {{0x1.1e6bc79126983p+2, -0x1.b5867cb57a86ap-3, 0x1.a12f2e71b18a6p-4, -0x1.06ab693c2115bp-4, 0x1.384436f757960p-5, -0x1.ba7d5896e351ap-7}},
+    {{0x1.1e67341dc6e89p+2, -0x1.b03d870cacd03p-3, 0x1.77fba8e236a7dp-4, -0x1.61f2726497a44p-5, 0x1.e5e4c04d98d91p-7, -0x1.46568ab019d18p-9}},
+    {{0x1.14cb78e0ac079p+2, -0x1.c372eb68c0c51p-3, 0x1.ad3bff1052097p-4, -0x1.0df62d338f42fp-4, 0x1.40c158c0845dfp-5, -0x1.c6641bd5dd073p-7}},
+    {{0x1.14c6c5cdcbbb3p+2, -0x1.be057cebb3e65p-3, 0x1.82eca8026eea2p-4, -0x1.6bedd650dc2d4p-5, 0x1.f366dc01cc619p-7, -0x1.4f58310b403adp-9}},
+    {{0x1.0ada38ed240b6p+2, -0x1.d2c0ecba8301cp-3, 0x1.ba5a53b2a9649p-4, -0x1.15dfae292626fp-4, 0x1.49f3468b03aa7p-5, -0x1.d34592e983b93p-7}},
+    {{0x1.0ad5639e5200ep+2, -0x1.cd2c038b93964p-3, 0x1.8ed7cf015261cp-4, -0x1.76c5f140375f2p-5, 0x1.010799e49ed5ap-6, -0x1.591c899627b85p-9}},
+    {{0x1.008fba8d1cbcbp+2, -0x1.e3ae1b89d8feep-3, 0x1.c8b3d850f06d8p-4, -0x1.1e7f11918124bp-4, 0x1.53f3c5fb98407p-5, -0x1.e14512f8dbe1fp-7}},
+    {{0x1.008ac007647a3p+2, -0x1.ddee491777e89p-3, 0x1.9be37efb5f41ep-4, -0x1.829b72408f6eap-5, 0x1.0904562cea7d0p-6, -0x1.63bfbd8b21d83p-9}},
+    {{0x1.ebc461b593fbdp+1, -0x1.f6880bf40dfebp-3, 0x1.d87b5f845e5a8p-4, -0x1.27f0594e53b38p-4, 0x1.5ee1e6c6d3938p-5, -0x1.f08d1c3f9e524p-7}},
+    {{0x1.ebba1b62f05f7p+1, -0x1.f0995ee1c25b3p-3, 0x1.aa3e94b41810cp-4, -0x1.8f95ffff5a1afp-5, 0x1.11c3951199a6ap-6, -0x1.6f63d2a8f9fb4p-9}},
+    {{0x1.d58bcf967004ep+1, -0x1.05d8ff7d1d07cp-2, 0x1.e9ef847580cb7p-4, -0x1.3255bb4a72668p-4, 0x1.6ae37062fd8a2p-5, -0x1.00a8a212ea758p-6}},
+    {{0x1.d581300ef10acp+1, -0x1.02c7f3909fdb8p-2, 0x1.ba22dcde055ccp-4, -0x1.9de62c16f1019p-5, 0x1.1b65063a586d8p-6, -0x1.7c3245c2a9f83p-9}},
+    {{0x1.be596c8e675b6p+1, -0x1.11d6a274a5552p-2, 0x1.fd5e375938362p-4, -0x1.3dd96ddadeb27p-4, 0x1.7826c9c3802e7p-5, -0x1.09e860a9d29bep-6}},
+    {{0x1.be4e6a91a8bbbp+1, -0x1.0ea937be2affcp-2, 0x1.cbd863dbd76c0p-4, -0x1.adc811e9832acp-5, 0x1.260fc02463752p-6, -0x1.8a5e2fd549991p-9}},
+    {{0x1.a60a6d9e1e9f1p+1, -0x1.1f92f6c78bb83p-2, 0x1.0994c5f5bcdd6p-3, -0x1.4ab0166edb355p-4, 0x1.86e58a6ef90fep-5, -0x1.142cec2078a0bp-6}},
+    {{0x1.a5fefe481404dp+1, -0x1.1c460b55bc836p-2, 0x1.dfb9f2979fc0bp-4, -0x1.bf86e438bdd85p-5, 0x1.31f47f87253a1p-6, -0x1.9a272bb502093p-9}},
+    {{0x1.8c734f45ed6aep+1, -0x1.2f8351507b92fp-2, 0x1.15e71b484472cp-3, -0x1.591c1a198becep-4, 0x1.9767f7a1bca49p-5, -0x1.1fa7404d2f614p-6}},
+    {{0x1.8c6765a4ec183p+1, -0x1.2c132c42fbb31p-2, 0x1.f63b1cdcfcd56p-4, -0x1.d381c6c0f8e3dp-5, 0x1.3f50b7de8d150p-6, -0x1.abdd4867dde74p-9}},
+    {{0x1.715c7b2d8fe33p+1, -0x1.424c7b62b1066p-2, 0x1.23f60ee003d30p-3, -0x1.697225e1150c0p-4, 0x1.aa09c9d4f4d8dp-5, -0x1.2c955f64e6832p-6}},
+    {{0x1.715007b61aed8p+1, -0x1.3eb4a4b670395p-2, 0x1.07f81dabf0ee7p-3, -0x1.ea3270681aed5p-5, 0x1.4e72c5e20aef4p-6, -0x1.bfe670f45194bp-9}},
+    {{0x1.547d16451e9cep+1, -0x1.58de40a94c3cap-2, 0x1.34286f25850a4p-3, -0x1.7c1f5b01744bep-4, 0x1.bf40b4c3ca2bap-5, -0x1.3b46abe25deadp-6}},
+    {{0x1.54700616c0ebbp+1, -0x1.55194b917e87dp-2, 0x1.16cc101e8cbf8p-3, -0x1.021b172d281bdp-4, 0x1.5fbfab2290763p-6, -0x1.d6c5d23163d18p-9}},
+    {{0x1.357291e029f9bp+1, -0x1.74a533bad91b3p-2, 0x1.4700d664160d5p-3, -0x1.91b194863cca1p-4, 0x1.d7a541b945a08p-5, -0x1.4c21d62b192ebp-6}},
+    {{0x1.3564cdca55b52p+1, -0x1.70ac76a3e7bfep-2, 0x1.28126ec9f9c02p-3, -0x1.112cf1719f11ep-4, 0x1.73bac15dc1178p-6, -0x1.f125d943a3c36p-9}},
+    {{0x1.13b2296715684p+1, -0x1.97eb398704eeep-2, 0x1.5d1c1265a4ad2p-3, -0x1.aae236fe37390p-4, 0x1.f3fe6f6d5bcc4p-5, -0x1.5facc10b34fccp-6}},
+    {{0x1.13a39498da50fp+1, -0x1.93b66dabaf268p-2, 0x1.3c5b8d62aadf3p-3, -0x1.22d4c8d12ebcdp-4, 0x1.8b0f984e39747p-6, -0x1.07f29a9b40f2fp-8}},
+    {{0x1.dcdbfc944eb1bp+0, -0x1.c6a4d7fea2c1ep-2, 0x1.770e9f1d8804ap-3, -0x1.c8a53e526e5dbp-4, 0x1.0aa7d3d63be5cp-4, -0x1.76966b71decdbp-6}},
+    {{0x1.dcbce92e8107ep+0, -0x1.c2299a529a5c1p-2, 0x1.542b973bf5a1dp-3, -0x1.37c3673ffa78dp-4, 0x1.a69ce98b86539p-6, -0x1.1a1330397f3fbp-8}},
+    {{0x1.88bc1d4550e15p+0, -0x1.042f860463847p-1, 0x1.94aaae5ff6d37p-3, -0x1.ec51565855da4p-4, 0x1.1e717cabce953p-4, -0x1.91c22ac040d24p-6}},
+    {{0x1.889ac4b10ee8ap+0, -0x1.01c81ed5652bdp-1, 0x1.6f3f98ab31055p-3, -0x1.50f850198b03ep-4, 0x1.c77677342785bp-6, -0x1.2fb16e78af501p-8}},
+    {{0x1.267d495d95f38p+0, -0x1.36e38e6ee5102p-1, 0x1.b1363adbbcadap-3, -0x1.0c6ff3b3cc2bcp-3, 0x1.35fce63729b18p-4, -0x1.b2691cbd1137bp-6}},
+    {{0x1.26593b1e882cep+0, -0x1.344a46c85258bp-1, 0x1.88c56f267cd2ep-3, -0x1.7107c8f2e2784p-4, 0x1.ee597db6d5e13p-6, -0x1.4a5310aa0a7a7p-8}},
+    {{0x1.5956b2b4fa470p-1, -0x1.92c938bdc840dp-1, 0x1.aa41293f2adcdp-3, -0x1.325999fb241f0p-3, 0x1.4d178625abeeap-4, -0x1.e3716ab3b4d4cp-6}},
+    {{0x1.5910e54d44bd7p-1, -0x1.903c4310c32f9p-1, 0x1.81ede58f6400ep-3, -0x1.ba8b879322b83p-4, 0x1.1a67394d0a4a5p-5, -0x1.d28f57304e568p-8}},
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 static __shared__ __attribute__((aligned(16))) phf_normtab phf_lds_normal[PHF_NORMAL_TAB_N];
@@ -783,7 +907,7 @@ static __shared__ __attribute__((aligned(16))) phf_normtab phf_lds_normal[PHF_NO
 PHF_HD double phf_normal_u32(uint32_t v) {
   const uint64_t ab = phf_bits((double)((v << 1) | 1u));             /* a = 2 w + 1 in [1, 2^32): exact */
   const uint32_t hi = (uint32_t)(ab >> 32);
-  const int j = (int)(hi >> 18) - (0x3ff << 2);                       /* 4 E + the top two mantissa bits: 0..127 */
+  const int j = (int)(hi >> 19) - (0x3ff << 1);                       /* 2 E + the top mantissa bit: 0..63 */
   const double sft = phf_from_bits((ab & 0x000fffffffffffffull) | 0x3ff0000000000000ull) - 1.0;   /* m - 1 in [0, 1) */
   const phf_normtab e = PHF_T_NORMAL(j);
   double z = phf_fma(e.c[5], sft, e.c[4]);
@@ -791,7 +915,8 @@ PHF_HD double phf_normal_u32(uint32_t v) {
   z = phf_fma(z, sft, e.c[2]);
   z = phf_fma(z, sft, e.c[1]);
   z = phf_fma(z, sft, e.c[0]);
-  return phf_from_bits(phf_bits(z) | ((uint64_t)(v & 0x80000000u) << 32));   /* z > 0: the sign bit comes from v */
+  /* |P| with the sign bit of v (one v_bfi_b32): exactly symmetric even where the polynomial's error crosses zero (p -> 1/2) */
+  return phf_from_bits((phf_bits(z) & 0x7fffffffffffffffull) | ((uint64_t)(v & 0x80000000u) << 32));
 }
 
 /* 53-bit uniform on [0,1) from two words — numpy's random_sample() construction

@@ -57,11 +57,8 @@ PHF_HD double phf_censored_z(double pred, double y, double inv_s) {
  * sample of every rung; it falls out of the same arithmetic here, so the samplers carry it along for free.      */
 PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, const double* w, int n_other, int n_cens,
                               double n_other_points, double ss_within, double pi_bit, double temperature,
-                              const double* th, phf_ktab k_exp, phf_ktab k_log, phf_ktab k_erfcx_resident, int erfcx_resident,
+                              const double* th, phf_ktab k_exp, phf_ktab k_log,
                               double* out_lik, double* out_prior, double* out_ll1) {
-  /* erfcx_resident != 0: k_erfcx_resident holds the 24 erfcx coefficients in VGPRs (kernels that own the whole register
-   * file keep them there for the launch); 0: fetched through the scalar cache at each use (48 SGPRs, only while needed).
-   * A literal at every call site, so that the choice is made at compile time. */
   const double pic50 = th[0];
   const double hill = (model == 1) ? 1.0 : th[1];
   const double sigma = (model == 1) ? th[1] : th[2];
@@ -108,21 +105,21 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
   }
   j = n_other;
   const int n = n_other + n_cens;
-  for (; j + 2 <= n; j += 2) {                    /* censored entries, two at a time (:244-245) */
-    PHF_KFETCH_UNLESS(k_erfcx, erfcx_resident, k_erfcx_resident, phf_k_erfcx, 24);   /* issued now, needed after the two exponentials */
+  /* censored entries (:244-245): log Phi(z), z <= 0, from the table of phf_math.h — it covers every z a likelihood that is not
+   * -inf anyway (sigma above its floor, below) can produce */
+  for (; j + 2 <= n; j += 2) {                    /* two at a time: one division for the two Hill curves */
     const phf_ktab ke = k_exp;
     const double d0 = phf_hill_den(model, lc[j], hill, ln_ic50, ke), d1 = phf_hill_den(model, lc[j + 1], hill, ln_ic50, ke);
     const double inv = phf_rcp(d0 * d1);
     const double z0 = phf_censored_z(PHF_PCT_(inv * d1), y[j], inv_s);
     const double z1 = phf_censored_z(PHF_PCT_(inv * d0), y[j + 1], inv_s);
-    double l0, l1;
-    phf_log_ndtr_nonpos_x2_kx(z0, z1, &l0, &l1, k_erfcx, erfcx_resident, k_log);
-    cens = phf_fma(w[j], l0, cens); cens = phf_fma(w[j + 1], l1, cens);
+    cens = phf_fma(w[j], phf_log_ndtr_tab(z0, -z0 * PHF_INV_SQRT2), cens);
+    cens = phf_fma(w[j + 1], phf_log_ndtr_tab(z1, -z1 * PHF_INV_SQRT2), cens);
   }
   for (; j < n; ++j) {
-    PHF_KFETCH_UNLESS(k_erfcx, erfcx_resident, k_erfcx_resident, phf_k_erfcx, 24);
     const double pred = PHF_PCT_(phf_rcp(phf_hill_den(model, lc[j], hill, ln_ic50, k_exp)));
-    cens = phf_fma(w[j], phf_log_ndtr_nonpos_kx(phf_censored_z(pred, y[j], inv_s), k_erfcx, erfcx_resident, k_log), cens);
+    const double z = phf_censored_z(pred, y[j], inv_s);
+    cens = phf_fma(w[j], phf_log_ndtr_tab(z, -z * PHF_INV_SQRT2), cens);
   }
   double a = cens - pi_bit;
   a = phf_fma(-n_other_points, log_sigma, a);                            /* :246 */

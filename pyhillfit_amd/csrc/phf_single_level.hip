@@ -83,7 +83,7 @@ __device__ __forceinline__ void stage_points(const phf_points& pts, int pair, do
 // KO / KC >= 0: the pair's numbers of uncensored / censored entries are these compile-time constants (the point loops of
 // phf_sl_log_target fold away and an iteration is straight-line code the scheduler can interleave: measured 17 % faster
 // on Amiodarone-hERG); -1: read from the data at run time.  Either way the same operations in the same order.
-template <int MODEL, bool MOMENTS, int KO, int KC, bool ERFCX_IN_VGPRS>
+template <int MODEL, bool MOMENTS, int KO, int KC, bool LONE_WAVE>
 __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double* s_pts, int q, int c, int pair,
                                              int n_other_rt, int n_cens_rt, const int64_t t_begin, const int64_t t_end) {
   constexpr int D = Dim<MODEL>::d;
@@ -105,7 +105,7 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   // round); as vector values they cost registers the scratch spills outside the loop absorb (sgpr_spill_count 236 -> 195,
   // vgpr_spill_count 96 -> 145): C3 159.1 -> 158.0 ms per 8 000 iterations on one box, twice.  The lone-wavefront build keeps
   // them scalar (round 2: scalar work is free there, vector issue slots are not).
-  if (!ERFCX_IN_VGPRS) { asm volatile("" : "+v"(seed_lo)); asm volatile("" : "+v"(seed_hi)); }
+  if (!LONE_WAVE) { asm volatile("" : "+v"(seed_lo)); asm volatile("" : "+v"(seed_hi)); }
   const size_t nchains = (size_t)a.prob.num_problems * C;
   const size_t g = (size_t)q * C + c;
 
@@ -125,13 +125,6 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   // exp and log coefficients: in VGPRs for the whole launch (8 doubles)
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
-  // the 24 erfcx coefficients too when this wavefront owns the whole register file (no scalar-cache refetch per use)
-  double k_erfcx_buf[ERFCX_IN_VGPRS ? 24 : 1];
-  if (ERFCX_IN_VGPRS) {
-#pragma unroll
-    for (int i = 0; i < 24; ++i) { k_erfcx_buf[i] = phf_k_erfcx[i]; asm volatile("" : "+v"(k_erfcx_buf[i])); }
-  }
-  const phf_ktab k_erfcx = ERFCX_IN_VGPRS ? k_erfcx_buf : nullptr;
   chol_packed<D>(cov, L);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
 
@@ -174,7 +167,7 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
     }
     // ---- target and accept test (PyHillFit.py:833-838) ----
     double lik_star, prior_star, ll1_star;
-    phf_sl_log_target(MODEL, lc, yv, wv, n_other, n_cens, n_other_points, ss_within, pi_bit, temperature, star, k_exp, k_log, k_erfcx, ERFCX_IN_VGPRS ? 1 : 0, &lik_star, &prior_star, &ll1_star);
+    phf_sl_log_target(MODEL, lc, yv, wv, n_other, n_cens, n_other_points, ss_within, pi_bit, temperature, star, k_exp, k_log, &lik_star, &prior_star, &ll1_star);
     const double lt_star = lik_star + prior_star;
     const bool acc = log_u < lt_star - lt;
     if (acc) {
@@ -299,6 +292,7 @@ template <int MODEL, bool MOMENTS, int WPS>
 __global__ __launch_bounds__(kBlock, WPS) void mh_advance_kernel(const AdvanceArgs a) {
   PHF_MATH_TABLES_TO_LDS();
   PHF_NORMAL_TABLE_TO_LDS();
+  PHF_LOGPHI_TABLE_TO_LDS();
   extern __shared__ double s_pts[];
   const bool queued = a.queue != nullptr;                         // wave-uniform; ONE call site of run_block serves both kinds of launch
   const int nblocks = a.blocks_per_problem * a.prob.num_problems;
@@ -359,6 +353,7 @@ struct InitArgs {
 template <int MODEL>
 __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_LOGPHI_TABLE_TO_LDS();
   constexpr int D = Dim<MODEL>::d;
   constexpr int NTRI = D * (D + 1) / 2;
   extern __shared__ double s_pts[];
@@ -380,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void mh_init_kernel(const InitArgs a) {
   PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   phf_sl_log_target(MODEL, s_pts, s_pts + a.pts.stride, s_pts + 2 * a.pts.stride, n_other, n_zero + n_hundred,
                     a.pts.extra[2 * pair], a.pts.extra[2 * pair + 1], a.pts.pi_bit[pair], a.prob.temperature[q],
-                    th, k_exp, k_log, nullptr, 0, &lik0, &prior0, &ll10);
+                    th, k_exp, k_log, &lik0, &prior0, &ll10);
   const double lt = lik0 + prior0;
   double* sp = a.state + g;
 #pragma unroll
@@ -408,6 +403,7 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
                                                           const double* temperature, const double* theta,
                                                           double* out_lik, double* out_prior) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_LOGPHI_TABLE_TO_LDS();
   constexpr int D = Dim<MODEL>::d;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
@@ -421,13 +417,14 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
   PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
   phf_sl_log_target(MODEL, pts.ln_conc + (size_t)pair * pts.stride, pts.response + (size_t)pair * pts.stride,
                     pts.weight + (size_t)pair * pts.stride, cnt[0], cnt[1] + cnt[2], pts.extra[2 * pair], pts.extra[2 * pair + 1],
-                    pts.pi_bit[pair], temperature[i], th, k_exp, k_log, nullptr, 0, &lik, &prior, &ll1);
+                    pts.pi_bit[pair], temperature[i], th, k_exp, k_log, &lik, &prior, &ll1);
   if (out_lik) out_lik[i] = lik;
   if (out_prior) out_prior[i] = prior;
 }
 
 __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* out) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_LOGPHI_TABLE_TO_LDS();
   PHF_NORMAL_TABLE_TO_LDS();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -451,6 +448,7 @@ __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* o
     case 15: r = phf_sqrt_nonneg(x); break;
     case 16: r = phf_div(x, PHF_LN10); break;
     case 17: r = phf_normal_u32((uint32_t)x); break;
+    case 18: r = phf_log_ndtr_tab(x, -x * PHF_INV_SQRT2); break;
     default: phf_sincos_2pi_u32((uint32_t)x, &s, &c); r = c; break;
   }
   out[i] = r;
@@ -585,7 +583,7 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
 }
 
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream) {
-  if (fn < 0 || fn > 17 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
+  if (fn < 0 || fn > 18 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
   if (n == 0) return PHF_OK;
   hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, n, in, out);
   return phf_check_launch("phf_debug_math");

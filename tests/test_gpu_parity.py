@@ -52,6 +52,7 @@ def test_device_math_bit_identical_to_host_build(gpu):
         9: ("exp_fast", np.concatenate([rng.uniform(-760, 720, n), rng.uniform(-3, 3, n), [np.nan, np.inf, -np.inf]])),
         10: ("log_fast", np.concatenate([np.exp(rng.uniform(-708, 709, n)), rng.uniform(-1, 2, n), [0.0, 1e-310]])),
         11: ("log_ndtr_nonpos", np.concatenate([-np.exp(rng.uniform(-30, 11.6, n)), rng.uniform(-40, 0, n), [0.0, -1e5]])),
+        18: ("log_ndtr_tab", np.concatenate([-np.exp(rng.uniform(-30, 12.1, n)), rng.uniform(-40, 0, n), [0.0, -0.0, -1e5, -1.85e5, -2e5, 3.0, 1e5, np.nan, np.inf]])),
     }
     for fn, (name, x) in cases.items():
         got, want = debug_math(fn, x, gpu), co.vec(name, x)

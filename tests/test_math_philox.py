@@ -54,6 +54,10 @@ def test_erfcx_and_normal_cdf():
     # log Phi on the branch the censored likelihood uses (x <= 0), down to -1e5 (sigma = 1e-3)
     x = np.concatenate([-np.exp(RNG.uniform(-20, 11.6, 100000)), RNG.uniform(-40, 0, 100000), [0.0, -1e5]])
     assert np.max(np.abs(co.vec("log_ndtr", x) / sp.log_ndtr(x) - 1)) < 6e-15
+    # the table form the single-level censored likelihood uses (y = -x/sqrt2 < 131 071) against the erfcx form and scipy
+    x = np.concatenate([-np.exp(RNG.uniform(-20, 12.1, 100000)), RNG.uniform(-40, 0, 100000), [0.0, -1e5, -1.85e5]])
+    assert np.max(np.abs(co.vec("log_ndtr_tab", x) / co.vec("log_ndtr", x) - 1)) < 2e-15
+    assert np.max(np.abs(co.vec("log_ndtr_tab", x) / sp.log_ndtr(x) - 1)) < 6e-15
     x = RNG.uniform(0, 38, 50000)
     assert np.max(np.abs(co.vec("log_ndtr", x) - sp.log_ndtr(x))) < 4e-15
     x = RNG.uniform(-38, 10, 100000)
@@ -96,9 +100,9 @@ def test_normal_from_a_word_is_the_inverse_cdf():
                         [0, 1, 2, 3, 2 ** 31 - 1]]).astype(np.uint32)
     z = co.normal_u32(w)
     want = stats.norm.ppf((w.astype(np.float64) + 0.5) / 2.0 ** 32)          # low half: negative quantiles ...
-    assert np.max(np.abs(-z - want)) < 1e-8                                   # ... the table holds |z|; word w (top bit clear) is +|z|
+    assert np.max(np.abs(-z - want)) < 3e-7                                   # ... the table holds |z|; word w (top bit clear) is +|z|
     assert np.array_equal(co.normal_u32(w | np.uint32(0x80000000)), -z)        # the top bit is the sign: exactly symmetric
-    assert z.max() < 6.34 and z.min() >= 0 and np.all(np.diff(z[:40000]) <= 1e-8)   # |z| falls as w rises
+    assert z.max() < 6.34 and z.min() >= 0 and np.all(np.diff(z[:40000]) <= 1e-6)   # |z| falls as w rises
 
 
 def test_draw_distributions():

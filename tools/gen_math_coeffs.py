@@ -150,26 +150,56 @@ def gen_sincos():
 
 def gen_normal():
     """Standard normal from 32 random bits by a piecewise inverse CDF: w = the low 31 bits, p = (w + 1/2) / 2^32 in (0, 1/2),
-    |z| = -Phi^-1(p), sign = the top bit.  a = 2 w + 1 = 2^E m (E = 0..31, m in [1, 2)); interval 4 E + k, k = floor(4 (m - 1));
-    on it |z| = P(s), s = m - 1, degree 5, coefficients of s^0..s^5 (monomials about s = 0: the loss to cancellation is ~4
-    digits of 16).  128 x 6 doubles."""
+    |z| = -Phi^-1(p), sign = the top bit.  a = 2 w + 1 = 2^E m (E = 0..31, m in [1, 2)); interval 2 E + k, k = floor(2 (m - 1));
+    on it |z| = P(s), s = m - 1, degree 5, coefficients of s^0..s^5 (monomials about s = 0).  64 x 6 doubles."""
     def z_of(E, s):
         p = mp.mpf(2) ** (E - 33) * (1 + s)
         return -mp.sqrt(2) * mp.erfinv(2 * p - 1)
     worst = mp.mpf(0)
-    print("/* |z| on interval 4 E + k: coefficients of s^0 .. s^5 */")
+    print("/* |z| on interval 2 E + k: coefficients of s^0 .. s^5 */")
     for E in range(32):
-        for k in range(4):
-            a, b = mp.mpf(k) / 4, mp.mpf(k + 1) / 4
+        for k in range(2):
+            a, b = mp.mpf(k) / 2, mp.mpf(k + 1) / 2
             cf = to_double(cheb_fit(lambda s: z_of(E, s), a, b, 5))
             print("    {{%s}}," % ", ".join(float(v).hex() for v in cf))
-            for i in range(21):
-                s = a + (b - a) * i / 20
+            for i in range(41):
+                s = a + (b - a) * i / 40
                 worst = max(worst, abs(horner(cf, s) - z_of(E, s)))
     print("normal: max abs error", mp.nstr(worst, 3))
 
 
+LOGPHI_BINADES = 17
+
+
+def gen_logphi():
+    """log Phi(x) for x <= 0 (the censored likelihood's only case) = -x^2/2 + g(y), y = -x/sqrt2, g(y) = log(erfcx(y)/2): smooth and
+    slowly varying.  v = y + 1 = 2^E m; interval 8 E + k, k = floor(8 (m - 1)), E = 0..16 (y < 131071); on it g = P(s), s = m - 1,
+    degree 9, coefficients of s^0..s^9 (monomials about s = 0).  136 x 10 doubles."""
+    def g_of(E, s):
+        y = mp.mpf(2) ** E * (1 + s) - 1
+        if y > 40:            # erfcx(y) = 1/(y sqrt(pi)) sum_n (-1)^n (2n-1)!! / (2 y^2)^n: the terms fall below 1e-55 long before they grow
+            u, ssum, term = 1 / (2 * y * y), mp.mpf(1), mp.mpf(1)
+            for n in range(1, 60):
+                term *= -(2 * n - 1) * u
+                ssum += term
+                if abs(term) < mp.mpf('1e-55'):
+                    break
+            return mp.log(ssum / (y * mp.sqrt(mp.pi)) / 2)
+        return mp.log(mp.exp(y * y) * mp.erfc(y) / 2)
+    worst = mp.mpf(0)
+    print("/* g on interval 8 E + k: coefficients of s^0 .. s^9 */")
+    for E in range(LOGPHI_BINADES):
+        for k in range(8):
+            a, b = mp.mpf(k) / 8, mp.mpf(k + 1) / 8
+            cf = to_double(cheb_fit(lambda s: g_of(E, s), a, b, 9))
+            print("    {{%s}}," % ", ".join(float(v).hex() for v in cf))
+            for i in range(21):
+                s = a + (b - a) * i / 20
+                worst = max(worst, abs(horner(cf, s) - g_of(E, s)))
+    print("logphi: max abs error of g", mp.nstr(worst, 3))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["exp", "log", "erfcx", "sincos", "normal"]
+    which = sys.argv[1:] or ["exp", "log", "erfcx", "sincos", "normal", "logphi"]
     for w in which:
         globals()["gen_" + w]()
