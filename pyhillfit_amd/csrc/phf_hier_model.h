@@ -57,127 +57,20 @@ PHF_HD void phf_batch_recip(double* v, int n) {
   v[0] = inv;
 }
 
-/* Truncated-Gaussian terms of two points at once (PyHillFit.py:121-125): the masses Phi(b) - Phi(a) of the two points,
- * a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma.  Phi(b)-Phi(a) = 1 - [Q(b) + Phi(a)], both tails through erfcx (no cancellation
- * in the tails); the two lower tails share one division, the two upper tails another.  The per-Ne target multiplies the masses of
- * a half's points and takes one logarithm (phf_hier_target_half); the per-experiment form takes one per point.
- *
- * An UPPER tail with argument/sqrt2 >= PHF_TAIL_CUT = 6 is DEFINED as zero: Q(6 sqrt2) = 1.1e-17 is below half an ulp of the 1 it is
- * subtracted from.  That makes it skippable: the upper tails of a pair of points — 2 erfcx, 2 exponentials, a division — are
- * computed only if SOME lane of the wavefront has one above the cut (a wave-uniform branch; every other lane's result is replaced
- * by the zero it is defined as, so a chain's value does not depend on its wavefront's other chains, and the scalar twin simply
- * tests its own).  On the Crumb posteriors the upper tails (100 - pred >= 8.5 sigma) are negligible on all 64 chains for two
- * thirds of the point pairs (tools/diag_hier_tails.py), the lower ones almost never: those are computed unconditionally.        */
-#define PHF_TAIL_CUT 6.0
-
-/* The two points' lower tails Phi(a) (always needed) and upper arguments b — first part of phf_trunc_terms_x2_core. */
-PHF_HD void phf_trunc_lower_x2(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab ke, int kv,
-                               double* t0, double* t1, double* b0_out, double* b1_out) {
-  const double a0 = -pred0 * inv_s, b0 = (PHF_K100(kx) - pred0) * inv_s, a1 = -pred1 * inv_s, b1 = (PHF_K100(kx) - pred1) * inv_s;
-  const double ya0 = -a0 * PHF_INV_SQRT2, ya1 = -a1 * PHF_INV_SQRT2;
-  double qa[2] = {phf_erfcx_den(ya0), phf_erfcx_den(ya1)};
-  phf_batch_recip(qa, 2);
-  const double ea0 = phf_erfcx_finish_kx(ya0, qa[0], ke, kv), ea1 = phf_erfcx_finish_kx(ya1, qa[1], ke, kv);
-  const double ga0 = phf_exp_capped_k(-0.5 * a0 * a0, kx), ga1 = phf_exp_capped_k(-0.5 * a1 * a1, kx);
-  *t0 = ea0 * ga0; *t1 = ea1 * ga1;
-  *b0_out = b0; *b1_out = b1;
-}
-
-/* Second part: the upper tails Q(b) where some lane's is above the cut, then the masses m = Phi(b) - Phi(a) = 1 - t/2 with
- * t = 2 Phi(a) + 2 Q(b) = erfc(-a/sqrt2) + erfc(b/sqrt2).
- * skip (a literal): branch around negligible upper tails; 0: compute them regardless and select the zero (same values: the
- * 256-register two-lane build, whose register allocation spills once the branches cut its straight-line body into blocks).
- * Measured on one box (one-lane Ne = 3 group of C4): no skipping 17.19 / 17.44 ms, skipping pair by pair 16.52 / 16.82,
- * skipping in a second pass over the pairs 16.92 / 17.13 (not kept). */
-PHF_HD void phf_trunc_upper_mass_x2(double t0, double t1, double b0, double b1, phf_ktab kx, phf_ktab ke, int kv, int skip,
-                                    double* m0, double* m1) {
-  const double yb0 = b0 * PHF_INV_SQRT2, yb1 = b1 * PHF_INV_SQRT2;
-  const int up0 = yb0 < PHF_TAIL_CUT, up1 = yb1 < PHF_TAIL_CUT;
-  if (!skip || PHF_ANY_LANE(up0 | up1)) {
-    double qb[2] = {phf_erfcx_den(yb0), phf_erfcx_den(yb1)};
-    phf_batch_recip(qb, 2);
-    const double eb0 = phf_erfcx_finish_kx(yb0, qb[0], ke, kv), eb1 = phf_erfcx_finish_kx(yb1, qb[1], ke, kv);
-    const double gb0 = phf_exp_capped_k(-0.5 * b0 * b0, kx), gb1 = phf_exp_capped_k(-0.5 * b1 * b1, kx);
-    t0 += up0 ? eb0 * gb0 : 0.0;
-    t1 += up1 ? eb1 * gb1 : 0.0;
-  }
-  *m0 = phf_fma(-0.5, t0, 1.0);                           /* Phi(b) - Phi(a) = 1 - (Q(b) + Phi(a)) */
-  *m1 = phf_fma(-0.5, t1, 1.0);
-}
-
-/* the truncation masses Phi(b) - Phi(a) of two points */
-PHF_HD void phf_trunc_mass_x2_core(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab ke, int kv, int skip,
-                                   double* m0, double* m1) {
-  double t0, t1, b0, b1;
-  phf_trunc_lower_x2(pred0, pred1, inv_s, kx, ke, kv, &t0, &t1, &b0, &b1);
-  phf_trunc_upper_mass_x2(t0, t1, b0, b1, kx, ke, kv, skip, m0, m1);
-}
-
-/* ke: the 23 erfcx coefficients; kv: they are read as they stand (registers, LDS: compiler-scheduled fma) rather than from SGPRs */
-PHF_HD double phf_trunc_terms_x2_core(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
-  double m0, m1;
-  phf_trunc_mass_x2_core(pred0, pred1, inv_s, kx, ke, kv, skip, &m0, &m1);
-  return phf_log_fast_k(m0, kl) + phf_log_fast_k(m1, kl);
-}
-
-/* m0 m1, with the erfcx coefficients from the caller or fetched here (see phf_trunc_terms_x2_ke) */
-PHF_HD double phf_trunc_mass_x2_ke(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab ke_given, int have_ke, int skip) {
-  double m0, m1;
-  if (have_ke) {
-    phf_trunc_mass_x2_core(pred0, pred1, inv_s, kx, ke_given, 1, skip, &m0, &m1);
-  } else {
-    PHF_KFETCH(ke, phf_k_erfcx, 24);
-    phf_trunc_mass_x2_core(pred0, pred1, inv_s, kx, ke, 0, skip, &m0, &m1);
-  }
-  return m0 * m1;
-}
-
-/* ke_given: the erfcx coefficients where the caller keeps them (LDS) if have_ke (a literal at the call site), else fetched
- * through the scalar cache into SGPRs here.  Two call sites rather than a selected pointer: the compiler then knows the address
- * space of each; a literal flag rather than a null test: an LDS address cannot be proven non-null.                  */
-PHF_HD double phf_trunc_terms_x2_ke(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke_given, int have_ke, int skip) {
-  if (have_ke) return phf_trunc_terms_x2_core(pred0, pred1, inv_s, kx, kl, ke_given, 1, skip);
-  PHF_KFETCH(ke, phf_k_erfcx, 24);
-  return phf_trunc_terms_x2_core(pred0, pred1, inv_s, kx, kl, ke, 0, skip);
-}
-
-PHF_HD double phf_trunc_terms_x2(double pred0, double pred1, double inv_s, phf_ktab kx, phf_ktab kl) {
-  return phf_trunc_terms_x2_ke(pred0, pred1, inv_s, kx, kl, 0, 0, 1);
-}
-
-PHF_HD double phf_trunc_mass_core(double pred, double inv_s, phf_ktab kx, phf_ktab ke, int kv, int skip) {
+/* Truncated-Gaussian term of a point (PyHillFit.py:121-125): the mass Phi(b) - Phi(a), a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma,
+ * = 1 - [erfc(ya) + erfc(yb)]/2 with ya = -a/sqrt2, yb = b/sqrt2 >= 0: both tails from the erfc table of phf_math.h (absolute
+ * accuracy below half an ulp of the 1 they are subtracted from; a tail with argument >= PHF_ERFC_CUT = 6 — more than 8.5 sigma
+ * from its bound — is DEFINED as zero).  No division, no branch.  The per-Ne target multiplies the masses of a half's points and
+ * takes one logarithm (phf_hier_target_half); the per-experiment form takes one per point.
+ * (Rounds 1-3: erfcx(y) exp(-y^2) per tail, two tails per division, the upper tails of a pair of points skipped under a
+ * wave-uniform branch when negligible on every lane — ~50 fp64 operations per tail against 15.)                              */
+PHF_HD double phf_trunc_mass(double pred, double inv_s, phf_ktab kx) {
   const double a = -pred * inv_s, b = (PHF_K100(kx) - pred) * inv_s;
   const double ya = -a * PHF_INV_SQRT2, yb = b * PHF_INV_SQRT2;
-  const double ea = phf_erfcx_finish_kx(ya, phf_rcp(phf_erfcx_den(ya)), ke, kv);
-  const double ga = phf_exp_capped_k(-0.5 * a * a, kx);
-  double t = ea * ga;
-  const int up = yb < PHF_TAIL_CUT;
-  if (!skip || PHF_ANY_LANE(up)) {
-    const double eb = phf_erfcx_finish_kx(yb, phf_rcp(phf_erfcx_den(yb)), ke, kv);
-    const double gb = phf_exp_capped_k(-0.5 * b * b, kx);
-    t += up ? eb * gb : 0.0;
-  }
-  return phf_fma(-0.5, t, 1.0);
+  return phf_fma(-0.5, phf_erfc_tab(ya) + phf_erfc_tab(yb), 1.0);
 }
 
-PHF_HD double phf_trunc_term_core(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke, int kv, int skip) {
-  const double m = phf_trunc_mass_core(pred, inv_s, kx, ke, kv, skip);
-  return phf_log_fast_k(m, kl);
-}
-
-PHF_HD double phf_trunc_mass_ke(double pred, double inv_s, phf_ktab kx, phf_ktab ke_given, int have_ke, int skip) {
-  if (have_ke) return phf_trunc_mass_core(pred, inv_s, kx, ke_given, 1, skip);
-  PHF_KFETCH(ke, phf_k_erfcx, 24);
-  return phf_trunc_mass_core(pred, inv_s, kx, ke, 0, skip);
-}
-
-PHF_HD double phf_trunc_term_ke(double pred, double inv_s, phf_ktab kx, phf_ktab kl, phf_ktab ke_given, int have_ke, int skip) {
-  if (have_ke) return phf_trunc_term_core(pred, inv_s, kx, kl, ke_given, 1, skip);
-  PHF_KFETCH(ke, phf_k_erfcx, 24);
-  return phf_trunc_term_core(pred, inv_s, kx, kl, ke, 0, skip);
-}
-
-PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl) { return phf_trunc_term_ke(pred, inv_s, kx, kl, 0, 0, 1); }
+PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl) { return phf_log_fast_k(phf_trunc_mass(pred, inv_s, kx), kl); }
 
 /* ---- the target as the sum of two HALVES ---------------------------------------------------------------------------
  * log target = P_0 + P_1 (or -inf outside the support), where each half is a fixed sequence of operations on its own share of
@@ -196,7 +89,7 @@ PHF_HD double phf_trunc_term(double pred, double inv_s, phf_ktab kx, phf_ktab kl
  *   half 1: + sum_i -(pIC50_i - mu)/s  - 2 ln prod_i (1 + exp(-(pIC50_i - mu)/s))  (logistic, :144-154; either product term by
  *           term if it is not below 2^1000)
  *   both:   - [ SSE_h / (2 sigma^2) + ln prod over the half's points of (Phi((100-p)/sigma) - Phi((0-p)/sigma)) ]   (:113-132; an upper
- *           tail beyond PHF_TAIL_CUT counts as zero; a product that underflows makes the half -inf)
+ *           tail beyond PHF_ERFC_CUT counts as zero; a product that underflows makes the half -inf)
  *     where experiment i's n points are split  first 2*floor((n+2)/4) -> half 0, the others -> half 1  (4 points: 2 + 2).
  *
  * `h` is a literal at the call site (twin, one-lane kernels: the selects below fold away) or the lane's parity (two-lane
@@ -227,8 +120,7 @@ PHF_HD int phf_hier_out_of_support(int n_expts, const double* th, int ts, const 
 }
 
 PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
-                                   const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log,
-                                   phf_ktab ke_given, int have_ke, int skip_tails) {
+                                   const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
   const int dim = 5 + 2 * n_expts;
   const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
   /* fixed_n is a SHAPE CODE (PHF_HIER_SHAPE): low 4 bits = points of every experiment (a multiple of 4), the bits above = points of the
@@ -338,7 +230,7 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
       const double pred0 = phf_fma(-PHF_K100(k_exp), inv * d1, PHF_K100(k_exp)), pred1 = phf_fma(-PHF_K100(k_exp), inv * d0, PHF_K100(k_exp));
       const double r0 = y0 - pred0, r1 = y1 - pred1;
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
-      mass *= phf_trunc_mass_x2_ke(pred0, pred1, inv_s, k_exp, ke_given, have_ke, skip_tails);
+      mass *= phf_trunc_mass(pred0, inv_s, k_exp) * phf_trunc_mass(pred1, inv_s, k_exp);
     }
     if (fixed_n ? (fcnt & 1) : (j < jend)) {                                 /* at most one left */
       const double lcs = fixed_n ? plc[poff + fcnt - 1] : lc[j], ys = fixed_n ? py[poff + fcnt - 1] : y[j];
@@ -346,7 +238,7 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
       const double pred = phf_fma(-PHF_K100(k_exp), w, PHF_K100(k_exp));
       const double r = ys - pred;
       sse = phf_fma(r, r, sse);
-      mass *= phf_trunc_mass_ke(pred, inv_s, k_exp, ke_given, have_ke, skip_tails);
+      mass *= phf_trunc_mass(pred, inv_s, k_exp);
     }
     poff += fcnt;
   }
@@ -362,8 +254,8 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
 PHF_HD double phf_hier_log_target_n(int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
                                     const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
   const int bad = phf_hier_out_of_support(n_expts, th, ts, pr);
-  const double p0 = phf_hier_target_half(0, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 0, 0, 1);
-  const double p1 = phf_hier_target_half(1, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 0, 0, 1);
+  const double p0 = phf_hier_target_half(0, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log);
+  const double p1 = phf_hier_target_half(1, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log);
   return bad ? -PHF_INF : p0 + p1;
 }
 
@@ -425,7 +317,7 @@ PHF_HD void phf_hier_experiment_terms(const phf_hier_common* c, double pic50, do
     const double pred0 = phf_fma(-PHF_K100(k_exp), inv * d1, PHF_K100(k_exp)), pred1 = phf_fma(-PHF_K100(k_exp), inv * d0, PHF_K100(k_exp));
     const double r0 = y[j] - pred0, r1 = y[j + 1] - pred1;
     sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
-    trunc += phf_trunc_terms_x2(pred0, pred1, c->inv_s, k_exp, k_log);
+    trunc += phf_trunc_term(pred0, c->inv_s, k_exp, k_log) + phf_trunc_term(pred1, c->inv_s, k_exp, k_log);
   }
   for (; j < n; ++j) {
     const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc[j] - ln_ic50), 40.0), k_exp));

@@ -259,6 +259,7 @@ template <int NE>
 __global__ __launch_bounds__(kBlock, 1) void hier_advance_kernel(const HierArgs a) {
   extern __shared__ double s_mem[];
   PHF_MATH_TABLES_TO_LDS();
+  PHF_ERFC_TABLE_TO_LDS();
   double* s_lc = s_mem + (size_t)Lds<NE>::slots * kBlock;
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
@@ -308,9 +309,8 @@ struct Lds2 {
   static constexpr int A = (dim + 1) / 2;
   static constexpr int slots = A * A;                      // pair-row a: 2a+1 slots; lane 1's diagonals in its unused last pair-row
   // constants read through LDS (wave-uniform addresses: broadcast reads on the LDS pipe) instead of occupying scalar or vector
-  // registers: 24 erfcx + 12 sin/cos coefficients and the 15 prior parameters.  With SGPR-resident erfcx coefficients the kernel
-  // spilled ~50 scalar registers to VGPR lanes around every pair of points (420 v_readlane/v_writelane per iteration).
-  static constexpr int consts = 24 + 12 + 15;
+  // registers: the 12 sin/cos coefficients and the 15 prior parameters
+  static constexpr int consts = 12 + 15;
   static size_t point_bytes(int stride) { return (size_t)stride * 16 + (NE + 1) * 4 + 8; }
   static size_t bytes(int stride) { return (size_t)(slots * kBlock + consts) * 8 + point_bytes(stride); }
 };
@@ -326,7 +326,7 @@ __device__ __forceinline__ double phf_dpp_quad(double v, const int ctrl_tag) {
 #define PHF_FROM_LANE(hsrc, v) phf_dpp_quad((v), (hsrc))
 #define PHF_FROM_PARTNER(v) phf_dpp_quad((v), 2)
 
-// WPS = wavefronts per SIMD the body is compiled for.  2: 256 registers — the erfcx and sin/cos coefficients and the prior
+// WPS = wavefronts per SIMD the body is compiled for.  2: 256 registers — the sin/cos coefficients and the prior
 // parameters are read through LDS (s_k) where they are used; 1: 512 registers — every table resident in registers, the prior in
 // scalar registers (launches whose wavefronts have a SIMD each: nothing would hide an LDS or scalar-cache latency).
 template <int NE, int FIXED_N, int WPS>
@@ -373,15 +373,13 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
   double nacc = PHF_SP(2 * D + 2 + TRI);
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);                      // used by every polynomial of the iteration: registers
   PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
-  double kv_erfcx[WPS == 1 ? 24 : 1], kv_sc[WPS == 1 ? 12 : 1];
+  double kv_sc[WPS == 1 ? 12 : 1];
   if (WPS == 1) {
-#pragma unroll
-    for (int i = 0; i < 24; ++i) { kv_erfcx[WPS == 1 ? i : 0] = phf_k_erfcx[i]; asm volatile("" : "+v"(kv_erfcx[WPS == 1 ? i : 0])); }
 #pragma unroll
     for (int i = 0; i < 12; ++i) { kv_sc[WPS == 1 ? i : 0] = phf_k_sincos[i]; asm volatile("" : "+v"(kv_sc[WPS == 1 ? i : 0])); }
   }
-  const phf_ktab k_erfcx = (WPS == 1) ? kv_erfcx : s_k, k_sc = (WPS == 1) ? kv_sc : s_k + 24;
-  const phf_hier_prior* const prior = (WPS == 1) ? &a.prior : reinterpret_cast<const phf_hier_prior*>(s_k + 36);
+  const phf_ktab k_sc = (WPS == 1) ? kv_sc : s_k;
+  const phf_hier_prior* const prior = (WPS == 1) ? &a.prior : reinterpret_cast<const phf_hier_prior*>(s_k + 12);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
 
   const bool want_moments = a.moments != nullptr;
@@ -474,7 +472,7 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
     }
     // ---- target: this lane's half + the partner's (:486), accept (:487-492) ----
     const int bad = phf_hier_out_of_support(NE, star, 1, prior);
-    const double half = phf_hier_target_half(h, NE, FIXED_N, s_es, s_lc, s_y, star, 1, prior, k_exp, k_log, k_erfcx, 1, WPS == 1);
+    const double half = phf_hier_target_half(h, NE, FIXED_N, s_es, s_lc, s_y, star, 1, prior, k_exp, k_log);
     const double lt_star = bad ? -PHF_INF : half + PHF_FROM_PARTNER(half);
     const bool acc = log_u < lt_star - lt;
     if (acc) {                                             // own rows out of the full vector (not kept apart across the target: registers)
@@ -578,6 +576,7 @@ constexpr int kChains2 = kBlock / 2;                       // chains per wavefro
 template <int NE, int WPS>
 __global__ __launch_bounds__(kBlock, WPS) void hier_advance2_kernel(const HierArgs a) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_ERFC_TABLE_TO_LDS();
   extern __shared__ double s_mem[];
   double* s_k = s_mem + (size_t)Lds2<NE>::slots * kBlock;
   double* s_lc = s_k + Lds2<NE>::consts;
@@ -588,13 +587,12 @@ __global__ __launch_bounds__(kBlock, WPS) void hier_advance2_kernel(const HierAr
   const int q = a.prob.launch_order ? a.prob.launch_order[slot] : slot;
   const int c0 = chunk * kChains2;
   const int pair = a.prob.pair_index[q];
-  if (threadIdx.x < 24) s_k[threadIdx.x] = phf_k_erfcx[threadIdx.x];
-  else if (threadIdx.x < 36) s_k[threadIdx.x] = phf_k_sincos[threadIdx.x - 24];
+  if (threadIdx.x < 12) s_k[threadIdx.x] = phf_k_sincos[threadIdx.x];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {                            // static indices: a run-time index would copy the argument block to scratch
-    if (threadIdx.x == 36 + i) s_k[36 + i] = a.prior.shape_m1[i];
-    if (threadIdx.x == 41 + i) s_k[41 + i] = a.prior.inv_scale[i];
-    if (threadIdx.x == 46 + i) s_k[46 + i] = a.prior.loc[i];
+    if (threadIdx.x == 12 + i) s_k[12 + i] = a.prior.shape_m1[i];
+    if (threadIdx.x == 17 + i) s_k[17 + i] = a.prior.inv_scale[i];
+    if (threadIdx.x == 22 + i) s_k[22 + i] = a.prior.loc[i];
   }
   stage<NE>(a.pts, pair, s_lc, s_y, s_es);
   if (c0 + (int)(threadIdx.x >> 1) >= a.prob.chains_per_problem) return;    // both lanes of a chain leave together
@@ -607,6 +605,7 @@ __global__ __launch_bounds__(kBlock, WPS) void hier_advance2_kernel(const HierAr
 template <int NE>
 __global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_ERFC_TABLE_TO_LDS();
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
   extern __shared__ double s_mem[];
@@ -651,6 +650,7 @@ template <int NE>
 __global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_points pts, const phf_hier_prior prior, int64_t m,
                                                                  const int32_t* pair_index, const double* theta, double* out) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_ERFC_TABLE_TO_LDS();
   constexpr int D = 5 + 2 * NE;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= m) return;
@@ -690,6 +690,7 @@ struct WaveLds {
 
 __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArgs a) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_ERFC_TABLE_TO_LDS();
   extern __shared__ double s_mem[];
   const int ne = a.pts.n_expts;
   const int D = 5 + 2 * ne;
@@ -847,6 +848,7 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
 
 __global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_ERFC_TABLE_TO_LDS();
   const int ne = a.pts.n_expts;
   const int D = 5 + 2 * ne;
   const int q = blockIdx.x / a.blocks_per_problem;
@@ -881,6 +883,7 @@ __global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a)
 __global__ __launch_bounds__(64) void hier_generic_log_target_kernel(const phf_hier_points pts, const phf_hier_prior prior, int64_t m,
                                                                      const int32_t* pair_index, const double* theta, double* out) {
   PHF_MATH_TABLES_TO_LDS();
+  PHF_ERFC_TABLE_TO_LDS();
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= m) return;
   const int ne = pts.n_expts;
@@ -939,8 +942,8 @@ HierPolicy& hier_policy() {                                       // first use r
 int hier_lanes_override() { return hier_policy().lanes; }
 int hier_wps_override() { return hier_policy().wps; }
 
-// a workgroup's 160 KB of LDS less the static part every kernel here has: the exp / log tables of phf_math.h
-constexpr size_t kMaxDynamicLds = 160 * 1024 - PHF_MATH_LDS_BYTES;
+// a workgroup's 160 KB of LDS less the static part every kernel here has: the exp / log and erfc tables of phf_math.h
+constexpr size_t kMaxDynamicLds = 160 * 1024 - PHF_MATH_LDS_BYTES - PHF_ERFC_TAB_N * sizeof(phf_erfctab);
 
 template <typename K>
 int allow_big_lds(K kernel, bool* configured) {                   // the attribute is per function AND per device

@@ -575,6 +575,76 @@ PHF_HD double phf_log_ndtr_nonpos_kx(double x, phf_ktab ke, int ke_in_vgpr, phf_
 
 PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab ke, phf_ktab kl) { return phf_log_ndtr_nonpos_kx(x, ke, 0, kl); }
 
+/* erfc(y), y >= 0, to an ABSOLUTE accuracy of 3.6e-17 through a table — the hierarchical target's form: its truncation masses
+ * Phi(b) - Phi(a) = 1 - (erfc(ya) + erfc(yb))/2 need the tails to half an ulp of 1, not to a relative accuracy.  Centres
+ * c_j = j/4 (the nearest to y, magic-number rounding), s = y - c_j in [-1/8, 1/8], degree 11 (tools/gen_math_coeffs.py erfc);
+ * erfc(6) = 2.2e-17 is below half an ulp of the 1 it is subtracted from: from PHF_ERFC_CUT on the tail is DEFINED as zero.
+ * 15 fp64 operations and six 16-byte LDS reads where erfcx x exp(-y^2) took ~50, no division, no branch.  The table (2.4 KB)
+ * goes to LDS with PHF_ERFC_TABLE_TO_LDS().  (The index is clamped: any argument is safe to evaluate.) */
+#define PHF_ERFC_TAB_N 25
+#define PHF_ERFC_CUT 6.0
+typedef struct { double c[12]; } phf_erfctab;
+static const phf_erfctab phf_t_erfc[PHF_ERFC_TAB_N] = {
+    {{0x1.0000000000000p+0, -0x1.20dd750429b6dp+0, -0x1.1011ffb71c7eep-188, 0x1.812746b0379a0p-2, 0x1.f4572a9871ca6p-180, -0x1.ce2f21a00f2fcp-4, -0x1.45a0000000000p-172, 0x1.b82ce2367f627p-6, 0x1.6155555555555p-166, -0x1.565a247787ddap-8, -0x1.1155555555555p-161, 0x1.bd39fdb90fa3ap-11}},
+    {{0x1.728558ee694fcp-1, -0x1.0f5d1602f7e41p+0, 0x1.0f5d1602f7d94p-2, 0x1.3c974458cbde1p-2, -0x1.040e8a6d43d1dp-3, -0x1.47e5cfee31131p-4, 0x1.4c0b24317213ep-5, 0x1.08d9468a5e011p-6, -0x1.3db4f8210378dp-7, -0x1.55613142c98afp-9, 0x1.e2631bbd80df3p-10, 0x1.64bb2a48c9969p-12}},
+    {{0x1.eb02147ce245cp-2, -0x1.c1efca49a5011p-1, 0x1.c1efca49a4f9ep-2, 0x1.2bf531866e06fp-3, -0x1.76f27de7df78fp-3, -0x1.dfeeb5a62a146p-8, 0x1.99f13a73477c9p-5, -0x1.623c5f112004ep-8, -0x1.493bedf1a6959p-7, 0x1.1c13edd64a268p-9, 0x1.9907484199c5fp-10, -0x1.02aaeb6b9d521p-11}},
+    {{0x1.27c6d14c5e341p-2, -0x1.492e42d78d2c5p-1, 0x1.edc5644353c65p-2, -0x1.b6e8591f66b94p-6, -0x1.349b5eaa2af7dp-3, 0x1.b42a18908d619p-5, 0x1.b8477a27cd97dp-6, -0x1.2e0afa814c26fp-6, -0x1.2db61c7e31d1cp-9, 0x1.040f51c2dcaa8p-8, -0x1.7bc355700ad98p-13, -0x1.454a7084b2f36p-11}},
+    {{0x1.4226162fbddd5p-3, -0x1.a911f096fbc26p-2, 0x1.a911f096fbc9bp-2, -0x1.1b614b0f5282fp-3, -0x1.1b614b0fa8153p-4, 0x1.1b614b0f5a72fp-4, -0x1.2e459fb0c45c4p-8, -0x1.f096fdb402567p-7, 0x1.390e85fe8a0b8p-8, 0x1.ee31df8a34c33p-10, -0x1.3f03a0b1dcd9ap-10, -0x1.6a5cad6230683p-14}},
+    {{0x1.3bcd133aa0ffcp-4, -0x1.e4652fadcb6b2p-3, 0x1.2ebf3dcc9f24ep-2, -0x1.571d01c5c5700p-3, 0x1.93a9a7ba1302dp-8, 0x1.8281ce0b64bf9p-5, -0x1.5d00034e6d934p-6, -0x1.db43cca1e52edp-9, 0x1.756671dff7a0ep-8, -0x1.cc1c2fce1d469p-11, -0x1.9ebaf6388a9d8p-11, 0x1.50f558b0669b1p-12}},
+    {{0x1.15aaa8ec85205p-5, -0x1.e723726b824a9p-4, 0x1.6d5a95d0a1b24p-3, -0x1.1c2a02beb6acdp-3, 0x1.6d5a95d0e3fe8p-5, 0x1.e723726bc0292p-7, -0x1.3ca3d7b9ba81ep-6, 0x1.36d739dde13e0p-8, 0x1.35b0703fc2452p-9, -0x1.c0370dbb499bdp-10, 0x1.76846ae70e497p-14, 0x1.09ecd2fea9675p-12}},
+    {{0x1.b4be201caa4b4p-7, -0x1.b055303221015p-5, 0x1.7a4a8a2bdcd71p-4, -0x1.7148c3d57c2e9p-4, 0x1.8a0da54340f86p-5, -0x1.b22257dd7a0f7p-8, -0x1.25b379c47520ap-7, 0x1.8d10fbec88ca9p-8, -0x1.7eba3eba4f77dp-11, -0x1.d4d0fcefe33e5p-11, 0x1.cce38c94b0662p-12, 0x1.a4e2425477377p-18}},
+    {{0x1.328f5ec350e67p-8, -0x1.529b9e8cf9a1ep-6, 0x1.529b9e8cf9a05p-5, -0x1.8b0ae3a4788d7p-5, 0x1.1a2c59757f58ap-5, -0x1.ace7404c62debp-7, -0x1.e193612087723p-12, 0x1.bae0ac8b67b83p-9, -0x1.a113e810f8d98p-10, 0x1.a44fa9c5c5b49p-15, 0x1.134e399508787p-12, -0x1.b00973c1ff3acp-14}},
+    {{0x1.7f713f9cc9783p-10, -0x1.d4143a9dfe965p-8, 0x1.074b60f8df41dp-6, -0x1.63ef61e824418p-6, 0x1.38a98327624afp-6, -0x1.5d3b17bbe5a9dp-7, 0x1.7cae0e90978f9p-9, 0x1.5f83140762f9fp-11, -0x1.0604228718f3fp-10, 0x1.83527fb65d54dp-12, 0x1.a448645e3fd86p-17, -0x1.10edcd64bc8ecp-14}},
+    {{0x1.aab859b20ac9dp-12, -0x1.1d83170fbf6fbp-9, 0x1.64e3dcd3af6cep-8, -0x1.119da0c46cd09p-7, 0x1.1a89b97cba5c5p-7, -0x1.90e81283da98bp-8, 0x1.6ecdc0365d488p-9, -0x1.1c610cdd72ff0p-11, -0x1.11583acbda9f2p-12, 0x1.067280fda61ebp-12, -0x1.47bfe2d08e3d2p-14, -0x1.676f97d1bc118p-18}},
+    {{0x1.a609f7584d32bp-14, -0x1.3360ccd23db3ap-11, 0x1.a6a519a114e18p-10, -0x1.69cf466cce02dp-9, 0x1.ab0c273ab313dp-9, -0x1.693596063fda3p-9, 0x1.b2755c1e0e460p-10, -0x1.52b626dcdd7acp-11, 0x1.755677c721618p-14, 0x1.2abd9d6d3f0e4p-14, -0x1.cceaa0d3bd40fp-15, 0x1.07b3894bcebcdp-16}},
+    {{0x1.729df65034230p-16, -0x1.2408e9ba3327fp-13, 0x1.b60d5e974c4a4p-12, -0x1.9db74b1d1dd06p-11, 0x1.11c85b1ee2cfdp-10, -0x1.0a7b5546b179fp-10, 0x1.82f234ff7fdd5p-11, -0x1.998b47d5abf31p-12, 0x1.1aa737717e520p-13, -0x1.d2a25165478bap-17, -0x1.085eb63742f48p-16, 0x1.69f8d84a727a9p-17}},
+    {{0x1.20c1303550f1ep-18, -0x1.e9b5e8d00ce78p-16, 0x1.8de3cd29095c7p-14, -0x1.9aa489e3caa8ep-13, 0x1.2c7d5ef12599fp-12, -0x1.490a4d234ab2cp-12, 0x1.1454640a7f08ap-12, -0x1.647f719bfadbfp-13, 0x1.56762921e98d1p-14, -0x1.b2c50e744d729p-16, 0x1.2c97ed504a2ddp-19, 0x1.83e07111513d8p-19}},
+    {{0x1.8ef2a9a18d875p-21, -0x1.6a597219a93dcp-18, 0x1.3d0e43d673074p-16, -0x1.62ccea63cab12p-15, 0x1.1c07721b8d476p-14, -0x1.586bafca3e808p-14, 0x1.46153ee733221p-14, -0x1.e827f9defad7ep-15, 0x1.1f63cf8207188p-15, -0x1.0136377850d21p-16, 0x1.360c879c6f4e1p-18, -0x1.ce4e1e4173e89p-22}},
+    {{0x1.e87470e4f4217p-24, -0x1.d9371e2ff7c39p-21, 0x1.bba3ac4cf9f12p-19, -0x1.0b6a7b0f1b125p-17, 0x1.d06f585f5d223p-17, -0x1.3436bca02a923p-16, 0x1.4357b5fa5e733p-16, -0x1.110de42f28ac0p-16, 0x1.75661e9389f9fp-17, -0x1.99f6970f427dfp-18, 0x1.5df833cfbf755p-19, -0x1.9ecf06081e0b7p-21}},
+    {{0x1.08ddd13bd34e5p-26, -0x1.10b1488aeb230p-23, 0x1.10b1488af4309p-21, -0x1.603a5308c5b3bp-20, 0x1.4980e24bed079p-19, -0x1.da5f10db61713p-19, 0x1.105056fc200cep-18, -0x1.fd7c66700181bp-19, 0x1.88c44a0ee8b6ap-19, -0x1.f4236bf395920p-20, 0x1.05f7f3583ffd8p-20, -0x1.af339c270ec00p-22}},
+    {{0x1.fcae93fb72ab6p-30, -0x1.155a09065d4d2p-26, 0x1.26afa996e4fe8p-24, -0x1.95ea6fe000658p-23, 0x1.96ba734e1156bp-22, -0x1.3b468015f8c43p-21, 0x1.8868eefc08490p-21, -0x1.916e963513e10p-21, 0x1.5668a994c857ap-21, -0x1.eab106ddf01dap-22, 0x1.2a2a33cbd26a9p-22, -0x1.29928ccdcbb0bp-23}},
+    {{0x1.b05cfe2e9814bp-33, -0x1.f1e3523b41c8ap-30, 0x1.180fde41aa25dp-27, -0x1.99b8665629efcp-26, 0x1.b598cb0807b78p-25, -0x1.6b1baf38f543ap-24, 0x1.e651045ac6e5ap-24, -0x1.0d67962a69900p-23, 0x1.f5e32a19fa10fp-24, -0x1.8d27fc15c07cap-24, 0x1.0fc42053f27b4p-24, -0x1.37c69e3cfed70p-25}},
+    {{0x1.4531410820bfap-36, -0x1.8a61745ec7af6p-33, 0x1.d453ba31d2f76p-31, -0x1.6a8aeba49d1a4p-29, 0x1.9b017a453afd4p-28, -0x1.6b43c936c2f9ep-27, 0x1.042f4a0abfcb2p-26, -0x1.35dc9229118ffp-26, 0x1.3825a6988c396p-26, -0x1.0d45b29454bb1p-26, 0x1.976d4877bedb0p-27, -0x1.051d7ee7af912p-27}},
+    {{0x1.b0c1a759f0883p-40, -0x1.13af4f04f95dcp-36, 0x1.589b22c82a29cp-34, -0x1.196da0aaacb06p-32, 0x1.516d3c01da1efp-31, -0x1.3c51d079a2b09p-30, 0x1.e235e7a9a4964p-30, -0x1.32c74326ea416p-29, 0x1.4bb756cf02be1p-29, -0x1.34f9678364e4cp-29, 0x1.fe675890886b9p-30, -0x1.670ef93c9a518p-30}},
+    {{0x1.fd5f08ad19cb9p-44, -0x1.5422ef5d88a3cp-40, 0x1.be6dda2fa6900p-38, -0x1.7f8a0f3ede434p-36, 0x1.e4cb4922bd157p-35, -0x1.e044b362f0c07p-34, 0x1.83eac510d9ee3p-33, -0x1.06597cf8e4042p-32, 0x1.2ea81305ac120p-32, -0x1.2e26e583a68e2p-32, 0x1.0dfb64c216932p-32, -0x1.9be597e51954cp-33}},
+    {{0x1.09182b3258f7ap-47, -0x1.7258610b39a88p-44, 0x1.fd398579a93c7p-42, -0x1.cb12e2f795f80p-40, 0x1.31011cba1778bp-38, -0x1.3e4a1eee24db1p-37, 0x1.0f6f08ccac2e9p-36, -0x1.84a533bac1111p-36, 0x1.dbfb9bc353330p-36, -0x1.fa52c68d06182p-36, 0x1.e60013716d50bp-36, -0x1.8e6a4b07d9332p-36}},
+    {{0x1.e7eea02e0eceep-52, -0x1.63daf8b4af110p-48, 0x1.ff8ac595c1f3bp-46, -0x1.e2d06d72fda7bp-44, 0x1.505d91eda3dffp-42, -0x1.70b6ffef37c60p-41, 0x1.4aee47ed7f06cp-40, -0x1.f3c62fd9046dcp-40, 0x1.438b4d928ebb0p-39, -0x1.6cf31221e9dcbp-39, 0x1.7638142d73f1cp-39, -0x1.476976e6fedf5p-39}},
+    {{0x1.8cf8155772405p-56, -0x1.2dc1190952aa1p-52, 0x1.c4a1a5a8f3195p-50, -0x1.be584a62e0a25p-48, 0x1.45542a15a4be2p-46, -0x1.75a81a2865782p-45, 0x1.5ff9234088ef0p-44, -0x1.177287afcb477p-43, 0x1.7d2495b5025fep-43, -0x1.c60964539d7f9p-43, 0x1.ef1d0d92952aap-43, -0x1.cbc4bc38a2e47p-43}},
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+static __shared__ __attribute__((aligned(16))) phf_erfctab phf_lds_erfc[PHF_ERFC_TAB_N];
+#define PHF_T_ERFC(j) phf_lds_erfc[j]
+#define PHF_ERFC_TABLE_TO_LDS()                                                                                     \
+  do {                                                                                                              \
+    for (int phf_i_ = threadIdx.x; phf_i_ < PHF_ERFC_TAB_N * 12; phf_i_ += blockDim.x)                              \
+      (&phf_lds_erfc[0].c[0])[phf_i_] = (&phf_t_erfc[0].c[0])[phf_i_];                                              \
+    __syncthreads();                                                                                                \
+  } while (0)
+#else
+#define PHF_T_ERFC(j) phf_t_erfc[j]
+#define PHF_ERFC_TABLE_TO_LDS() do { } while (0)
+#endif
+
+PHF_HD double phf_erfc_tab(double y) {
+  const double t = phf_fma(y, 4.0, PHF_EXP_MAGIC);                      /* nearest integer to 4 y in the low mantissa bits */
+  const double s = phf_fma(t - PHF_EXP_MAGIC, -0.25, y);                /* y - c_j, exact */
+  const uint32_t jr = (uint32_t)phf_bits(t);
+  const uint32_t j = jr < (uint32_t)PHF_ERFC_TAB_N ? jr : (uint32_t)(PHF_ERFC_TAB_N - 1);
+  const phf_erfctab e = PHF_T_ERFC(j);
+  double p = phf_fma(e.c[11], s, e.c[10]);
+  p = phf_fma(p, s, e.c[9]);
+  p = phf_fma(p, s, e.c[8]);
+  p = phf_fma(p, s, e.c[7]);
+  p = phf_fma(p, s, e.c[6]);
+  p = phf_fma(p, s, e.c[5]);
+  p = phf_fma(p, s, e.c[4]);
+  p = phf_fma(p, s, e.c[3]);
+  p = phf_fma(p, s, e.c[2]);
+  p = phf_fma(p, s, e.c[1]);
+  p = phf_fma(p, s, e.c[0]);
+  return (y < PHF_ERFC_CUT) ? p : 0.0;
+}
+
 /* log Phi(x) for x <= 0 through a table — the single-level censored likelihood's form: log Phi(x) = -x^2/2 + g(y), y = -x/sqrt2,
  * g(y) = log(erfcx(y)/2), smooth and slowly varying, so a degree-9 polynomial per interval does it: v = y + 1 = 2^E m, interval
  * 8 E + floor(8 (m - 1)), E = 0..16, i.e. 0 <= y < 131071, g = P(m - 1) to 9.4e-16 absolute (tools/gen_math_coeffs.py logphi):

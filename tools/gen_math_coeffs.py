@@ -199,7 +199,25 @@ def gen_logphi():
     print("logphi: max abs error of g", mp.nstr(worst, 3))
 
 
+def gen_erfc():
+    """erfc(y) on [0, 6) to an ABSOLUTE accuracy below half an ulp of 1 — what the hierarchical target's truncation masses
+    1 - (erfc(ya) + erfc(yb))/2 need: centres c_j = j/4, j = 0..24 (the nearest to y), s = y - c_j in [-1/8, 1/8], degree 11,
+    coefficients of s^0..s^11.  25 x 12 doubles.  (erfc(6) = 2.2e-17: from there on the tail counts as zero.)"""
+    H = mp.mpf(1) / 8
+    worst = mp.mpf(0)
+    print("/* erfc about c_j = j/4: coefficients of s^0 .. s^11 */")
+    for j in range(25):
+        c = mp.mpf(j) / 4
+        cf = to_double(cheb_fit(lambda s: mp.erfc(c + s), -H, H, 11))
+        print("    {{%s}}," % ", ".join(float(v).hex() for v in cf))
+        lo = -H if j > 0 else mp.mpf(0)
+        for i in range(41):
+            s = lo + (H - lo) * i / 40
+            worst = max(worst, abs(horner(cf, s) - mp.erfc(c + s)))
+    print("erfc: max abs error", mp.nstr(worst, 3))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["exp", "log", "erfcx", "sincos", "normal", "logphi"]
+    which = sys.argv[1:] or ["exp", "log", "erfcx", "sincos", "normal", "logphi", "erfc"]
     for w in which:
         globals()["gen_" + w]()
