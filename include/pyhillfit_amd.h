@@ -238,7 +238,8 @@ int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior
  * the MH loops' own division / square root without exponent-range handling (phf_math.h; correctly rounded for operands within
  * 2^-600..2^600): 12 phf_rcp(x), 13 phf_sqrt_pos(x), 14 phf_div(ln 10, x), 15 phf_sqrt_nonneg(x) (0 -> 0), 16 phf_div(x, ln 10);
  * 17 phf_normal_u32(w): the single-level sampler's standard normal of a 32-bit word (input doubles hold integer values w in [0, 2^32));
- * 18 phf_log_ndtr_tab(x): log Phi(x) from the censored likelihood's table (valid for -185 000 < x <= 0; any x is safe to pass). */
+ * 18 phf_log_ndtr_tab(x): log Phi(x) from the censored likelihood's table (valid for -185 000 < x <= 0; any x is safe to pass);
+ * 19 phf_erfc_tab(y): erfc(y), y >= 0, to 3.6e-17 absolute from the hierarchical target's table, 0 from y = 6 on (any y is safe to pass). */
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream);
 
 /* The four Philox words of n (counter, key) tuples: in device uint32 [n][6], out device uint32 [n][4]. */

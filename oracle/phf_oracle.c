@@ -277,6 +277,7 @@ VEC1(phfo_vec_log_fast, phf_log_fast)
 VEC1(phfo_vec_log_ndtr_nonpos, phf_log_ndtr_nonpos)
 static inline double log_ndtr_tab1(double x) { return phf_log_ndtr_tab(x, -x * PHF_INV_SQRT2); }
 VEC1(phfo_vec_log_ndtr_tab, log_ndtr_tab1)
+VEC1(phfo_vec_erfc_tab, phf_erfc_tab)
 
 void phfo_vec_log_ndtr_nonpos_x2(int64_t n, const double* x, double* out) {
   for (int64_t i = 0; i + 1 < n; i += 2) phf_log_ndtr_nonpos_x2(x[i], x[i + 1], &out[i], &out[i + 1]);

@@ -425,6 +425,7 @@ __global__ __launch_bounds__(256) void log_target_kernel(const phf_points pts, i
 __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* out) {
   PHF_MATH_TABLES_TO_LDS();
   PHF_LOGPHI_TABLE_TO_LDS();
+  PHF_ERFC_TABLE_TO_LDS();
   PHF_NORMAL_TABLE_TO_LDS();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -449,6 +450,7 @@ __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* o
     case 16: r = phf_div(x, PHF_LN10); break;
     case 17: r = phf_normal_u32((uint32_t)x); break;
     case 18: r = phf_log_ndtr_tab(x, -x * PHF_INV_SQRT2); break;
+    case 19: r = phf_erfc_tab(x); break;
     default: phf_sincos_2pi_u32((uint32_t)x, &s, &c); r = c; break;
   }
   out[i] = r;
@@ -583,7 +585,7 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
 }
 
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream) {
-  if (fn < 0 || fn > 18 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
+  if (fn < 0 || fn > 19 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
   if (n == 0) return PHF_OK;
   hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, n, in, out);
   return phf_check_launch("phf_debug_math");

@@ -52,6 +52,8 @@ def test_device_math_bit_identical_to_host_build(gpu):
         9: ("exp_fast", np.concatenate([rng.uniform(-760, 720, n), rng.uniform(-3, 3, n), [np.nan, np.inf, -np.inf]])),
         10: ("log_fast", np.concatenate([np.exp(rng.uniform(-708, 709, n)), rng.uniform(-1, 2, n), [0.0, 1e-310]])),
         11: ("log_ndtr_nonpos", np.concatenate([-np.exp(rng.uniform(-30, 11.6, n)), rng.uniform(-40, 0, n), [0.0, -1e5]])),
+        19: ("erfc_tab", np.concatenate([rng.uniform(0, 6.5, n), np.exp(rng.uniform(-30, 2, n)), np.arange(0, 26) / 4.0, np.arange(0, 26) / 4.0 + 0.125,
+                          [0.0, -0.0, 5.999999, 6.0, 7.0, 1e300, -1.0, -1e300, np.nan, np.inf]])),
         18: ("log_ndtr_tab", np.concatenate([-np.exp(rng.uniform(-30, 12.1, n)), rng.uniform(-40, 0, n), [0.0, -0.0, -1e5, -1.85e5, -2e5, 3.0, 1e5, np.nan, np.inf]])),
     }
     for fn, (name, x) in cases.items():

@@ -58,6 +58,13 @@ def test_erfcx_and_normal_cdf():
     x = np.concatenate([-np.exp(RNG.uniform(-20, 12.1, 100000)), RNG.uniform(-40, 0, 100000), [0.0, -1e5, -1.85e5]])
     assert np.max(np.abs(co.vec("log_ndtr_tab", x) / co.vec("log_ndtr", x) - 1)) < 2e-15
     assert np.max(np.abs(co.vec("log_ndtr_tab", x) / sp.log_ndtr(x) - 1)) < 6e-15
+    # the hierarchical truncation masses' erfc table: ABSOLUTE accuracy (half an ulp of 1), zero from 6 on, interval joints included
+    y = np.concatenate([RNG.uniform(0, 6, 200000), np.arange(0, 24) / 4.0 + 0.125, np.nextafter(np.arange(0, 24) / 4.0 + 0.125, 0), [0.0, 5.9999999]])
+    assert np.max(np.abs(co.vec("erfc_tab", y) - sp.erfc(y))) < 4e-16          # scipy's own erfc is off by up to 3e-16 around y = 0.9
+    assert np.array_equal(co.vec("erfc_tab", [6.0, 6.5, 1e300, np.inf]), [0.0, 0.0, 0.0, 0.0]) and co.vec("erfc_tab", [0.0])[0] == 1.0
+    mp.mp.dps = 40
+    for yy in np.concatenate([[0.01, 0.124, 0.126, 1.0, 2.37, 4.0, 5.9], RNG.uniform(0, 6, 2000)]):       # half an ulp of its own value at most
+        assert abs(mp.mpf(float(co.vec("erfc_tab", [yy])[0])) - mp.erfc(mp.mpf(float(yy)))) < 1.2e-16
     x = RNG.uniform(0, 38, 50000)
     assert np.max(np.abs(co.vec("log_ndtr", x) - sp.log_ndtr(x))) < 4e-15
     x = RNG.uniform(-38, 10, 100000)
