@@ -469,7 +469,10 @@ PHF_HD double phf_log(double x) {
 /* ------------------------------------------------------------------------------------------------ erfcx
  * erfcx(y) = exp(y^2) erfc(y) for y >= 0:  (1+2y) erfcx(y) = P(t), t = (y-4)/(y+4) in [-1,1], P degree 22
  * as even + t*odd (approximation error 3.1e-16).  den/finish are split: r = 1/((y+4)(1+2y)) serves both t and
- * the final scaling and may come from a batched reciprocal.                                                    */
+ * the final scaling and may come from a batched reciprocal.
+ * Since round 3 the MH loops no longer call this family: the single-level censored likelihood takes log Phi from
+ * phf_log_ndtr_tab and the hierarchical truncation masses take erfc from phf_erfc_tab (both below).  It stays as the full-range,
+ * full-relative-accuracy form behind phf_log_ndtr / phf_ndtr (any argument) and as what the tables are tested against.   */
 PHF_HD double phf_erfcx_den(double y) { return (y + 4.0) * phf_fma(2.0, y, 1.0); }
 
 PHF_KTABLE phf_k_erfcx[24] = { /* (1+2y) erfcx(y) in t = (y-4)/(y+4), coefficient of t^i (24th entry pads the burst) */
@@ -480,38 +483,33 @@ PHF_KTABLE phf_k_erfcx[24] = { /* (1+2y) erfcx(y) in t = (y-4)/(y+4), coefficien
     0x1.355884b1ca9fcp-24, 0x1.8f0920c7d5e28p-24, -0x1.1f8f10ba20f78p-26, -0x1.dff032d300316p-28,
     0x1.c2e324cb33784p-30, 0.0};
 
-/* the coefficient operand of a Horner step: from an SGPR pair (table fetched through the scalar cache) or a VGPR pair */
-#define PHF_FMA_KX(p, t, c, in_vgpr) ((in_vgpr) ? PHF_FMA_KV(p, t, c) : PHF_FMA_K(p, t, c))
-
-PHF_HD double phf_erfcx_finish_kx(double y, double r, phf_ktab k, int in_vgpr) {
+PHF_HD double phf_erfcx_finish_k(double y, double r, phf_ktab k) {
   const double a = y + 4.0, b = phf_fma(2.0, y, 1.0);
   const double t = ((y - 4.0) * b) * r;
   const double t2 = t * t;
   double pe = k[22], po = k[21];
   PHF_UNROLL
   for (int i = 20; i >= 0; i -= 2) {               /* even and odd chains alternate: neighbours are independent */
-    pe = PHF_FMA_KX(pe, t2, k[i], in_vgpr);
-    if (i >= 2) po = PHF_FMA_KX(po, t2, k[i - 1], in_vgpr);
+    pe = PHF_FMA_K(pe, t2, k[i]);
+    if (i >= 2) po = PHF_FMA_K(po, t2, k[i - 1]);
   }
   const double p = phf_fma(po, t, pe);
   return (p * a) * r;
 }
 
-PHF_HD double phf_erfcx_finish_k(double y, double r, phf_ktab k) { return phf_erfcx_finish_kx(y, r, k, 0); }
-
 /* two arguments at once: the four Horner chains advance in turn */
-PHF_HD void phf_erfcx_finish_x2_kx(double y0, double r0, double y1, double r1, phf_ktab k, int in_vgpr, double* e0, double* e1) {
+PHF_HD void phf_erfcx_finish_x2_k(double y0, double r0, double y1, double r1, phf_ktab k, double* e0, double* e1) {
   const double a0 = y0 + 4.0, b0 = phf_fma(2.0, y0, 1.0), a1 = y1 + 4.0, b1 = phf_fma(2.0, y1, 1.0);
   const double t0 = ((y0 - 4.0) * b0) * r0, t1 = ((y1 - 4.0) * b1) * r1;
   const double s0 = t0 * t0, s1 = t1 * t1;
   double pe0 = k[22], pe1 = k[22], po0 = k[21], po1 = k[21];
   PHF_UNROLL
   for (int i = 20; i >= 0; i -= 2) {
-    pe0 = PHF_FMA_KX(pe0, s0, k[i], in_vgpr);
-    pe1 = PHF_FMA_KX(pe1, s1, k[i], in_vgpr);
+    pe0 = PHF_FMA_K(pe0, s0, k[i]);
+    pe1 = PHF_FMA_K(pe1, s1, k[i]);
     if (i >= 2) {
-      po0 = PHF_FMA_KX(po0, s0, k[i - 1], in_vgpr);
-      po1 = PHF_FMA_KX(po1, s1, k[i - 1], in_vgpr);
+      po0 = PHF_FMA_K(po0, s0, k[i - 1]);
+      po1 = PHF_FMA_K(po1, s1, k[i - 1]);
     }
   }
   *e0 = (phf_fma(po0, t0, pe0) * a0) * r0;
@@ -546,18 +544,14 @@ PHF_HD double phf_log_ndtr_nonpos(double x) {
 }
 
 /* two at once, sharing one division for the two erfcx */
-PHF_HD void phf_log_ndtr_nonpos_x2_kx(double x0, double x1, double* r0, double* r1, phf_ktab ke, int ke_in_vgpr, phf_ktab kl) {
+PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r1, phf_ktab ke, phf_ktab kl) {
   const double y0 = -x0 * PHF_INV_SQRT2, y1 = -x1 * PHF_INV_SQRT2;
   const double q0 = phf_erfcx_den(y0), q1 = phf_erfcx_den(y1);
   const double iq = phf_rcp(q0 * q1);
   double e0, e1;
-  phf_erfcx_finish_x2_kx(y0, iq * q1, y1, iq * q0, ke, ke_in_vgpr, &e0, &e1);
+  phf_erfcx_finish_x2_k(y0, iq * q1, y1, iq * q0, ke, &e0, &e1);
   *r0 = phf_fma(-0.5 * x0, x0, phf_log_pos_k(0.5 * e0, kl));
   *r1 = phf_fma(-0.5 * x1, x1, phf_log_pos_k(0.5 * e1, kl));
-}
-
-PHF_HD void phf_log_ndtr_nonpos_x2_k(double x0, double x1, double* r0, double* r1, phf_ktab ke, phf_ktab kl) {
-  phf_log_ndtr_nonpos_x2_kx(x0, x1, r0, r1, ke, 0, kl);
 }
 
 PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1) {
@@ -567,13 +561,11 @@ PHF_HD void phf_log_ndtr_nonpos_x2(double x0, double x1, double* r0, double* r1)
 }
 
 /* one, with the log table from the caller */
-PHF_HD double phf_log_ndtr_nonpos_kx(double x, phf_ktab ke, int ke_in_vgpr, phf_ktab kl) {
+PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab ke, phf_ktab kl) {
   const double yv = -x * PHF_INV_SQRT2;
-  const double e = phf_erfcx_finish_kx(yv, phf_rcp(phf_erfcx_den(yv)), ke, ke_in_vgpr);
+  const double e = phf_erfcx_finish_k(yv, phf_rcp(phf_erfcx_den(yv)), ke);
   return phf_fma(-0.5 * x, x, phf_log_pos_k(0.5 * e, kl));
 }
-
-PHF_HD double phf_log_ndtr_nonpos_k(double x, phf_ktab ke, phf_ktab kl) { return phf_log_ndtr_nonpos_kx(x, ke, 0, kl); }
 
 /* erfc(y), y >= 0, to an ABSOLUTE accuracy of 3.6e-17 through a table — the hierarchical target's form: its truncation masses
  * Phi(b) - Phi(a) = 1 - (erfc(ya) + erfc(yb))/2 need the tails to half an ulp of 1, not to a relative accuracy.  Centres
