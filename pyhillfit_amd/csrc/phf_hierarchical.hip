@@ -62,14 +62,21 @@ struct HierArgs {
   double* row0;
 };
 
-// One lane per chain: the strictly lower triangle of L in LDS ([dim(dim-1)/2][64] doubles, 28..105 KB per wavefront: at most 4
-// wavefronts per CU, one per SIMD), the diagonal d in registers, and all 512 registers for the iteration.  (LDS is what the four
-// groups of C4 compete for — a CU holds its four wavefronts only if their footprints add up to 160 KB: +2.5 KB per wavefront cost
-// 5 % of C4 on one box — so the diagonal, 11..21 doubles that the exp / log tables' shorter coefficient sets pay for, left LDS.)
+// One lane per chain: the strictly lower triangle of L in LDS ([slot][64] doubles, 25..102 KB per wavefront: at most 4 wavefronts per
+// CU, one per SIMD) except its first three rows, which stay in registers like the diagonal d, and all 512 registers for the
+// iteration.  (LDS is what the four groups of C4 compete for — a CU holds its four wavefronts only if their footprints add up to
+// 160 KB: +2.5 KB per wavefront cost 5 % of C4 on one box — so the diagonal, 11..21 doubles that the exp / log tables' shorter
+// coefficient sets pay for, left LDS (C4 18.4 -> 17.5 ms), and then rows 1..3, six elements (16.9 -> 16.4; 4 or 6 rows: the same).)
+// rows 1..kRegRows of L (kRegRows (kRegRows + 1) / 2 elements) stay in registers next to the diagonal
+#ifndef PHF_HIER_REG_ROWS
+#define PHF_HIER_REG_ROWS 3
+#endif
+constexpr int kRegRows = PHF_HIER_REG_ROWS;
+constexpr int kRegElems = kRegRows * (kRegRows + 1) / 2;
 template <int NE>
 struct Lds {
   static constexpr int dim = 5 + 2 * NE;
-  static constexpr int slots = dim * (dim - 1) / 2;
+  static constexpr int slots = dim * (dim - 1) / 2 - kRegElems;
   static size_t point_bytes(int stride) { return (size_t)stride * 16 + (NE + 1) * 4 + 8; }
   static size_t bytes(int stride) { return (size_t)slots * kBlock * 8 + point_bytes(stride); }
 };
@@ -93,8 +100,10 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
   double* sL = s_mem + threadIdx.x;                        // element (i, k < i) of L: sL[(i (i - 1) / 2 + k) * 64]; the diagonal d: dg[]
-#define PHF_LGET(i, k) sL[((i) * ((i) - 1) / 2 + (k)) * kBlock]
-#define PHF_LSET(i, k, v) sL[((i) * ((i) - 1) / 2 + (k)) * kBlock] = (v)
+  double Lreg[kRegElems > 0 ? kRegElems : 1];              // rows 1..kRegRows
+#define PHF_LIDX(i, k) ((i) * ((i) - 1) / 2 + (k))
+#define PHF_LGET(i, k) (((i) <= kRegRows) ? Lreg[((i) <= kRegRows) ? PHF_LIDX(i, k) : 0] : sL[(PHF_LIDX(i, k) - kRegElems) * kBlock])
+#define PHF_LSET(i, k, v) do { if ((i) <= kRegRows) Lreg[((i) <= kRegRows) ? PHF_LIDX(i, k) : 0] = (v); else sL[(PHF_LIDX(i, k) - kRegElems) * kBlock] = (v); } while (0)
   const int C = a.prob.chains_per_problem;
   const uint32_t pid = a.prob.problem_id[q];
   const uint32_t cid = a.prob.chain_id_base + (a.prob.chain_offset ? a.prob.chain_offset[q] : 0u) + (uint32_t)c;
@@ -252,6 +261,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #undef PHF_PLAIN_LU
 #undef PHF_LGET
 #undef PHF_LSET
+#undef PHF_LIDX
 #undef PHF_SP
 }
 
