@@ -374,44 +374,31 @@ PHF_HD double phf_hier_log_target_any(int n_expts, const int* expt_start, const 
   return phf_hier_log_target_n(n_expts, 0, expt_start, lc, y, th, ts, pr, k_exp, k_log);
 }
 
-/* Draws of hierarchical MH iteration t: dim standard normals into z[i*zs] (Box-Muller, two pairs per Philox block,
- * blocks 0..ceil(dim/4)-1) and log(u) of the accept uniform (block ceil(dim/4)).                                 */
-PHF_HD void phf_box_muller_k(uint32_t w1, uint32_t w2, double* z0, double* z1, phf_ktab k_log, phf_ktab k_sc) {
-  const double ua = phf_unit_open32(w1);
-  const double rad = phf_sqrt_pos(-2.0 * phf_log_pos_k(ua, k_log));
-  double sn, cs;
-  phf_sincos_2pi_u32_k(w2, &sn, &cs, k_sc);
-  *z0 = rad * cs;
-  *z1 = rad * sn;
-}
-
-/* k_sc_resident: the 12 sin/cos coefficients already in registers, or NULL (a literal at the call site): fetched through the
- * scalar cache here (builds that have no VGPRs to spare for them).                                                */
+/* Draws of hierarchical MH iteration t: Philox blocks 0..NB-1, NB = ceil(dim/4); word j of block b is standard normal 4 b + j
+ * (phf_normal_u32: the piecewise inverse CDF of one word, as in the single-level sampler) for 4 b + j < dim; dim = 5 + 2 Ne is odd,
+ * so the last block always has a word to spare, and its LAST word is the accept uniform u = (w + 1/2) / 2^32 (32 bits, like
+ * single-level model 2: log u >= -22.9).  Returns log(u); the normals go to z[i*zs].
+ * (Rounds 1-3 first half: two Box-Muller pairs per block and one more block for a 53-bit uniform.)                      */
 PHF_HD double phf_hier_draws_k(int dim, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
-                               uint32_t seed_hi, phf_ktab k_log, phf_ktab k_sc_resident, int sc_resident, double* z, int zs) {
-  PHF_KFETCH_UNLESS(k_sc, sc_resident, k_sc_resident, phf_k_sincos, 12);
+                               uint32_t seed_hi, phf_ktab k_log, double* z, int zs) {
   const int nb = (dim + 3) / 4;
+  uint32_t w_u = 0u;
   PHF_UNROLL
   for (int b = 0; b < nb; ++b) {
     const phf_u32x4 w = phf_philox4x32_10(chain_id, problem_id, t, (uint32_t)b, seed_lo, seed_hi);
-    double z0, z1, z2, z3;
-    phf_box_muller_k(w.w[0], w.w[1], &z0, &z1, k_log, k_sc);
-    phf_box_muller_k(w.w[2], w.w[3], &z2, &z3, k_log, k_sc);
     const int i = 4 * b;
-    z[i * zs] = z0;
-    if (i + 1 < dim) z[(i + 1) * zs] = z1;
-    if (i + 2 < dim) z[(i + 2) * zs] = z2;
-    if (i + 3 < dim) z[(i + 3) * zs] = z3;
+    z[i * zs] = phf_normal_u32(w.w[0]);
+    if (i + 1 < dim) z[(i + 1) * zs] = phf_normal_u32(w.w[1]);
+    if (i + 2 < dim) z[(i + 2) * zs] = phf_normal_u32(w.w[2]);
+    if (i + 3 < dim) z[(i + 3) * zs] = phf_normal_u32(w.w[3]);
+    if (b == nb - 1) w_u = w.w[3];
   }
-  const phf_u32x4 wu = phf_philox4x32_10(chain_id, problem_id, t, (uint32_t)nb, seed_lo, seed_hi);
-  const double u = phf_uniform53(wu.w[0], wu.w[1]);
-  return phf_log_fast_k(u, k_log);
+  return phf_log_pos_k(phf_unit_open32(w_u), k_log);
 }
 
 PHF_HD double phf_hier_draws(int dim, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
                              uint32_t seed_hi, phf_ktab k_log, double* z, int zs) {
-  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
-  return phf_hier_draws_k(dim, chain_id, problem_id, t, seed_lo, seed_hi, k_log, k_sc, 1, z, zs);
+  return phf_hier_draws_k(dim, chain_id, problem_id, t, seed_lo, seed_hi, k_log, z, zs);
 }
 
 #endif /* PHF_HIER_MODEL_H */

@@ -62,14 +62,15 @@ struct HierArgs {
   double* row0;
 };
 
-// One lane per chain: the strictly lower triangle of L in LDS ([slot][64] doubles, 25..102 KB per wavefront: at most 4 wavefronts per
-// CU, one per SIMD) except its first three rows, which stay in registers like the diagonal d, and all 512 registers for the
-// iteration.  (LDS is what the four groups of C4 compete for — a CU holds its four wavefronts only if their footprints add up to
-// 160 KB: +2.5 KB per wavefront cost 5 % of C4 on one box — so the diagonal, 11..21 doubles that the exp / log tables' shorter
-// coefficient sets pay for, left LDS (C4 18.4 -> 17.5 ms), and then rows 1..3, six elements (16.9 -> 16.4; 4 or 6 rows: the same).)
+// One lane per chain: the strictly lower triangle of L in LDS ([slot][64] doubles, 17..95 KB per wavefront: at most 4 wavefronts per
+// CU, one per SIMD) except its first six rows (21 elements), which stay in registers like the diagonal d, and all 512 registers
+// for the iteration.  (LDS is what the four groups of C4 compete for — a CU holds its four wavefronts only if their footprints add
+// up to 160 KB: +2.5 KB per wavefront cost 5 % of C4 on one box — so the diagonal, 11..21 doubles that the exp / log tables'
+// shorter coefficient sets pay for, left LDS (C4 18.4 -> 17.5 ms), then rows 1..3 (16.9 -> 16.4), then — with the 3 KB table of
+// the inverse-CDF normals coming in and the sin/cos coefficients going out — rows 4..6 (16.5 -> 16.0).)
 // rows 1..kRegRows of L (kRegRows (kRegRows + 1) / 2 elements) stay in registers next to the diagonal
 #ifndef PHF_HIER_REG_ROWS
-#define PHF_HIER_REG_ROWS 3
+#define PHF_HIER_REG_ROWS 6
 #endif
 constexpr int kRegRows = PHF_HIER_REG_ROWS;
 constexpr int kRegElems = kRegRows * (kRegRows + 1) / 2;
@@ -133,7 +134,6 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   // coefficient tables in VGPRs for the launch: a lone wavefront cannot hide the scalar-load latency
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
-  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
 
   const bool want_moments = a.moments != nullptr;
@@ -158,7 +158,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   double log_u;
   {
     double z0[D];
-    log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(a.t_begin + 1), seed_lo, seed_hi, k_log, k_sc, 1, z0, 1);
+    log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(a.t_begin + 1), seed_lo, seed_hi, k_log, z0, 1);
     PHF_PLAIN_LU(z0, y);
   }
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
@@ -184,7 +184,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #pragma unroll
       for (int k = 0; k < i; ++k) Lr[i * (i - 1) / 2 + k] = PHF_LGET(i, k);
     double zn[D];
-    log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, k_sc, 1, zn, 1);
+    log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, zn, 1);
     // ---- adaptation (:495-501): cov <- (1-g) cov + g v v' applied to the L D L' factors as a rank-one update (PHF_LDL_COLUMN),
     // and the next proposal's y = L' sqrt(D') z' accumulated from the new elements while they are in registers.  Before the
     // adaptation starts the sweep runs with g = 0 — an exact no-op on mean, loga, d and L (x + 0 y) that still delivers y — so
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(kBlock, 1) void hier_advance_kernel(const HierArgs 
   extern __shared__ double s_mem[];
   PHF_MATH_TABLES_TO_LDS();
   PHF_ERFC_TABLE_TO_LDS();
+  PHF_NORMAL_TABLE_TO_LDS();
   double* s_lc = s_mem + (size_t)Lds<NE>::slots * kBlock;
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
@@ -319,8 +320,8 @@ struct Lds2 {
   static constexpr int A = (dim + 1) / 2;
   static constexpr int slots = A * A;                      // pair-row a: 2a+1 slots; lane 1's diagonals in its unused last pair-row
   // constants read through LDS (wave-uniform addresses: broadcast reads on the LDS pipe) instead of occupying scalar or vector
-  // registers: the 12 sin/cos coefficients and the 15 prior parameters
-  static constexpr int consts = 12 + 15;
+  // registers: the 15 prior parameters
+  static constexpr int consts = 15;
   static size_t point_bytes(int stride) { return (size_t)stride * 16 + (NE + 1) * 4 + 8; }
   static size_t bytes(int stride) { return (size_t)(slots * kBlock + consts) * 8 + point_bytes(stride); }
 };
@@ -336,7 +337,7 @@ __device__ __forceinline__ double phf_dpp_quad(double v, const int ctrl_tag) {
 #define PHF_FROM_LANE(hsrc, v) phf_dpp_quad((v), (hsrc))
 #define PHF_FROM_PARTNER(v) phf_dpp_quad((v), 2)
 
-// WPS = wavefronts per SIMD the body is compiled for.  2: 256 registers — the sin/cos coefficients and the prior
+// WPS = wavefronts per SIMD the body is compiled for.  2: 256 registers — the prior
 // parameters are read through LDS (s_k) where they are used; 1: 512 registers — every table resident in registers, the prior in
 // scalar registers (launches whose wavefronts have a SIMD each: nothing would hide an LDS or scalar-cache latency).
 template <int NE, int FIXED_N, int WPS>
@@ -383,13 +384,7 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
   double nacc = PHF_SP(2 * D + 2 + TRI);
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);                      // used by every polynomial of the iteration: registers
   PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
-  double kv_sc[WPS == 1 ? 12 : 1];
-  if (WPS == 1) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { kv_sc[WPS == 1 ? i : 0] = phf_k_sincos[i]; asm volatile("" : "+v"(kv_sc[WPS == 1 ? i : 0])); }
-  }
-  const phf_ktab k_sc = (WPS == 1) ? kv_sc : s_k;
-  const phf_hier_prior* const prior = (WPS == 1) ? &a.prior : reinterpret_cast<const phf_hier_prior*>(s_k + 12);
+  const phf_hier_prior* const prior = (WPS == 1) ? &a.prior : reinterpret_cast<const phf_hier_prior*>(s_k);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
 
   const bool want_moments = a.moments != nullptr;
@@ -401,37 +396,34 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
   double* const mom = want_moments ? a.moments + (size_t)h * nchains + g : nullptr;
 
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
-    // ---- draws: block b by lane b mod 2 — normals 4b..4b+3 for b < NB, the accept uniform for b = NB (phf_hier_draws) ----
+    // ---- draws (phf_hier_draws): block b by lane b mod 2 — word j of block b is normal 4b + j, the last word of block NB - 1 the accept uniform ----
     double z[D];
     double log_u = 0.0;
     {
       constexpr int NB = (D + 3) / 4;
-      constexpr int J = (NB + 2) / 2;                      // evaluations per lane: blocks 2j + h, j < J, cover 0..NB
+      constexpr int J = (NB + 1) / 2;                      // evaluations per lane: blocks 2j + h, j < J, cover 0..NB-1
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int b0 = 2 * j, b1 = 2 * j + 1;              // lane 0's block, lane 1's block
         const phf_u32x4 w = phf_philox4x32_10(cid, pid, (uint32_t)t, (uint32_t)(2 * j + h), seed_lo, seed_hi);
-        const bool first_pair = (b0 < NB) || (b1 < NB);                                  // normals 4b, 4b+1 always exist for b < NB
-        const bool second_pair = (b0 < NB && 4 * b0 + 2 < D) || (b1 < NB && 4 * b1 + 2 < D);
-        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
-        if (first_pair) phf_box_muller_k(w.w[0], w.w[1], &n0, &n1, k_log, k_sc);
-        if (second_pair) phf_box_muller_k(w.w[2], w.w[3], &n2, &n3, k_log, k_sc);
-        if (b0 < NB) {
-          z[4 * b0] = PHF_FROM_LANE(0, n0);
-          if (4 * b0 + 1 < D) z[4 * b0 + 1] = PHF_FROM_LANE(0, n1);
-          if (4 * b0 + 2 < D) z[4 * b0 + 2] = PHF_FROM_LANE(0, n2);
-          if (4 * b0 + 3 < D) z[4 * b0 + 3] = PHF_FROM_LANE(0, n3);
-        }
+        const bool need1 = (4 * b0 + 1 < D) || (b1 < NB && 4 * b1 + 1 < D);
+        const bool need2 = (4 * b0 + 2 < D) || (b1 < NB && 4 * b1 + 2 < D);
+        const bool need3 = (4 * b0 + 3 < D) || (b1 < NB && 4 * b1 + 3 < D);
+        const double n0 = phf_normal_u32(w.w[0]);
+        const double n1 = need1 ? phf_normal_u32(w.w[1]) : 0.0, n2 = need2 ? phf_normal_u32(w.w[2]) : 0.0, n3 = need3 ? phf_normal_u32(w.w[3]) : 0.0;
+        z[4 * b0] = PHF_FROM_LANE(0, n0);
+        if (4 * b0 + 1 < D) z[4 * b0 + 1] = PHF_FROM_LANE(0, n1);
+        if (4 * b0 + 2 < D) z[4 * b0 + 2] = PHF_FROM_LANE(0, n2);
+        if (4 * b0 + 3 < D) z[4 * b0 + 3] = PHF_FROM_LANE(0, n3);
         if (b1 < NB) {
           z[4 * b1] = PHF_FROM_LANE(1, n0);
           if (4 * b1 + 1 < D) z[4 * b1 + 1] = PHF_FROM_LANE(1, n1);
           if (4 * b1 + 2 < D) z[4 * b1 + 2] = PHF_FROM_LANE(1, n2);
           if (4 * b1 + 3 < D) z[4 * b1 + 3] = PHF_FROM_LANE(1, n3);
         }
-        if (b0 == NB || b1 == NB) {
-          const double u = phf_uniform53(w.w[0], w.w[1]);
-          const double v = phf_log_fast_k(u, k_log);
-          log_u = PHF_FROM_LANE((b0 == NB) ? 0 : 1, v);
+        if (b0 == NB - 1 || b1 == NB - 1) {
+          const double v = phf_log_pos_k(phf_unit_open32(w.w[3]), k_log);
+          log_u = PHF_FROM_LANE((b0 == NB - 1) ? 0 : 1, v);
         }
       }
     }
@@ -587,6 +579,7 @@ template <int NE, int WPS>
 __global__ __launch_bounds__(kBlock, WPS) void hier_advance2_kernel(const HierArgs a) {
   PHF_MATH_TABLES_TO_LDS();
   PHF_ERFC_TABLE_TO_LDS();
+  PHF_NORMAL_TABLE_TO_LDS();
   extern __shared__ double s_mem[];
   double* s_k = s_mem + (size_t)Lds2<NE>::slots * kBlock;
   double* s_lc = s_k + Lds2<NE>::consts;
@@ -597,12 +590,11 @@ __global__ __launch_bounds__(kBlock, WPS) void hier_advance2_kernel(const HierAr
   const int q = a.prob.launch_order ? a.prob.launch_order[slot] : slot;
   const int c0 = chunk * kChains2;
   const int pair = a.prob.pair_index[q];
-  if (threadIdx.x < 12) s_k[threadIdx.x] = phf_k_sincos[threadIdx.x];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {                            // static indices: a run-time index would copy the argument block to scratch
-    if (threadIdx.x == 12 + i) s_k[12 + i] = a.prior.shape_m1[i];
-    if (threadIdx.x == 17 + i) s_k[17 + i] = a.prior.inv_scale[i];
-    if (threadIdx.x == 22 + i) s_k[22 + i] = a.prior.loc[i];
+    if (threadIdx.x == i) s_k[i] = a.prior.shape_m1[i];
+    if (threadIdx.x == 5 + i) s_k[5 + i] = a.prior.inv_scale[i];
+    if (threadIdx.x == 10 + i) s_k[10 + i] = a.prior.loc[i];
   }
   stage<NE>(a.pts, pair, s_lc, s_y, s_es);
   if (c0 + (int)(threadIdx.x >> 1) >= a.prob.chains_per_problem) return;    // both lanes of a chain leave together
@@ -616,6 +608,7 @@ template <int NE>
 __global__ __launch_bounds__(kBlock) void hier_init_kernel(const HierArgs a) {
   PHF_MATH_TABLES_TO_LDS();
   PHF_ERFC_TABLE_TO_LDS();
+  PHF_NORMAL_TABLE_TO_LDS();
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
   extern __shared__ double s_mem[];
@@ -661,6 +654,7 @@ __global__ __launch_bounds__(kBlock) void hier_log_target_kernel(const phf_hier_
                                                                  const int32_t* pair_index, const double* theta, double* out) {
   PHF_MATH_TABLES_TO_LDS();
   PHF_ERFC_TABLE_TO_LDS();
+  PHF_NORMAL_TABLE_TO_LDS();
   constexpr int D = 5 + 2 * NE;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= m) return;
@@ -701,6 +695,7 @@ struct WaveLds {
 __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArgs a) {
   PHF_MATH_TABLES_TO_LDS();
   PHF_ERFC_TABLE_TO_LDS();
+  PHF_NORMAL_TABLE_TO_LDS();
   extern __shared__ double s_mem[];
   const int ne = a.pts.n_expts;
   const int D = 5 + 2 * ne;
@@ -739,7 +734,6 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
   double lt = sp[(size_t)D * nch], loga = sp[(size_t)(2 * D + 1 + TRI) * nch], nacc = sp[(size_t)(2 * D + 2 + TRI) * nch];
   PHF_KFETCH_V(k_exp, phf_k_exp, PHF_K_EXP_N);
   PHF_KFETCH_V(k_log, phf_k_log, PHF_K_LOG_N);
-  PHF_KFETCH_V(k_sc, phf_k_sincos, 12);
   double sc = phf_exp_fast_k(0.5 * loga, k_exp);
   const int thin = a.cfg.thinning;
   int until_save = thin - (int)(a.t_begin % thin);
@@ -748,21 +742,17 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
   const int nb = (D + 3) / 4;
 
   for (int64_t t = a.t_begin + 1; t <= a.t_end; ++t) {
-    // ---- draws: Philox block b -> normals 4b..4b+3 (as phf_hier_draws), lane b; the accept uniform in every lane ----
+    // ---- draws (phf_hier_draws): Philox block b -> normals 4b..4b+3, lane b; the accept uniform (last word of the last block) in every lane ----
     for (int b = lane; b < nb; b += kBlock) {
       const phf_u32x4 w = phf_philox4x32_10(cid, pid, (uint32_t)t, (uint32_t)b, seed_lo, seed_hi);
-      double z0, z1, z2, z3;
-      phf_box_muller_k(w.w[0], w.w[1], &z0, &z1, k_log, k_sc);
-      phf_box_muller_k(w.w[2], w.w[3], &z2, &z3, k_log, k_sc);
       const int i = 4 * b;
-      s_z[i] = z0;
-      if (i + 1 < D) s_z[i + 1] = z1;
-      if (i + 2 < D) s_z[i + 2] = z2;
-      if (i + 3 < D) s_z[i + 3] = z3;
+      s_z[i] = phf_normal_u32(w.w[0]);
+      if (i + 1 < D) s_z[i + 1] = phf_normal_u32(w.w[1]);
+      if (i + 2 < D) s_z[i + 2] = phf_normal_u32(w.w[2]);
+      if (i + 3 < D) s_z[i + 3] = phf_normal_u32(w.w[3]);
     }
-    const phf_u32x4 wu = phf_philox4x32_10(cid, pid, (uint32_t)t, (uint32_t)nb, seed_lo, seed_hi);
-    const double u = phf_uniform53(wu.w[0], wu.w[1]);
-    const double log_u = phf_log_fast_k(u, k_log);
+    const phf_u32x4 wu = phf_philox4x32_10(cid, pid, (uint32_t)t, (uint32_t)(nb - 1), seed_lo, seed_hi);
+    const double log_u = phf_log_pos_k(phf_unit_open32(wu.w[3]), k_log);
     __syncthreads();
     // ---- proposal theta* = theta + e^(loga/2) L sqrt(D) z: u = sqrt(d) z in place, then rows lane, lane+64, ... ----
     for (int i = lane; i < D; i += kBlock) s_z[i] = phf_sqrt_nonneg(sLm[i * (i + 1) / 2 + i]) * s_z[i];
@@ -859,6 +849,7 @@ __global__ __launch_bounds__(kBlock) void hier_wave_advance_kernel(const HierArg
 __global__ __launch_bounds__(64) void hier_generic_init_kernel(const HierArgs a) {
   PHF_MATH_TABLES_TO_LDS();
   PHF_ERFC_TABLE_TO_LDS();
+  PHF_NORMAL_TABLE_TO_LDS();
   const int ne = a.pts.n_expts;
   const int D = 5 + 2 * ne;
   const int q = blockIdx.x / a.blocks_per_problem;
@@ -894,6 +885,7 @@ __global__ __launch_bounds__(64) void hier_generic_log_target_kernel(const phf_h
                                                                      const int32_t* pair_index, const double* theta, double* out) {
   PHF_MATH_TABLES_TO_LDS();
   PHF_ERFC_TABLE_TO_LDS();
+  PHF_NORMAL_TABLE_TO_LDS();
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= m) return;
   const int ne = pts.n_expts;
@@ -952,8 +944,8 @@ HierPolicy& hier_policy() {                                       // first use r
 int hier_lanes_override() { return hier_policy().lanes; }
 int hier_wps_override() { return hier_policy().wps; }
 
-// a workgroup's 160 KB of LDS less the static part every kernel here has: the exp / log and erfc tables of phf_math.h
-constexpr size_t kMaxDynamicLds = 160 * 1024 - PHF_MATH_LDS_BYTES - PHF_ERFC_TAB_N * sizeof(phf_erfctab);
+// a workgroup's 160 KB of LDS less the static part every kernel here has: the exp / log, erfc and normal tables of phf_math.h
+constexpr size_t kMaxDynamicLds = 160 * 1024 - PHF_MATH_LDS_BYTES - PHF_ERFC_TAB_N * sizeof(phf_erfctab) - PHF_NORMAL_TAB_N * sizeof(phf_normtab);
 
 template <typename K>
 int allow_big_lds(K kernel, bool* configured) {                   // the attribute is per function AND per device
