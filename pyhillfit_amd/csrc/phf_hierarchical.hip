@@ -62,22 +62,26 @@ struct HierArgs {
   double* row0;
 };
 
-// One lane per chain: the strictly lower triangle of L in LDS ([slot][64] doubles, 17..95 KB per wavefront: at most 4 wavefronts per
-// CU, one per SIMD) except its first six rows (21 elements), which stay in registers like the diagonal d, and all 512 registers
-// for the iteration.  (LDS is what the four groups of C4 compete for — a CU holds its four wavefronts only if their footprints add
-// up to 160 KB: +2.5 KB per wavefront cost 5 % of C4 on one box — so the diagonal, 11..21 doubles that the exp / log tables'
-// shorter coefficient sets pay for, left LDS (C4 18.4 -> 17.5 ms), then rows 1..3 (16.9 -> 16.4), then — with the 3 KB table of
-// the inverse-CDF normals coming in and the sin/cos coefficients going out — rows 4..6 (16.5 -> 16.0).)
-// rows 1..kRegRows of L (kRegRows (kRegRows + 1) / 2 elements) stay in registers next to the diagonal
-#ifndef PHF_HIER_REG_ROWS
-#define PHF_HIER_REG_ROWS 6
+// One lane per chain: what of the strictly lower triangle of L does not stay in registers lives in LDS ([slot][64] doubles: 0 KB at
+// Ne = 3, 11.5 KB at Ne = 4, 28..76 KB at Ne = 5..8; at most 4 wavefronts per CU, one per SIMD), the diagonal d in registers,
+// and all 512 registers for the iteration.  (LDS is what the four groups of C4 compete for — a CU holds its four wavefronts only
+// if their footprints add up to 160 KB: +2.5 KB per wavefront cost 5 % of C4 on one box — so the diagonal, 11..21 doubles that the
+// exp / log tables' shorter coefficient sets pay for, left LDS (C4 18.4 -> 17.5 ms), then rows 1..3 (16.9 -> 16.4), then — with
+// the 3 KB table of the inverse-CDF normals coming in and the sin/cos coefficients going out — rows 4..6 (16.5 -> 16.0), then
+// rows 7..10 for Ne <= 4 (15.8 -> 15.2).)
+// rows 1..reg_rows of L (reg_rows (reg_rows + 1) / 2 elements) stay in registers next to the diagonal: all of them for Ne = 3 (55
+// elements; hipcc parks them in the accumulation registers), ten rows of twelve for Ne = 4, six beyond (Ne = 5 with ten rows: +32 %,
+// it spills) — measured on C4 and per group, profiles/r03/math_tables_ab.txt items 8-10
+#ifndef PHF_HIER_REG_ROWS_SMALL
+#define PHF_HIER_REG_ROWS_SMALL 10
 #endif
-constexpr int kRegRows = PHF_HIER_REG_ROWS;
-constexpr int kRegElems = kRegRows * (kRegRows + 1) / 2;
 template <int NE>
 struct Lds {
   static constexpr int dim = 5 + 2 * NE;
-  static constexpr int slots = dim * (dim - 1) / 2 - kRegElems;
+  static constexpr int want_rows = (NE <= 4) ? PHF_HIER_REG_ROWS_SMALL : 6;
+  static constexpr int reg_rows = want_rows < dim - 1 ? want_rows : dim - 1;
+  static constexpr int reg_elems = reg_rows * (reg_rows + 1) / 2;
+  static constexpr int slots = dim * (dim - 1) / 2 - reg_elems;
   static size_t point_bytes(int stride) { return (size_t)stride * 16 + (NE + 1) * 4 + 8; }
   static size_t bytes(int stride) { return (size_t)slots * kBlock * 8 + point_bytes(stride); }
 };
@@ -101,6 +105,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
   double* sL = s_mem + threadIdx.x;                        // element (i, k < i) of L: sL[(i (i - 1) / 2 + k) * 64]; the diagonal d: dg[]
+  constexpr int kRegRows = Lds<NE>::reg_rows, kRegElems = Lds<NE>::reg_elems;
   double Lreg[kRegElems > 0 ? kRegElems : 1];              // rows 1..kRegRows
 #define PHF_LIDX(i, k) ((i) * ((i) - 1) / 2 + (k))
 #define PHF_LGET(i, k) (((i) <= kRegRows) ? Lreg[((i) <= kRegRows) ? PHF_LIDX(i, k) : 0] : sL[(PHF_LIDX(i, k) - kRegElems) * kBlock])
