@@ -167,7 +167,7 @@ class HierarchicalBatch(object):
     units: None = every pair with chains [chain_id_base, chain_id_base + C); or this rank's (pair, 64-chain block) units
     (distributed.shard_blocks over all 210 pairs) — each block then is a problem of 64 chains with its own chain offset."""
     is_hier = True
-    kernel_name = "hier_advance_kernel<Ne=3,4> + hier_advance2_kernel<Ne=5,6> (one stream each)"
+    kernel_name = "hier_advance_kernel<Ne=3..6> (one stream each; hier_advance2_kernel for groups that do not fill the chip together)"
 
     def __init__(self, dr, names, C, thinning, chain_id_base, dev, torch, units=None):
         from pyhillfit_amd import hierarchical as H
@@ -199,6 +199,7 @@ class HierarchicalBatch(object):
         self.adapt_start = max(h.adapt_start for h in self.samplers)
         self.bytes_per_iter = sum(h.Q * h.C * 8.0 * (h.d + 1) for h in self.samplers) / thinning
         self.chains = sum(h.Q * h.C for h in self.samplers)
+        H.set_kernel_policy_for(self.chains)               # the groups run side by side: one lane per chain once they fill the chip together
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.samplers]
 
     def enable_moments(self):

@@ -109,6 +109,23 @@ def set_kernel_policy(lanes=0, wps=0):
     _lib.check(lib.phf_hierarchical_set_kernel_policy(int(lanes), int(wps)), "phf_hierarchical_set_kernel_policy")
 
 
+def simd_count():
+    """SIMDs of the current device (phf_simd_count)."""
+    return int(_lib.load().phf_simd_count())
+
+
+def set_kernel_policy_for(concurrent_chains):
+    """Called by whoever runs SEVERAL samplers side by side (one per Ne group, one stream each): the library decides one launch
+    at a time — two lanes per chain when that group's wavefronts would leave SIMDs idle —, but when the groups TOGETHER give every
+    SIMD a one-lane wavefront, a two-lane wavefront (half the latency, 1.7x the SIMD time) only takes slots from the others:
+    C4 15.15 -> 14.5 ms with one lane everywhere.  concurrent_chains: chains of all the samplers running concurrently.
+    PHF_HIER_LANES in the environment keeps the last word."""
+    import os
+    if os.environ.get("PHF_HIER_LANES"):
+        return
+    set_kernel_policy(lanes=1 if -(-int(concurrent_chains) // 64) >= simd_count() else 0)
+
+
 def log_target_batch(packed, pair_index, theta, prior=None, device="cuda"):
     """log_target_distribution (PyHillFit.py:173-193) of M parameter vectors theta[M][dim] on the GPU."""
     lib = _lib.load(); _bind(lib)
@@ -294,6 +311,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
                 curves.accumulate(s.row0.unsqueeze(0).contiguous(), cdf_chains(args, C))
         runs.append(dict(ne=ne, members=members, theta0=theta0, s=s, kept=kept, buf=buf, seg=seg, r=1, curves=curves, files=files,
                          stream=torch.cuda.Stream(device=device)))
+    set_kernel_policy_for(sum(r["s"].Q * r["s"].C for r in runs))
     torch.cuda.synchronize(device)
     start = time.time()
     done = 0
