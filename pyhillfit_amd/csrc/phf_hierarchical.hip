@@ -75,10 +75,13 @@ struct HierArgs {
 #ifndef PHF_HIER_REG_ROWS_SMALL
 #define PHF_HIER_REG_ROWS_SMALL 10
 #endif
+#ifndef PHF_HIER_REG_ROWS_BIG
+#define PHF_HIER_REG_ROWS_BIG 6
+#endif
 template <int NE>
 struct Lds {
   static constexpr int dim = 5 + 2 * NE;
-  static constexpr int want_rows = (NE <= 4) ? PHF_HIER_REG_ROWS_SMALL : 6;
+  static constexpr int want_rows = (NE <= 4) ? PHF_HIER_REG_ROWS_SMALL : PHF_HIER_REG_ROWS_BIG;
   static constexpr int reg_rows = want_rows < dim - 1 ? want_rows : dim - 1;
   static constexpr int reg_elems = reg_rows * (reg_rows + 1) / 2;
   static constexpr int slots = dim * (dim - 1) / 2 - reg_elems;

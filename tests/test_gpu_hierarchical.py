@@ -163,9 +163,38 @@ def test_zero_variance_direction_behaves_like_the_twin(lanes, gpu, oracle_pair):
         st = pk.init_state(theta0, 0.01)
         rows = pk.advance(st, 0, T, thin, adapt, gamma_table(T), seed=11, chain_id=c, problem_id=3)
         assert np.array_equal(chain[:, 0, :, c], rows) and np.array_equal(state[:, 0, c], st), c
+
         assert np.all(rows[:, 8] == 0.0) and np.isfinite(st).all()
         cov = co.hier_state_covariance(st, d)
         assert np.all(cov[8] == 0.0) and np.all(np.delete(np.diag(cov), 8) > 0.0)
+
+
+def test_policy_for_groups_running_side_by_side(gpu, oracle_pair, monkeypatch):
+    """set_kernel_policy_for: one lane per chain once the concurrent groups give every SIMD a wavefront, the library's own choice
+    below that, PHF_HIER_LANES keeps the last word — and whichever kernel runs, the chain is the same bit for bit"""
+    from pyhillfit_amd import hierarchical as H
+    shapes, scales, locs = H.prior_params()
+    p = oracle_pair("Amiodarone", "hERG")
+    packed = H.PackedHierPoints([p.experiments])
+    theta0 = np.array([H.first_iteration(p.experiments, locs)])
+    assert H.simd_count() >= 64
+
+    def run():
+        s = H.HierarchicalSampler(packed, [0], 64, thinning=5, seed=3, adapt_start=30, device=gpu)
+        s.init(theta0, cov_scale=0.01)
+        return s.advance(100).cpu().numpy()
+    monkeypatch.delenv("PHF_HIER_LANES", raising=False)
+    try:
+        H.set_kernel_policy_for(64 * H.simd_count())               # the chip is full: one lane
+        full = run()
+        H.set_kernel_policy_for(64)                                 # one wavefront: the library's choice (two lanes)
+        small = run()
+        monkeypatch.setenv("PHF_HIER_LANES", "2")
+        H.set_kernel_policy_for(64 * H.simd_count())               # no-op: the environment keeps the last word
+        assert np.array_equal(run(), small)
+    finally:
+        H.set_kernel_policy(0, 0)
+    assert np.array_equal(full, small)
 
 
 @pytest.mark.parametrize("C", [1, 33])
