@@ -482,7 +482,7 @@ __device__ __forceinline__ void hier_advance2_body(const HierArgs& a, double* s_
     }
     // ---- target: this lane's half + the partner's (:486), accept (:487-492) ----
     const int bad = phf_hier_out_of_support(NE, star, 1, prior);
-    const double half = phf_hier_target_half(h, NE, FIXED_N, s_es, s_lc, s_y, star, 1, prior, k_exp, k_log);
+    const double half = phf_hier_target_half(h, NE, FIXED_N, s_es, s_lc, s_y, star, 1, prior, k_exp, k_log, 0);
     const double lt_star = bad ? -PHF_INF : half + PHF_FROM_PARTNER(half);
     const bool acc = log_u < lt_star - lt;
     if (acc) {                                             // own rows out of the full vector (not kept apart across the target: registers)
