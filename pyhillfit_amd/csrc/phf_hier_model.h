@@ -60,8 +60,9 @@ PHF_HD void phf_batch_recip(double* v, int n) {
 /* Truncated-Gaussian term of a point (PyHillFit.py:121-125): the mass Phi(b) - Phi(a), a = (0-pred)/sigma <= 0 <= b = (100-pred)/sigma,
  * = 1 - [erfc(ya) + erfc(yb)]/2 with ya = -a/sqrt2, yb = b/sqrt2 >= 0: both tails from the erfc table of phf_math.h (absolute
  * accuracy below half an ulp of the 1 they are subtracted from; a tail with argument >= PHF_ERFC_CUT = 6 — more than 8.5 sigma
- * from its bound — is DEFINED as zero).  No division, no branch.  The per-Ne target multiplies the masses of a half's points and
- * takes one logarithm (phf_hier_target_half); the per-experiment form takes one per point.
+ * from its bound — is DEFINED as zero).  No division; the only branch is the one-lane kernels' skip of a pair's upper tails
+ * (phf_trunc_mass_x2).  The per-Ne target multiplies the masses of a half's points and takes one logarithm
+ * (phf_hier_target_half); the per-experiment form takes one per point.
  * (Rounds 1-3: erfcx(y) exp(-y^2) per tail, two tails per division, the upper tails of a pair of points skipped under a
  * wave-uniform branch when negligible on every lane — ~50 fp64 operations per tail against 15.)                              */
 PHF_HD double phf_trunc_mass(double pred, double inv_s, phf_ktab kx) {

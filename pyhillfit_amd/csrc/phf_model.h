@@ -7,9 +7,9 @@
  *   log_priors_model_{1,2} :166-184, log_pic50_exponential :151-156, log_gamma_prior :304-317.
  * How it computes it is shaped for the fp64 VALU (see phf_math.h): per-point work is done 4 (uncensored) or
  * 2 (censored) points at a time so independent polynomial chains interleave, and the IEEE divisions of a
- * group — 1/(1+x) of the Hill curve, the erfcx reciprocals — are shared through a product tree
- * (one division + a few multiplies instead of one division each; ~26 ns vs ~2 ns per wave-instruction).
- * Logarithms and exponentials reduce their argument through the LDS tables of phf_math.h (no division).
+ * group — 1/(1+x) of the Hill curves — are shared through a product tree (one division + a few multiplies
+ * instead of one division each).  Logarithms, exponentials, the censored entries' log Phi and the proposals'
+ * normals come from the LDS tables of phf_math.h (no division, no erfcx, no Box-Muller).
  *
  * Entry layout (include/pyhillfit_amd.h, phf_points): n_other uncensored entries first (0 < y < 100), then the
  * n_cens censored ones (y == 0, then y == 100).  Arrays must be readable up to index n_other + n_cens - 1.

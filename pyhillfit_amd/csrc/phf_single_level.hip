@@ -101,10 +101,10 @@ __device__ __forceinline__ void advance_body(const AdvanceArgs& a, const double*
   const uint32_t cid = a.prob.chain_id_base + (a.prob.chain_offset ? a.prob.chain_offset[q] : 0u) + (uint32_t)c;
   uint32_t seed_lo = (uint32_t)a.cfg.seed, seed_hi = (uint32_t)(a.cfg.seed >> 32);
   // Two wavefronts per SIMD (256 registers): the Philox key words as VECTOR values.  As scalars the ten round keys are loop
-  // invariants hipcc hoists into 20 SGPRs and then spills to VGPR lanes around the erfcx polynomials (a v_readlane + s_nop per
-  // round); as vector values they cost registers the scratch spills outside the loop absorb (sgpr_spill_count 236 -> 195,
-  // vgpr_spill_count 96 -> 145): C3 159.1 -> 158.0 ms per 8 000 iterations on one box, twice.  The lone-wavefront build keeps
-  // them scalar (round 2: scalar work is free there, vector issue slots are not).
+  // invariants hipcc hoists into 20 SGPRs and then spills to VGPR lanes (a v_readlane + s_nop per round); as vector values they
+  // cost registers the scratch spills outside the loop absorb: C3 159.1 -> 158.0 ms per 8 000 iterations on one box, twice;
+  // measured again after the table-driven functions (no scalar-memory fetches left to compete for SGPRs): 106.7 as scalars, 104.4
+  // as vectors.  The lone-wavefront build keeps them scalar (round 2: scalar work is free there, vector issue slots are not).
   if (!LONE_WAVE) { asm volatile("" : "+v"(seed_lo)); asm volatile("" : "+v"(seed_hi)); }
   const size_t nchains = (size_t)a.prob.num_problems * C;
   const size_t g = (size_t)q * C + c;
