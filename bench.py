@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: MH samples/sec of the HIP sampler (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--iters-per-step I]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--iters-per-step I] [--model 1|2] [--moments]
 
 A "step" is ONE pass of the sampler over the whole batch: every chain advanced by I Metropolis-Hastings iterations
 (thinned samples of all chains written to HBM).  The N=1 workload is the one BASELINE.json's metric is quoted on,
@@ -17,7 +17,9 @@ shards without a data-path collective (python/PyHillFit.py:978-1003 maps pairs o
   strong scaling:         the (pair, 64-chain block) units of ONE full-size workload are partitioned over the ranks by cost
                           (distributed.shard_blocks: 13 440 blocks -> 1 680 per GPU at 8), every chain keeping its Philox stream.
 With N > 1 BOTH are measured in the same run, one timed region each: `value` is the region --scaling names (weak by default),
-`strong_value` (or `weak_value`) the other.  With N = 1 the c3 run also times short regions of c2, c4 and c5 (`other_workloads`).
+`strong_value` (or `weak_value`) the other.  With N = 1 the c3 run also times short regions of c2, c4, c5 and of the kernels the command
+lines and the thermodynamic-integration path launch — c5 with the on-device <log L> and moments (`c5_moments`), c3 with model 1
+(`c3_model1`) — (`other_workloads`).
 RCCL is used outside the timed regions only: rank 0 reads and packs the data and broadcasts it, the per-problem
 acceptance summaries are gathered to rank 0.  Timing: barrier + synchronize on both sides, MAX over ranks.
 Rank 0 prints ONE JSON line."""
@@ -41,9 +43,13 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 64 fp64 FMA lanes x 2 x 2.4 GHz (vecto
 FP64_VALU_MEASURED_TFLOPS = 58.3  # tools/microbench.hip: v_fma_f64 saturates at 2.25 ns per wave-instruction per SIMD
 
 DEFAULT_CHAINS = {"c2": 65536, "c3": 4096, "c4": 1024, "c5": 1024}
-# c3: 8 000 iterations per step = one queued launch of 160 ms (4 quanta of 2 000), so that the driver's 20 timed steps last > 3 s
-DEFAULT_ITERS = {"c2": 2000, "c3": 8000, "c4": 500, "c5": 500}
-OTHER_STEPS = {"c2": (40, 10), "c4": (20, 6), "c5": (8, 4)}      # (timed steps, warm-up steps) of the short regions after the headline
+# c3: 24 000 iterations per step = one queued launch of ~0.3 s (6 quanta of 4 000), so that the driver's 20 timed steps last > 6 s;
+# c4: 2 000 per step — the command line runs 20 000 per launch, and at 500 a third of the HBM traffic was the state going in and out
+DEFAULT_ITERS = {"c2": 2000, "c3": 24000, "c4": 2000, "c5": 500}
+# (timed steps, warm-up steps) of the short regions after the headline; each region lasts 0.1 .. 0.5 s
+OTHER_STEPS = {"c2": (40, 10), "c4": (8, 3), "c5": (8, 4), "c5_moments": (8, 4), "c3_model1": (3, 2)}
+OTHER_SPECS = {"c2": ("c2", 2, False), "c4": ("c4", 2, False), "c5": ("c5", 2, False),          # name -> (workload, model, moments)
+               "c5_moments": ("c5", 2, True), "c3_model1": ("c3", 1, False)}
 
 
 def profile_facts(workload, chains, iters, thinning):
@@ -108,7 +114,12 @@ def cpu_baseline(budget_s=12.0):
     t0 = time.perf_counter()
     pk.advance(st, 0, n_c, 5, 3000, False, gam, seed=25)
     dtc = time.perf_counter() - t0
+    host_cpus = os.cpu_count() or 1
+    pool = max(1, min(210, host_cpus - 1))                 # mp.Pool(min(num_cores, cpu_count() - 1)) over the pairs, PyHillFit.py:997-1003
     return {"value": iterations / dt, "unit": "MH samples/s", "cores": 1, "kind": "port",
+            "pool_equivalent_value": iterations / dt * pool, "pool_equivalent_processes": pool,
+            "pool_equivalent_note": "the 1-core figure x min(210 pairs, host cpus - 1): what the reference's process pool over pairs "
+                                    "(python/PyHillFit.py:997-1003) would reach on this host if it scaled perfectly — computed, not measured",
             "sample": "%d iterations of 1 chain, Amiodarone-hERG model 2: restatement of the reference loop with the reference's "
                       "own library calls (scipy.stats.norm.logcdf/logsf per iteration, RandomState.multivariate_normal/rand; "
                       "oracle/pyhillfit_oracle.py as_reference=True), %.1f s" % (iterations, dt),
@@ -129,6 +140,7 @@ def parse_args(argv=None):
     ap.add_argument("--thinning", type=int, default=5)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--moments", action="store_true", help="also accumulate posterior moments and <log L> on the device (what the CLIs and the thermodynamic-integration path run)")
+    ap.add_argument("--model", type=int, default=2, choices=[1, 2], help="single-level workloads: 2 = (pIC50, Hill, sigma) (BASELINE configs), 1 = (pIC50, sigma), Hill = 1")
     ap.add_argument("--queue-quanta", type=int, default=None, help="quanta per block of the work-queue launch (0: plain launch; default: the sampler's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="N = 1, c3: skip the short c2 / c4 / c5 regions after the headline")
@@ -255,25 +267,26 @@ class HierarchicalBatch(object):
 class SingleLevelBatch(object):
     """c2 / c3 / c5: one SingleLevelSampler.  units as for HierarchicalBatch (indices into the problem list)."""
     is_hier = False
-    kernel_name = "mh_advance_kernel<2>"
 
     def __init__(self, packed, pair_index, temps, C, a, chain_id_base, dev, torch, tempered, units=None):
         from pyhillfit_amd.sampler import SingleLevelSampler
         self.torch, self.dev = torch, dev
+        model = a.model
+        self.kernel_name = "mh_advance_kernel<%d, %s>" % (model, "moments" if a.moments else "no moments")
         kw = {} if a.queue_quanta is None else {"queue_quanta": a.queue_quanta}
         if units is not None and len(units) == 0:
             raise SystemExit("bench.py: this rank's share of the batch is empty (more ranks than (pair, 64-chain block) units)")
         if units is None:
-            s = SingleLevelSampler(packed, 2, pair_index, temps, C, thinning=a.thinning, seed=25, chain_id_base=chain_id_base,
+            s = SingleLevelSampler(packed, model, pair_index, temps, C, thinning=a.thinning, seed=25, chain_id_base=chain_id_base,
                                    reset_mean_at_adapt_start=tempered, device=dev, **kw)
         else:
-            s = SingleLevelSampler(packed, 2, [pair_index[q] for q, _ in units], [temps[q] for q, _ in units], 64, thinning=a.thinning,
+            s = SingleLevelSampler(packed, model, [pair_index[q] for q, _ in units], [temps[q] for q, _ in units], 64, thinning=a.thinning,
                                    seed=25, problem_ids=[int(q) for q, _ in units], chain_offsets=[64 * int(b) for _, b in units],
                                    reset_mean_at_adapt_start=tempered, device=dev, **kw)
         if tempered:
-            s.init(np.ones(3), cov_identity=True, cov_scale=1.0)          # PyHillTemp.py:63,80 start
+            s.init(np.ones(s.d), cov_identity=True, cov_scale=1.0)        # PyHillTemp.py:63,80 start
         else:
-            s.init([6.0, 0.8, 8.0], cov_identity=False, cov_scale=0.05)   # PyHillFit.py:748-751 start
+            s.init([6.0, 0.8, 8.0] if model == 2 else [6.0, 8.0], cov_identity=False, cov_scale=0.05)   # PyHillFit.py:748-751 start
         self.s = s
         self.adapt_start = s.adapt_start
         self.bytes_per_iter = float(s.Q) * s.C * 8 * (s.d + 1) / a.thinning   # SURVEY 8(d): 8(d+1)/thin B per iteration
@@ -296,13 +309,14 @@ class SingleLevelBatch(object):
         return self.s.acceptance().mean(dim=1)
 
 
-def workload_label(workload, n_pairs, C, per):
+def workload_label(workload, n_pairs, C, per, model=2):
+    m = "model 2 (pIC50, Hill, sigma)" if model == 2 else "model 1 (pIC50, sigma; Hill = 1: doseresponse.py:203-226)"
     if workload == "c2":
-        return "Amiodarone-hERG, non-hierarchical model 2 (pIC50, Hill, sigma), %d chains %s (BASELINE configs[1])" % (C, per)
+        return "Amiodarone-hERG, non-hierarchical %s, %d chains %s (BASELINE configs[1])" % (m, C, per)
     if workload == "c3":
-        return "all %d Crumb drug x channel pairs, non-hierarchical model 2, %d chains each %s (BASELINE configs[2])" % (n_pairs, C, per)
+        return "all %d Crumb drug x channel pairs, non-hierarchical %s, %d chains each %s (BASELINE configs[2])" % (n_pairs, m, C, per)
     if workload == "c5":
-        return "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains %s, model 2 (BASELINE configs[4])" % (n_pairs, C, per)
+        return "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains %s, %s (BASELINE configs[4])" % (n_pairs, C, per, m)
     return ("hierarchical model, all %d Crumb pairs, %d chains each %s (BASELINE configs[3]); one stream per Ne group, "
             "not joined between steps" % (n_pairs, C, per))
 
@@ -341,11 +355,17 @@ def make_batch(workload, scaling, C, a, ctx):
             costs = 525.0 + 28.0 * cnt[:, 0] + 115.0 * (cnt[:, 1] + cnt[:, 2])     # instructions per iteration (sampler.py: launch_order)
             units = D.shard_blocks(costs, C // 64, world)[rank]
         b = SingleLevelBatch(packed, pair_index, temps, C, a, chain_id_base, dev, torch, workload == "c5", units=units)
-    b.label = workload_label(workload, len(names), C, "in all, split by 64-chain blocks over the GPUs" if scaling == "strong" else "per GPU")
+    b.label = workload_label(workload, len(names), C, "in all, split by 64-chain blocks over the GPUs" if scaling == "strong" else "per GPU",
+                             2 if workload == "c4" else a.model)
     if a.moments:
         b.enable_moments()
-        b.label += " + on-device moments"
+        b.label += " + on-device moments and <log L(t=1)> (the sums the command lines and compute_bayes_factors.py:11-27 need)"
     return b
+
+
+def facts_key(workload, a):
+    """the entry of profiles/pmc_facts.json a launch shape goes by: c2 | c3 | c4 | c5, + _model1 / _moments for the other kernels"""
+    return workload + ("_model1" if a.model == 1 and workload != "c4" else "") + ("_moments" if a.moments else "")
 
 
 def timed_region(b, I, steps, warmup, ctx):
@@ -468,7 +488,7 @@ def main():
     out = None
     if rank == 0:
         acc_all = np.concatenate(gathered)
-        roof, fp64 = rooflines(a.workload, b, I, a.thinning, kernel_ms)
+        roof, fp64 = rooflines(facts_key(a.workload, a), b, I, a.thinning, kernel_ms)
         out = {
             "metric": "MCMC samples/sec (whole node)", "value": chains_total * I * a.steps / dt, "unit": "MH samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -497,18 +517,23 @@ def main():
         release(torch)
 
     # ---- N = 1: the other BASELINE configurations, short regions of the same protocol, in the same JSON line ----
-    if world == 1 and a.workload == "c3" and a.chains is None and a.iters_per_step is None and not a.no_other_workloads:
+    if world == 1 and a.workload == "c3" and a.chains is None and a.iters_per_step is None and not a.no_other_workloads \
+            and a.model == 2 and not a.moments:
         others = {}
-        for w in ("c2", "c4", "c5"):
+        for name in ("c2", "c4", "c5", "c5_moments", "c3_model1"):
+            w, model_w, moments_w = OTHER_SPECS[name]
+            aw = argparse.Namespace(**vars(a))
+            aw.model, aw.moments = model_w, moments_w
             Cw, Iw = DEFAULT_CHAINS[w], DEFAULT_ITERS[w]
-            bw = make_batch(w, "weak", Cw, a, ctx)
-            steps_w, warm_w = OTHER_STEPS[w]
+            bw = make_batch(w, "weak", Cw, aw, ctx)
+            steps_w, warm_w = OTHER_STEPS[name]
             dtw, kmsw, chw = timed_region(bw, Iw, steps_w, warm_w, ctx)
-            roof, fp64 = rooflines(w, bw, Iw, a.thinning, kmsw)
-            others[w] = {"value": chw * Iw * steps_w / dtw, "unit": "MH samples/s", "ms_per_step": dtw / steps_w * 1e3, "kernel_ms": kmsw,
-                         "steps": steps_w, "warmup": warm_w, "iterations_per_step": Iw, "chains": bw.chains, "workload": bw.label,
-                         "roofline_frac": roof["frac"], "fp64_frac": fp64["frac"], "kernel": bw.kernel_name,
-                         "mean_acceptance": float(bw.acceptance_summary().mean().item())}
+            roof, fp64 = rooflines(facts_key(w, aw), bw, Iw, a.thinning, kmsw)
+            others[name] = {"value": chw * Iw * steps_w / dtw, "unit": "MH samples/s", "ms_per_step": dtw / steps_w * 1e3, "kernel_ms": kmsw,
+                            "steps": steps_w, "warmup": warm_w, "iterations_per_step": Iw, "chains": bw.chains, "workload": bw.label,
+                            "roofline_frac": roof["frac"], "fp64_frac": fp64["frac"], "flop_per_iteration": fp64["flop_per_iteration"],
+                            "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "traffic": roof["traffic"],
+                            "kernel": bw.kernel_name, "mean_acceptance": float(bw.acceptance_summary().mean().item())}
             del bw
             release(torch)
         out["other_workloads"] = others

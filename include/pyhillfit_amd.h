@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PHF_ABI_VERSION 4
+#define PHF_ABI_VERSION 5
 
 enum {
   PHF_OK = 0,
@@ -239,11 +239,18 @@ int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior
  * 2^-600..2^600): 12 phf_rcp(x), 13 phf_sqrt_pos(x), 14 phf_div(ln 10, x), 15 phf_sqrt_nonneg(x) (0 -> 0), 16 phf_div(x, ln 10);
  * 17 phf_normal_u32(w): the single-level sampler's standard normal of a 32-bit word (input doubles hold integer values w in [0, 2^32));
  * 18 phf_log_ndtr_tab(x): log Phi(x) from the censored likelihood's table (valid for -185 000 < x <= 0; any x is safe to pass);
- * 19 phf_erfc_tab(y): erfc(y), y >= 0, to 3.6e-17 absolute from the hierarchical target's table, 0 from y = 6 on (any y is safe to pass). */
+ * 19 phf_erfc_tab(y): erfc(y), y >= 0, to 3.6e-17 absolute from the hierarchical target's table, 0 from y = 6 on (any y is safe to pass);
+ * 20 / 21 phf_sqrt_rcp_pos(x): the reciprocal 1 / sqrt(x) (of the ROUNDED root) / the root itself — a Cholesky pivot and its reciprocal
+ * from one hardware estimate (ABI 5; python/PyHillFit.py:831 draws through numpy's factorisation of the same covariance). */
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream);
 
-/* The four Philox words of n (counter, key) tuples: in device uint32 [n][6], out device uint32 [n][4]. */
+/* The four Philox4x32-R words of n (counter, key) tuples: in device uint32 [n][6], out device uint32 [n][4].
+ * phf_debug_philox: R = the rounds the samplers draw with, phf_philox_rounds() (7 since ABI 5; rounds 1-3 of this build: 10);
+ * phf_debug_philox_rounds: R = 7 or 10 (both are held to the Random123 known-answer vectors).  Plays the role of the reference's
+ * numpy RandomState (python/PyHillFit.py:825,831,834; python/PyHillTemp.py:88,100). */
+int phf_philox_rounds(void);
 int phf_debug_philox(int64_t n, const uint32_t* counter_key, uint32_t* out, void* stream);
+int phf_debug_philox_rounds(int rounds, int64_t n, const uint32_t* counter_key, uint32_t* out, void* stream);
 
 /* ---- posterior-predictive curves -------------------------------------------------------------------
  * Replaces construct_posterior_predictive_cdfs (python/construct_hierarchical_cdfs.py:32-58): for every problem q

@@ -161,10 +161,16 @@ def normal_u32(w):
     return out
 
 
-def philox(ctr_key):
+def philox_rounds():
+    """rounds of the Philox4x32 block the samplers draw from (phf_philox.h: PHF_PHILOX_ROUNDS)"""
+    return int(lib().phfo_philox_rounds())
+
+
+def philox(ctr_key, rounds=0):
+    """rounds: 7 or 10; 0 = the samplers' own"""
     ck = np.ascontiguousarray(ctr_key, dtype=np.uint32).reshape(-1, 6)
     out = np.empty((ck.shape[0], 4), dtype=np.uint32)
-    lib().phfo_philox(C.c_int64(ck.shape[0]), _p(ck), _p(out))
+    lib().phfo_philox(C.c_int(rounds), C.c_int64(ck.shape[0]), _p(ck), _p(out))
     return out
 
 

@@ -291,10 +291,14 @@ void phfo_vec_sincos(int64_t n, const uint32_t* w, double* sn, double* cs) {
   for (int64_t i = 0; i < n; ++i) phf_sincos_2pi_u32(w[i], &sn[i], &cs[i]);
 }
 
-void phfo_philox(int64_t n, const uint32_t* ctr_key /* [n][6] */, uint32_t* out /* [n][4] */) {
+/* rounds: 7, 10, or 0 = the rounds the samplers draw with (PHF_PHILOX_ROUNDS) */
+int phfo_philox_rounds(void) { return PHF_PHILOX_ROUNDS; }
+void phfo_philox(int rounds, int64_t n, const uint32_t* ctr_key /* [n][6] */, uint32_t* out /* [n][4] */) {
   for (int64_t i = 0; i < n; ++i) {
     const uint32_t* c = ctr_key + 6 * i;
-    const phf_u32x4 r = phf_philox4x32_10(c[0], c[1], c[2], c[3], c[4], c[5]);
+    const phf_u32x4 r = rounds == 10 ? phf_philox4x32_10(c[0], c[1], c[2], c[3], c[4], c[5])
+                      : rounds == 7 ? phf_philox4x32_7(c[0], c[1], c[2], c[3], c[4], c[5])
+                                    : phf_philox_mh(c[0], c[1], c[2], c[3], c[4], c[5]);
     memcpy(out + 4 * i, r.w, 16);
   }
 }

@@ -62,11 +62,14 @@ def partition_units(points_per_pair, num_rungs, world):
 
 
 def assemble_thermodynamic_integration(unit_rows, pairs, temperatures, model, run_facts):
-    """unit_rows: [n][4 + d + 1] = (pair, rung, log_py_pooled, log_py_chain0, pooled means...) from ALL ranks, any order.
+    """unit_rows: [n][4 + d + 1 (+ 1)] = (pair, rung, log_py_pooled, log_py_chain0, pooled means..., and optionally the standard
+    deviation of the per-chain log_py over the rung's chains) from ALL ranks, any order.
     Returns (per-rung records in (pair, rung) order, one thermodynamic-integration record per pair with all its rungs):
     what python/compute_bayes_factors.py:67-83 recomputes from the chain files."""
     unit_rows = np.asarray(unit_rows, dtype=np.float64)
     R = len(temperatures)
+    n_means = (2 if model == 1 else 3) + 1
+    has_sd = unit_rows.shape[1] == 4 + n_means + 1
     order = np.lexsort((unit_rows[:, 1], unit_rows[:, 0]))
     unit_rows = unit_rows[order]
     keys = unit_rows[:, 0].astype(int) * R + unit_rows[:, 1].astype(int)
@@ -77,7 +80,7 @@ def assemble_thermodynamic_integration(unit_rows, pairs, temperatures, model, ru
         d_clean, c_clean = drug.replace('/', '_'), channel.replace('/', '_')
         rows = unit_rows[ip * R:(ip + 1) * R]
         for ir, temperature in enumerate(temperatures):
-            rungs.append({"drug": d_clean, "channel": c_clean, "temperature": float(temperature), "pooled_mean": rows[ir, 4:].tolist(),
+            rungs.append({"drug": d_clean, "channel": c_clean, "temperature": float(temperature), "pooled_mean": rows[ir, 4:4 + n_means].tolist(),
                           "chain_file": dr.nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature, make_dirs=False)[2],
                           "log_py_pooled": float(rows[ir, 2]), "log_py_chain0": float(rows[ir, 3])})
         ti = {"drug": d_clean, "channel": c_clean, "model": model, "temperatures": [float(t) for t in temperatures],
@@ -85,6 +88,13 @@ def assemble_thermodynamic_integration(unit_rows, pairs, temperatures, model, ru
         ti.update(run_facts)
         ti["expectation_pooled"] = float(dr.trapezium_rule(ti["temperatures"], ti["log_py_pooled"]))
         ti["expectation_chain0"] = float(dr.trapezium_rule(ti["temperatures"], ti["log_py_chain0"]))
+        if has_sd:
+            # Monte-Carlo error of ONE chain's estimate (what the reference computes from its one chain file per rung): the scatter of the
+            # per-chain rung means over this run's chains, carried through the trapezium weights (rungs are independent runs)
+            tt = np.asarray(ti["temperatures"])
+            w = np.zeros(R); w[1:] += 0.5 * np.diff(tt); w[:-1] += 0.5 * np.diff(tt)
+            ti["log_py_chain_sd"] = rows[:, 4 + n_means].tolist()
+            ti["expectation_chain_sd"] = float(np.sqrt(np.sum((w * rows[:, 4 + n_means]) ** 2)))
         tis.append(ti)
     return rungs, tis
 
@@ -111,7 +121,7 @@ def run_tempered(pairs, temperatures, args, device, rank=0, world=1):
         raise SystemExit("iterations must be a multiple of thinning")
     num_saved = total_iterations // thinning + 1                                                    # :70
     burn = num_saved // args.burn_in_fraction                                                       # :71
-    unit_rows = np.zeros((len(mine), 4 + d + 1))
+    unit_rows = np.zeros((len(mine), 4 + d + 1 + 1))
     mcmc_time = 0.0
     if len(mine):
         packed = dr.PackedPoints([(loaded[ip][2], loaded[ip][3]) for ip in my_pairs])
@@ -152,7 +162,8 @@ def run_tempered(pairs, temperatures, args, device, rank=0, world=1):
             print("chain_file:", chain_file)
             writers.submit(chainio.save_tempered_chain, chain_file, kept[burn:, q].numpy())         # :125,169
             unit_rows[q, :4] = ip, ir, ll1[q].mean(), ll1[q, 0]
-            unit_rows[q, 4:] = mean[:, q].mean(axis=1)
+            unit_rows[q, 4:4 + d + 1] = mean[:, q].mean(axis=1)
+            unit_rows[q, 4 + d + 1] = ll1[q].std(ddof=1) if C > 1 else 0.0
         writers.close()
     # ---- the one exchange step of the run: per-unit expectations to rank 0 (a few KB over RCCL / gloo) ----
     gathered = phfdist.gather_rows(torch.as_tensor(unit_rows, device=phfdist.collective_device(device)), dst=0)

@@ -6,12 +6,12 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpyhillfit_amd.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/pyhillfit_amd.h declares
 EXPORTS = ["phf_version", "phf_last_error", "phf_simd_count", "phf_single_level_state_size", "phf_single_level_init",
            "phf_single_level_advance", "phf_single_level_advance_queued", "phf_single_level_queue_status", "phf_single_level_log_target",
-           "phf_debug_math", "phf_debug_philox", "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance",
+           "phf_debug_math", "phf_philox_rounds", "phf_debug_philox", "phf_debug_philox_rounds", "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance",
            "phf_hierarchical_set_kernel_policy", "phf_hierarchical_log_target", "phf_predictive_scratch_bytes", "phf_predictive_accumulate"]
 
 
@@ -71,6 +71,8 @@ def load():
     lib.phf_single_level_log_target.argtypes = [C.POINTER(Points), i32, i64, vp, vp, vp, vp, vp, vp]
     lib.phf_debug_math.argtypes = [i32, i64, vp, vp, vp]
     lib.phf_debug_philox.argtypes = [i64, vp, vp, vp]
+    lib.phf_debug_philox_rounds.argtypes = [i32, i64, vp, vp, vp]
+    lib.phf_philox_rounds.restype = C.c_int
     lib.phf_predictive_scratch_bytes.argtypes = [i32, i64, i32, i32]
     lib.phf_predictive_scratch_bytes.restype = C.c_size_t
     lib.phf_predictive_accumulate.argtypes = [i32, vp, i64, i32, i32, i32, i32, vp, vp, i32, vp, vp, C.c_size_t, vp]

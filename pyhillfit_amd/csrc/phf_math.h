@@ -173,10 +173,33 @@ PHF_HD double phf_sqrt_pos(double x) {                      /* sqrt(x), x > 0 */
   d = __builtin_fma(-g, g, x);
   return __builtin_fma(d, h, g);
 }
+/* g = sqrt(x) AND 1/g for x > 0 — a Cholesky pivot and its reciprocal (phf_single_level.hip: chol_packed) — from ONE hardware
+ * estimate: the square-root iteration above carries h ~ 1/(2 sqrt x) along, so 2 h is already 1/g to a few ulp, and what
+ * phf_rcp does after ITS estimate and first Newton step — one more Newton step, then the correcting step — finishes it.  Same two
+ * correctly rounded results as phf_sqrt_pos(x) and phf_rcp(g) (checked bit for bit against sqrt and 1.0 / sqrt on 1.2 M arguments,
+ * tests/test_gpu_parity.py), 15 instructions and one quarter-rate one instead of 17 and two (round 4: C3 -1.x %). */
+PHF_HD double phf_sqrt_rcp_pos(double x, double* inv) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);                               /* sqrt(x), correctly rounded (as phf_sqrt_pos) */
+  double yi = h + h;                                        /* 1/g to a few ulp (h was refined once: relative error ~2^-51) */
+  const double e = __builtin_fma(-g, yi, 1.0);
+  yi = __builtin_fma(yi, e, yi);                            /* one Newton step: as phf_rcp_refined_ leaves its y (~0.5 ulp) */
+  const double c = __builtin_fma(-g, yi, 1.0);
+  *inv = __builtin_fma(c, yi, yi);                          /* 1.0 / g, correctly rounded (as phf_rcp) */
+  return g;
+}
 #else
 PHF_HD double phf_rcp(double d) { return 1.0 / d; }
 PHF_HD double phf_div(double n, double d) { return n / d; }
 PHF_HD double phf_sqrt_pos(double x) { return __builtin_sqrt(x); }
+PHF_HD double phf_sqrt_rcp_pos(double x, double* inv) { const double g = __builtin_sqrt(x); *inv = 1.0 / g; return g; }
 #endif
 /* sqrt(x) for x >= 0 with sqrt(0) = 0 (pivots of a degenerate factor); anything else non-positive also gives 0 */
 PHF_HD double phf_sqrt_nonneg(double x) {

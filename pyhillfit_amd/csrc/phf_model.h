@@ -149,7 +149,7 @@ PHF_HD void phf_sl_log_target(int model, const double* lc, const double* y, cons
  * (Rounds 1-3 drew the normals by Box-Muller from 24- / 32-bit fields; the inverse CDF costs a third of the fp64 operations.) */
 PHF_HD double phf_mh_draws(int d, uint32_t chain_id, uint32_t problem_id, uint32_t t, uint32_t seed_lo,
                            uint32_t seed_hi, phf_ktab k_log, double* z) {
-  const phf_u32x4 b = phf_philox4x32_10(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
+  const phf_u32x4 b = phf_philox_mh(chain_id, problem_id, t, 0u, seed_lo, seed_hi);
   z[0] = phf_normal_u32(b.w[0]);
   z[1] = phf_normal_u32(b.w[1]);
   if (d == 2) {

@@ -24,6 +24,9 @@ constexpr int kQueueMaxRounds = 16;          // beyond this many rounds of the c
 
 template <int MODEL> struct Dim { static constexpr int d = (MODEL == 1) ? 2 : 3; };
 
+#ifndef PHF_CHOL_FUSED_PIVOT
+#define PHF_CHOL_FUSED_PIVOT 1
+#endif
 // packed lower-triangular Cholesky, D <= 3, fully unrolled; non-positive pivot -> zero column
 template <int D>
 __device__ __forceinline__ void chol_packed(const double* c, double* l) {
@@ -38,9 +41,14 @@ __device__ __forceinline__ void chol_packed(const double* c, double* l) {
       if (i == j) {   // sqrt and reciprocal are computed unconditionally (no divergent branch); a non-positive pivot selects 0 —
                       // ONE predicate for both selects (sqrt(s) > 0 exactly when s > 0)
         const bool pos = s > 0.0;
-        const double rs = phf_sqrt_pos(s);
+        double ir = 0.0;
+#if PHF_CHOL_FUSED_PIVOT
+        const double rs = (i + 1 < D) ? phf_sqrt_rcp_pos(s, &ir) : phf_sqrt_pos(s);    // the last pivot's reciprocal is not used
+#else
+        const double rs = phf_sqrt_pos(s);                  // (A/B builds: root and reciprocal from an estimate each)
+        ir = phf_rcp(rs);
+#endif
         const double r = pos ? rs : 0.0;
-        const double ir = phf_rcp(rs);
         l[i * (i + 1) / 2 + i] = r;
         inv[i] = pos ? ir : 0.0;
       } else {
@@ -451,16 +459,19 @@ __global__ void debug_math_kernel(int fn, int64_t n, const double* in, double* o
     case 17: r = phf_normal_u32((uint32_t)x); break;
     case 18: r = phf_log_ndtr_tab(x, -x * PHF_INV_SQRT2); break;
     case 19: r = phf_erfc_tab(x); break;
+    case 20: (void)phf_sqrt_rcp_pos(x, &r); break;      // the reciprocal half; 21: the square-root half
+    case 21: r = phf_sqrt_rcp_pos(x, &s); break;
     default: phf_sincos_2pi_u32((uint32_t)x, &s, &c); r = c; break;
   }
   out[i] = r;
 }
 
+template <int ROUNDS>
 __global__ void debug_philox_kernel(int64_t n, const uint32_t* ck, uint32_t* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t* c = ck + 6 * i;
-  const phf_u32x4 r = phf_philox4x32_10(c[0], c[1], c[2], c[3], c[4], c[5]);
+  const phf_u32x4 r = phf_philox4x32_r(ROUNDS, c[0], c[1], c[2], c[3], c[4], c[5]);
   for (int k = 0; k < 4; ++k) out[4 * i + k] = r.w[k];
 }
 
@@ -585,17 +596,25 @@ int phf_single_level_log_target(const phf_points* pts, int model, int64_t m, con
 }
 
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream) {
-  if (fn < 0 || fn > 19 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
+  if (fn < 0 || fn > 21 || n < 0 || !in || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_math");
   if (n == 0) return PHF_OK;
   hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, n, in, out);
   return phf_check_launch("phf_debug_math");
 }
 
-int phf_debug_philox(int64_t n, const uint32_t* counter_key, uint32_t* out, void* stream) {
-  if (n < 0 || !counter_key || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_philox");
+int phf_philox_rounds(void) { return PHF_PHILOX_ROUNDS; }
+
+int phf_debug_philox_rounds(int rounds, int64_t n, const uint32_t* counter_key, uint32_t* out, void* stream) {
+  if ((rounds != 7 && rounds != 10) || n < 0 || !counter_key || !out) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad arguments to phf_debug_philox_rounds (rounds: 7 or 10)");
   if (n == 0) return PHF_OK;
-  hipLaunchKernelGGL(debug_philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, counter_key, out);
-  return phf_check_launch("phf_debug_philox");
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (rounds == 7) hipLaunchKernelGGL(debug_philox_kernel<7>, grid, block, 0, (hipStream_t)stream, n, counter_key, out);
+  else hipLaunchKernelGGL(debug_philox_kernel<10>, grid, block, 0, (hipStream_t)stream, n, counter_key, out);
+  return phf_check_launch("phf_debug_philox_rounds");
+}
+
+int phf_debug_philox(int64_t n, const uint32_t* counter_key, uint32_t* out, void* stream) {
+  return phf_debug_philox_rounds(PHF_PHILOX_ROUNDS, n, counter_key, out, stream);
 }
 
 }  // extern "C"

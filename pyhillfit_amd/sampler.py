@@ -69,6 +69,24 @@ def log_target_batch(packed, model, pair_index, temperature, theta, device="cuda
     return lik.cpu().numpy(), pri.cpu().numpy()
 
 
+# A quantum of a queued launch is at most this many iterations, however long the advance() call: a wavefront that pulled quantum k + 1 of a
+# block waits for the wavefront still running quantum k (at most about one quantum: ~10 ms of a C3-like launch at this cap), and
+# its give-up limit is a fixed number of polls (a few seconds) that must stay far above any correct wait.
+MAX_QUANTUM_ITERATIONS = 4000
+
+
+def queue_quantum(n_iterations, queue_quanta, thinning):
+    """iterations per quantum of a queued launch of n_iterations: about n / queue_quanta, a whole number of thinning periods, at least
+    100 (the state goes through HBM between quanta) and at most MAX_QUANTUM_ITERATIONS (more quanta instead).  0: plain launch."""
+    n, k = int(n_iterations), int(queue_quanta)
+    if k <= 1 or n < 100 * k:
+        return 0
+    cap = MAX_QUANTUM_ITERATIONS - MAX_QUANTUM_ITERATIONS % thinning
+    quantum = -(-n // k)
+    quantum = max(100, -(-quantum // thinning) * thinning)
+    return min(quantum, max(cap, thinning))
+
+
 def raise_if_drained(queue):
     """queue: the int32 workspace of phf_single_level_advance_queued ([2 + blocks], last word = sticky fault flag) or None"""
     if queue is not None and int(queue[-1].item()) != 0:
@@ -188,13 +206,10 @@ class SingleLevelSampler(object):
                 if tuple(out.shape) != shape or not out.is_contiguous():
                     raise ValueError("out must be contiguous with shape %s" % (shape,))
                 rows = out
-        n = int(n_iterations)
-        if self.queue_quanta > 1 and n >= 100 * self.queue_quanta:
-            # quanta of a whole number of thinning periods, at least 100 iterations each (the state goes through HBM between them).
+        quantum = queue_quantum(n_iterations, self.queue_quanta, self.thinning)
+        if quantum:
             # Whether the launch really runs as a queue is the library's decision (it knows the chip: phf_simd_count()): only launches
             # of 1..16 rounds of the chip's wavefront slots do, anything else falls back to the plain launch there.
-            quantum = -(-n // self.queue_quanta)
-            quantum = max(100, -(-quantum // self.thinning) * self.thinning)
             if self._queue is None:
                 self._queue = torch.zeros(2 + self.nblocks, dtype=torch.int32, device=self.device)   # last word: sticky fault flag
             _lib.check(self.lib.phf_single_level_advance_queued(C.byref(self.points.struct), C.byref(self.prob), C.byref(cfg),
@@ -292,11 +307,15 @@ def debug_math(fn, x, device="cuda"):
     return out.cpu().numpy()
 
 
-def debug_philox(counter_key, device="cuda"):
+def debug_philox(counter_key, device="cuda", rounds=0):
+    """Philox4x32-R blocks on the device; rounds 7 or 10, 0 = the samplers' own (phf_philox_rounds)"""
     lib = _lib.load()
     dev = torch.device(device)
     ck = np.ascontiguousarray(counter_key, dtype=np.uint32).reshape(-1, 6)
     cin = torch.from_numpy(ck.view(np.int32)).to(dev)
     out = torch.empty((ck.shape[0], 4), dtype=torch.int32, device=dev)
-    _lib.check(lib.phf_debug_philox(ck.shape[0], _ptr(cin), _ptr(out), _stream_ptr(dev)), "phf_debug_philox")
+    if rounds:
+        _lib.check(lib.phf_debug_philox_rounds(int(rounds), ck.shape[0], _ptr(cin), _ptr(out), _stream_ptr(dev)), "phf_debug_philox_rounds")
+    else:
+        _lib.check(lib.phf_debug_philox(ck.shape[0], _ptr(cin), _ptr(out), _stream_ptr(dev)), "phf_debug_philox")
     return out.cpu().numpy().view(np.uint32)

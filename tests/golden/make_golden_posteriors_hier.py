@@ -12,8 +12,14 @@ reference's stored chaste/samples (500 draws of (alpha, mu)) could only give for
 The start point is the one the product's command line would use (pyhillfit_amd.bestfit, host numpy) and is stored in the
 fixture so that the GPU test starts its chains at the same place.
 
+G10b (--per-drug, round 4): the same runs on ONE PAIR OF EVERY DRUG (30 pairs), two seeds each.  The pairs are fixed by a rule
+written down before any GPU number was looked at: drug i (the data file's order) takes channel (i mod 7), and if that pair is
+already in G10 the next channel; seeds 201 and 202 for every pair, no pair gets more.  Written to a fixture of its own
+(g10b_hier_posteriors_per_drug.json) so that G10 stays what it was.
+
 TEST INFRASTRUCTURE, generator side only (needs /root/reference; 18 runs of 3-6 minutes spread over worker processes).
     python tests/golden/make_golden_posteriors_hier.py [--iterations 500000] [--seeds 3] [--workers 7]
+    python tests/golden/make_golden_posteriors_hier.py --per-drug [--workers 5]          (60 runs of 4-8 minutes)
 """
 import argparse
 import contextlib
@@ -85,17 +91,30 @@ def main():
     ap.add_argument("--thinning", type=int, default=5)
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--workers", type=int, default=7)
+    ap.add_argument("--per-drug", action="store_true", help="G10b: one pair of every drug (rule in the docstring), seeds 201, 202")
     a = ap.parse_args()
     import _ref_loader as R
     import make_golden as G
     from pyhillfit_amd import bestfit
     dr = R.load_doseresponse(); dr.setup(os.path.join(G.REF_DATA, "crumb_data.csv"))
     _, _, locs, _ = G.elkins_prior_params()
+    global PAIRS
+    first_seed, out_name = 101, "g10_hier_posteriors.json"
+    if a.per_drug:
+        drugs, channels = list(dr.drugs), list(dr.channels)
+        chosen = []
+        for i, d in enumerate(drugs):
+            k = i % len(channels)
+            while (d, channels[k]) in PAIRS:
+                k = (k + 1) % len(channels)
+            chosen.append((d, channels[k]))
+        PAIRS = chosen
+        a.seeds, first_seed, out_name = 2, 201, "g10b_hier_posteriors_per_drug.json"
     starts = {}
     for d, c in PAIRS:
         pair = G.concat_pair(dr, d, c)
         starts[(d, c)] = np.asarray(bestfit.hierarchical_first_iteration(pair["experiments"], locs), dtype=float)
-    jobs = [(d, c, 101 + s, a.iterations, a.thinning, starts[(d, c)].tolist()) for s in range(a.seeds) for d, c in PAIRS]
+    jobs = [(d, c, first_seed + s, a.iterations, a.thinning, starts[(d, c)].tolist()) for s in range(a.seeds) for d, c in PAIRS]
     jobs.sort(key=lambda j: -len(j[5]))                   # longest (largest Ne) first
     t0 = time.time()
     runs = []
@@ -119,9 +138,9 @@ def main():
                     "first_iteration": starts[(d, c)].tolist(), "iterations": a.iterations, "thinning": a.thinning,
                     "burn": "first quarter of the saved rows", "columns": "alpha, beta, mu, s, (pIC50_i, Hill_i) x Ne, sigma, log-target",
                     "pooled": pooled, "runs": mine})
-    with open(os.path.join(HERE, "g10_hier_posteriors.json"), "w") as f:
+    with open(os.path.join(HERE, out_name), "w") as f:
         json.dump(out, f, indent=1)
-    print("G10 written: %d pairs x %d seeds in %.0f s" % (len(PAIRS), a.seeds, time.time() - t0))
+    print(out_name + " written: %d pairs x %d seeds in %.0f s" % (len(PAIRS), a.seeds, time.time() - t0))
 
 
 if __name__ == "__main__":

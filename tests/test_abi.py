@@ -33,7 +33,9 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_state_sizes(lib):
-    assert lib.phf_version() == 4
+    assert lib.phf_version() == 5
+    assert lib.phf_philox_rounds() == 7                  # phf_philox.h: PHF_PHILOX_ROUNDS
+    assert lib.phf_debug_philox_rounds(8, 1, 1, 1, None) == -1 and b"rounds" in lib.phf_last_error()
     assert lib.phf_simd_count() >= 4                      # without a GPU: the MI355X figure (1 024)
     assert lib.phf_single_level_state_size(1) == 11      # 2+1+2+3+1+1+1
     assert lib.phf_single_level_state_size(2) == 16      # 3+1+3+6+1+1+1

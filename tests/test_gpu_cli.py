@@ -104,9 +104,12 @@ def test_bayes_factor_fused_equals_chain_file_sweep(csv_file, tmp_path):
             ti = json.load(f)
         assert swept["expectations"][m] == pytest.approx(ti["expectation_chain0"], rel=1e-11)
         assert np.all(np.diff(ti["log_py_pooled"]) > 0)            # hotter rungs fit the data better
+        # pooled 64 chains vs chain 0 alone (what the reference's method sees: 600 kept samples of ONE chain per rung).  The tolerance is the
+        # run's own: 4 standard deviations of a single chain's estimate, measured over the 64 chains of every rung and carried through the
+        # trapezium weights (PyHillTemp.assemble_thermodynamic_integration) — not a fixed number (G6 is the strict check)
+        assert 0 < ti["expectation_chain_sd"] < 2.0
+        assert abs(fused["expectations"][m] - swept["expectations"][m]) <= 4 * ti["expectation_chain_sd"], (m, fused["expectations"][m], swept["expectations"][m], ti["expectation_chain_sd"])
     assert 1e-3 < fused["B12"] < 1e3      # evidence ratio of two nested, similarly good models (better fit vs Occam factor)
-    # pooled 64 chains vs chain 0 alone (600 kept samples per rung: its own Monte-Carlo error is a few tenths; G6 is the strict check)
-    assert fused["expectations"][1] == pytest.approx(swept["expectations"][1], abs=1.0)
 
 
 def test_rccl_backend_collectives_of_the_multi_gpu_path(tmp_path):

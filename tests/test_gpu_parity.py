@@ -71,6 +71,9 @@ def test_device_math_bit_identical_to_host_build(gpu):
     assert np.array_equal(debug_math(16, x, gpu), x / ln10), "phf_div (numerator varies)"
     xp = np.abs(x)
     assert np.array_equal(debug_math(13, xp, gpu), np.sqrt(xp)), "phf_sqrt_pos"
+    # a Cholesky pivot and its reciprocal from one hardware estimate (phf_sqrt_rcp_pos): the same two correctly rounded numbers
+    assert np.array_equal(debug_math(21, xp, gpu), np.sqrt(xp)), "phf_sqrt_rcp_pos: square root"
+    assert np.array_equal(debug_math(20, xp, gpu), 1.0 / np.sqrt(xp)), "phf_sqrt_rcp_pos: reciprocal of the rounded square root"
     xz = np.concatenate([xp[:1000], [0.0, -0.0, -1.0, -1e-300]])
     want = np.where(xz > 0, np.sqrt(np.abs(xz)), 0.0)
     assert np.array_equal(debug_math(15, xz, gpu), want), "phf_sqrt_nonneg"
@@ -89,11 +92,13 @@ def test_device_philox_known_answers(gpu):
     ck = np.random.default_rng(5).integers(0, 2 ** 32, (10000, 6), dtype=np.uint64).astype(np.uint32)
     ck[0] = 0; ck[1] = 0xffffffff
     ck[2] = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0]
-    got = debug_philox(ck, gpu)
-    assert got[0].tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    assert got[1].tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
-    assert got[2].tolist() == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
-    assert np.array_equal(got, co.philox(ck))
+    from test_math_philox import PHILOX_KAT
+    for rounds, kat in PHILOX_KAT.items():                  # Random123 kat_vectors, 7 and 10 rounds
+        got = debug_philox(ck, gpu, rounds=rounds)
+        for i, (_, want) in enumerate(kat):
+            assert got[i].tolist() == want, (rounds, i)
+        assert np.array_equal(got, co.philox(ck, rounds))
+    assert np.array_equal(debug_philox(ck, gpu), co.philox(ck, 7))          # the samplers' own block: 7 rounds
 
 
 # ------------------------------------------------------------------------------------------------- log-target

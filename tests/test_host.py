@@ -119,6 +119,20 @@ def test_gamma_table_is_the_reference_expression():
     assert len(gamma_table(10)) == 11
 
 
+def test_queue_quantum_is_bounded_however_long_the_advance():
+    """a queued launch's quantum: ~n / quanta, whole thinning periods, >= 100, and never above MAX_QUANTUM_ITERATIONS — the kernel's
+    give-up limit for a hand-over wait is a fixed number of polls, so a quantum must not grow with the call"""
+    from pyhillfit_amd.sampler import MAX_QUANTUM_ITERATIONS, queue_quantum
+    assert queue_quantum(8000, 4, 5) == 2000 and queue_quantum(2000, 4, 5) == 500
+    assert queue_quantum(399, 4, 5) == 0 and queue_quantum(8000, 0, 5) == 0 and queue_quantum(8000, 1, 5) == 0     # plain launch
+    assert queue_quantum(401, 4, 5) == 105                                       # rounded up to a thinning period
+    for n in (24000, 500000, 50_000_000):
+        for thin in (1, 5, 7):
+            q = queue_quantum(n, 4, thin)
+            assert 100 <= q <= MAX_QUANTUM_ITERATIONS and q % thin == 0
+    assert queue_quantum(24000, 4, 5) == 4000                                    # six quanta instead of four of 6 000
+
+
 def test_ladder_and_models(dr):
     lad = dr.temperature_ladder()
     assert len(lad) == 41 and lad[1] == (1 / 40.) ** 3 and len(dr.temperature_ladder(31)) == 32

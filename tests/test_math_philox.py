@@ -14,13 +14,38 @@ def _ulps(got, want):
     return np.max(np.abs(got - want) / np.spacing(np.abs(want)))
 
 
+# Random123 kat_vectors: "philox4x32 10" and "philox4x32 7" on counter/key all zero, all ones, and the digits of pi
+PHILOX_KAT = {
+    10: [([0, 0, 0, 0, 0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+         ([0xffffffff] * 6, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+         ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])],
+    7: [([0, 0, 0, 0, 0, 0], [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+        ([0xffffffff] * 6, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0], [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a])],
+}
+
+
+def philox_python(ck, rounds):
+    """the round function written out once more, independently of phf_philox.h (Salmon et al., SC'11, section 3.3)"""
+    c, k = [int(x) for x in ck[:4]], [int(x) for x in ck[4:]]
+    for _ in range(rounds):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+        k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+    return c
+
+
 def test_philox_known_answers():
-    kat = [([0, 0, 0, 0, 0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
-           ([0xffffffff] * 6, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
-           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0],
-            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
-    for ck, want in kat:
-        assert co.philox([ck])[0].tolist() == want
+    assert co.philox_rounds() == 7                         # what the samplers draw with (round 4; 10 before)
+    for rounds, kat in PHILOX_KAT.items():
+        for ck, want in kat:
+            assert co.philox([ck], rounds)[0].tolist() == want
+            assert philox_python(ck, rounds) == want
+    ck = RNG.integers(0, 2 ** 32, (2000, 6), dtype=np.uint64).astype(np.uint32)
+    for rounds in (7, 10):
+        got = co.philox(ck, rounds)
+        assert all(got[i].tolist() == philox_python(ck[i], rounds) for i in range(0, 2000, 7))
+    assert np.array_equal(co.philox(ck), co.philox(ck, 7))    # rounds = 0: the samplers' own
 
 
 def test_exp_log_within_an_ulp_or_two_of_libm():

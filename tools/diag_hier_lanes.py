@@ -24,8 +24,10 @@ for C, I in [(c_, 500 if c_ >= 512 else 5000) for c_ in shapes]:
         s.init(np.array([bestfit.hierarchical_first_iteration(e, locs) for e in exs]), cov_scale=0.01)
         s.advance(2000, save=False)
         out = []
-        for lanes in ("1", "2"):
-            H.set_kernel_policy(lanes=int(lanes))
+        # PHF_DIAG_VARIANTS: lanes:wps pairs beyond the two defaults, e.g. "1:2" = the one-lane kernel built for two wavefronts per SIMD
+        variants = [(1, 0), (2, 0)] + [tuple(int(x) for x in v.split(":")) for v in os.environ.get("PHF_DIAG_VARIANTS", "").split(",") if v]
+        for lanes, wps in variants:
+            H.set_kernel_policy(lanes=lanes, wps=wps)
             s.advance(I, save=True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(3):
@@ -33,5 +35,6 @@ for C, I in [(c_, 500 if c_ >= 512 else 5000) for c_ in shapes]:
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
             out.append(dt)
         H.set_kernel_policy(0, 0)
-        print("chains/pair %4d  Ne=%d pairs=%3d  %d iterations: one lane %.2f ms, two lanes %.2f ms  (x%.2f)  | %.2f / %.2f us per iteration"
-              % (C, ne, s.Q, I, out[0] * 1e3, out[1] * 1e3, out[0] / out[1], out[0] / I * 1e6, out[1] / I * 1e6), flush=True)
+        extra = "".join("  | lanes %d wps %d: %.2f ms" % (l, w, o * 1e3) for (l, w), o in zip(variants[2:], out[2:]))
+        print("chains/pair %4d  Ne=%d pairs=%3d  %d iterations: one lane %.2f ms, two lanes %.2f ms  (x%.2f)  | %.2f / %.2f us per iteration%s"
+              % (C, ne, s.Q, I, out[0] * 1e3, out[1] * 1e3, out[0] / out[1], out[0] / I * 1e6, out[1] / I * 1e6, extra), flush=True)
