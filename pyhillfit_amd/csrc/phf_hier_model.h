@@ -75,26 +75,11 @@ PHF_HD double phf_trunc_mass(double pred, double inv_s, phf_ktab kx) {
  * Crumb point pairs — are evaluated only if some lane needs one; phf_erfc_tab is 0 beyond the cut anyway, so skipping changes
  * nobody's value.  One-lane kernels skip (C4 14.58 -> 14.09 ms); the two-lane kernels, bound by the latency of one iteration, do
  * better without the branch (9.71 against 9.99 us per Ne = 6 iteration). */
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PHF_LEAN_FENCE(lean_) do { if (lean_) __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PHF_LEAN_FENCE(lean_) ((void)(lean_))
-#endif
-/* skip bit 1 = lean (phf_hier_target_half): one table evaluation at a time — its twelve coefficients are 24 registers */
-PHF_HD double phf_trunc_mass_x2(double pred0, double pred1, double inv_s, phf_ktab kx, int skip_and_lean) {
-  const int skip = skip_and_lean & 1, lean = (skip_and_lean >> 1) & 1;
+PHF_HD double phf_trunc_mass_x2(double pred0, double pred1, double inv_s, phf_ktab kx, int skip) {
   const double ya0 = (pred0 * inv_s) * PHF_INV_SQRT2, ya1 = (pred1 * inv_s) * PHF_INV_SQRT2;
   const double yb0 = ((PHF_K100(kx) - pred0) * inv_s) * PHF_INV_SQRT2, yb1 = ((PHF_K100(kx) - pred1) * inv_s) * PHF_INV_SQRT2;
-  PHF_LEAN_FENCE(lean);
-  double t0 = phf_erfc_tab(ya0);
-  PHF_LEAN_FENCE(lean);
-  double t1 = phf_erfc_tab(ya1);
-  PHF_LEAN_FENCE(lean);
-  if (!skip || PHF_ANY_LANE((yb0 < PHF_ERFC_CUT) | (yb1 < PHF_ERFC_CUT))) {
-    t0 += phf_erfc_tab(yb0);
-    PHF_LEAN_FENCE(lean);
-    t1 += phf_erfc_tab(yb1);
-  }
+  double t0 = phf_erfc_tab(ya0), t1 = phf_erfc_tab(ya1);
+  if (!skip || PHF_ANY_LANE((yb0 < PHF_ERFC_CUT) | (yb1 < PHF_ERFC_CUT))) { t0 += phf_erfc_tab(yb0); t1 += phf_erfc_tab(yb1); }
   return phf_fma(-0.5, t0, 1.0) * phf_fma(-0.5, t1, 1.0);
 }
 
@@ -147,12 +132,8 @@ PHF_HD int phf_hier_out_of_support(int n_expts, const double* th, int ts, const 
   return bad;
 }
 
-/* lean (a literal; bit 1 of skip_tails): the build for TWO wavefronts per SIMD has half the registers — the points are read where they
- * are used (not ahead), and the instruction scheduler is told not to interleave the point pairs with each other or with the batch
- * of logarithms (fewer values live at once; the partner wavefront fills the gaps).  Same operations in the same order.            */
 PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
-                                   const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log, int skip_tails_and_lean) {
-  const int skip_tails = skip_tails_and_lean & 1, lean = (skip_tails_and_lean >> 1) & 1;
+                                   const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log, int skip_tails) {
   const int dim = 5 + 2 * n_expts;
   const double alpha = th[0], beta = th[1 * ts], mu = th[2 * ts], s = th[3 * ts], sigma = th[(dim - 1) * ts];
   /* fixed_n is a SHAPE CODE (PHF_HIER_SHAPE): low 4 bits = points of every experiment (a multiple of 4), the bits above = points of the
@@ -165,7 +146,7 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
   /* fixed shapes (straight-line bodies): this half's points are read HERE, a few hundred instructions ahead of their use, so that a
    * wavefront that has its SIMD to itself does not wait out the LDS latency pair by pair inside the point loop */
   double plc[32], py[32];                                         /* this half's points, experiment after experiment */
-  if (fixed_n && !lean) {
+  if (fixed_n) {
     int off = 0;
     PHF_UNROLL
     for (int i = 0; i < n_expts; ++i) {
@@ -203,7 +184,6 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
     lg[j] = phf_log_fast_k(PHF_PICK(h, a0, a1), k_log);
     part = phf_fma(PHF_PICK(h, w0, w1), lg[j], part);
   }
-  PHF_LEAN_FENCE(lean);
   /* ---- linear terms: Gamma priors (half 0), logistic density of the pIC50_i (half 1) ---- */
   double lin0 = 0.0, lin1 = 0.0;
   PHF_UNROLL
@@ -236,7 +216,6 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
     }
     part = phf_fma(-2.0, v, part);
   }
-  PHF_LEAN_FENCE(lean);
   /* ---- this half's points (:117-125) ---- */
   double sse = 0.0, mass = 1.0;                                    /* mass: product of the truncation masses Phi(b) - Phi(a) of this half's points */
   int poff = 0;                                                    /* fixed shapes: where experiment i's points start in plc / py */
@@ -256,19 +235,18 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
     PHF_UNROLL
     for (int p = 0; p < npairs; ++p, j += 2) {                               /* two points at a time */
       const phf_ktab ke = k_exp;
-      const double lc0 = (fixed_n && !lean) ? plc[poff + 2 * p] : lc[j], lc1 = (fixed_n && !lean) ? plc[poff + 2 * p + 1] : lc[j + 1];
-      const double y0 = (fixed_n && !lean) ? py[poff + 2 * p] : y[j], y1 = (fixed_n && !lean) ? py[poff + 2 * p + 1] : y[j + 1];
+      const double lc0 = fixed_n ? plc[poff + 2 * p] : lc[j], lc1 = fixed_n ? plc[poff + 2 * p + 1] : lc[j + 1];
+      const double y0 = fixed_n ? py[poff + 2 * p] : y[j], y1 = fixed_n ? py[poff + 2 * p + 1] : y[j + 1];
       const double d0 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc0 - ln_ic50), 40.0), ke);
       const double d1 = 1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lc1 - ln_ic50), 40.0), ke);
       const double inv = phf_rcp(d0 * d1);
       const double pred0 = phf_fma(-PHF_K100(k_exp), inv * d1, PHF_K100(k_exp)), pred1 = phf_fma(-PHF_K100(k_exp), inv * d0, PHF_K100(k_exp));
       const double r0 = y0 - pred0, r1 = y1 - pred1;
       sse = phf_fma(r0, r0, sse); sse = phf_fma(r1, r1, sse);
-      mass *= phf_trunc_mass_x2(pred0, pred1, inv_s, k_exp, skip_tails | (lean << 1));
-      PHF_LEAN_FENCE(lean);
+      mass *= phf_trunc_mass_x2(pred0, pred1, inv_s, k_exp, skip_tails);
     }
     if (fixed_n ? (fcnt & 1) : (j < jend)) {                                 /* at most one left */
-      const double lcs = (fixed_n && !lean) ? plc[poff + fcnt - 1] : lc[j], ys = (fixed_n && !lean) ? py[poff + fcnt - 1] : y[j];
+      const double lcs = fixed_n ? plc[poff + fcnt - 1] : lc[j], ys = fixed_n ? py[poff + fcnt - 1] : y[j];
       const double w = phf_rcp(1.0 + phf_exp_capped_k(__builtin_fmin(hill * (lcs - ln_ic50), 40.0), k_exp));
       const double pred = phf_fma(-PHF_K100(k_exp), w, PHF_K100(k_exp));
       const double r = ys - pred;
@@ -286,18 +264,12 @@ PHF_HD double phf_hier_target_half(int h, int n_expts, int fixed_n, const int* e
   return (mass < PHF_DBL_MIN) ? -PHF_INF : r;
 }
 
-PHF_HD double phf_hier_log_target_n_mode(int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
-                                         const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log, int lean) {
-  const int bad = phf_hier_out_of_support(n_expts, th, ts, pr);
-  const double p0 = phf_hier_target_half(0, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 1 | (lean << 1));
-  PHF_LEAN_FENCE(lean);
-  const double p1 = phf_hier_target_half(1, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 1 | (lean << 1));
-  return bad ? -PHF_INF : p0 + p1;
-}
-
 PHF_HD double phf_hier_log_target_n(int n_expts, int fixed_n, const int* expt_start, const double* lc, const double* y,
                                     const double* th, int ts, const phf_hier_prior* pr, phf_ktab k_exp, phf_ktab k_log) {
-  return phf_hier_log_target_n_mode(n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 0);
+  const int bad = phf_hier_out_of_support(n_expts, th, ts, pr);
+  const double p0 = phf_hier_target_half(0, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 1);
+  const double p1 = phf_hier_target_half(1, n_expts, fixed_n, expt_start, lc, y, th, ts, pr, k_exp, k_log, 1);
+  return bad ? -PHF_INF : p0 + p1;
 }
 
 PHF_HD double phf_hier_log_target(int n_expts, const int* expt_start, const double* lc, const double* y,

@@ -78,13 +78,10 @@ struct HierArgs {
 #ifndef PHF_HIER_REG_ROWS_BIG
 #define PHF_HIER_REG_ROWS_BIG 6
 #endif
-#ifndef PHF_HIER_REG_ROWS_W2
-#define PHF_HIER_REG_ROWS_W2 8
-#endif
-template <int NE, int WPS = 1>
+template <int NE>
 struct Lds {
   static constexpr int dim = 5 + 2 * NE;
-  static constexpr int want_rows = (WPS == 2) ? PHF_HIER_REG_ROWS_W2 : (NE <= 4) ? PHF_HIER_REG_ROWS_SMALL : PHF_HIER_REG_ROWS_BIG;
+  static constexpr int want_rows = (NE <= 4) ? PHF_HIER_REG_ROWS_SMALL : PHF_HIER_REG_ROWS_BIG;
   static constexpr int reg_rows = want_rows < dim - 1 ? want_rows : dim - 1;
   static constexpr int reg_elems = reg_rows * (reg_rows + 1) / 2;
   static constexpr int slots = dim * (dim - 1) / 2 - reg_elems;
@@ -105,13 +102,13 @@ __device__ __forceinline__ void stage(const phf_hier_points& pts, int pair, doub
 
 // The whole launch of one wavefront.  FIXED_N > 0: every experiment of the pair has exactly FIXED_N points, known at compile
 // time (the point loops unroll: straight-line iteration); 0: run-time experiment boundaries.
-template <int NE, int FIXED_N, int WPS = 1>
+template <int NE, int FIXED_N>
 __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_mem, const double* s_lc, const double* s_y,
                                                   const int* s_es, int q, int c) {
   constexpr int D = 5 + 2 * NE;
   constexpr int TRI = D * (D + 1) / 2;
   double* sL = s_mem + threadIdx.x;                        // element (i, k < i) of L: sL[(i (i - 1) / 2 + k) * 64]; the diagonal d: dg[]
-  constexpr int kRegRows = Lds<NE, WPS>::reg_rows, kRegElems = Lds<NE, WPS>::reg_elems;
+  constexpr int kRegRows = Lds<NE>::reg_rows, kRegElems = Lds<NE>::reg_elems;
   double Lreg[kRegElems > 0 ? kRegElems : 1];              // rows 1..kRegRows
 #define PHF_LIDX(i, k) ((i) * ((i) - 1) / 2 + (k))
 #define PHF_LGET(i, k) (((i) <= kRegRows) ? Lreg[((i) <= kRegRows) ? PHF_LIDX(i, k) : 0] : sL[(PHF_LIDX(i, k) - kRegElems) * kBlock])
@@ -178,9 +175,7 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #pragma unroll
     for (int i = 0; i < D; ++i) star[i] = phf_fma(sc, y[i], th[i]);
     // ---- target, accept (:486-492) ----
-    if constexpr (WPS == 2) __builtin_amdgcn_sched_barrier(0);
-    const double lt_star = phf_hier_log_target_n_mode(NE, FIXED_N, s_es, s_lc, s_y, star, 1, &a.prior, k_exp, k_log, WPS == 2);
-    if constexpr (WPS == 2) __builtin_amdgcn_sched_barrier(0);
+    const double lt_star = phf_hier_log_target_n(NE, FIXED_N, s_es, s_lc, s_y, star, 1, &a.prior, k_exp, k_log);
     const bool acc = log_u < lt_star - lt;
     if (acc) {
 #pragma unroll
@@ -191,22 +186,17 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
     // ---- the factors for the sweep, read from LDS HERE — ahead of the draws, whose ~700 instructions cover the LDS latency a lone
     // wavefront would otherwise wait out element by element inside the sweep (same box: Ne = 3 group 13.80 -> 13.62 ms, Ne = 4 6.37 ->
     // 6.17, C4 19.11 -> 18.86) — and the draws of iteration t + 1 (a function of (chain, t + 1) alone) ----
-    // (two wavefronts per SIMD: the partner covers the latency, and 55 doubles read ahead are 110 registers this build does not have —
-    // the elements are read where the sweep uses them)
-    double Lr[WPS == 1 ? TRI - D : 1];
-    if constexpr (WPS == 1) {
+    double Lr[TRI - D];
 #pragma unroll
-      for (int i = 1; i < D; ++i)
+    for (int i = 1; i < D; ++i)
 #pragma unroll
-        for (int k = 0; k < i; ++k) Lr[i * (i - 1) / 2 + k] = PHF_LGET(i, k);
-    }
+      for (int k = 0; k < i; ++k) Lr[i * (i - 1) / 2 + k] = PHF_LGET(i, k);
     double zn[D];
-    if constexpr (WPS == 1) log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, zn, 1);
+    log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, zn, 1);
     // ---- adaptation (:495-501): cov <- (1-g) cov + g v v' applied to the L D L' factors as a rank-one update (PHF_LDL_COLUMN),
     // and the next proposal's y = L' sqrt(D') z' accumulated from the new elements while they are in registers.  Before the
     // adaptation starts the sweep runs with g = 0 — an exact no-op on mean, loga, d and L (x + 0 y) that still delivers y — so
     // that the iteration is one straight-line body ----
-    if constexpr (WPS == 1) {
     if (t > a.cfg.adapt_start) {
       const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
       const double omg = 1.0 - gs;
@@ -238,51 +228,6 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
       sc = phf_exp_fast_k(0.5 * loga, k_exp);
     } else {
       PHF_PLAIN_LU(zn, y);
-    }
-    } else {
-      // Two wavefronts per SIMD (256 registers): the sweep, THEN the draws and y = L sqrt(D) z as a pass of its own — the same
-      // sums in the same order (ascending k from +0, u_i last), so the same numbers; the normals and y are not live across the
-      // sweep (22 doubles = 44 registers this build does not have), the factor's LDS elements are read a second time (no vector
-      // instruction), and the latencies are the partner wavefront's to cover.  The scheduler is told not to mix the phases.
-      if (t > a.cfg.adapt_start) {
-        const double gs = a.cfg.gamma[t - a.cfg.adapt_start];
-        const double omg = 1.0 - gs;
-        double w[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-          w[i] = th[i] - mean[i];
-          mean[i] = phf_fma(gs, th[i], omg * mean[i]);
-        }
-        loga = phf_fma(gs, (acc ? 1.0 : 0.0) - 0.25, loga);
-        double alpha = gs;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          double dn, beta;
-          PHF_LDL_COLUMN(omg, alpha, w[k], dg[k], dn, beta);
-          dg[k] = dn;
-#pragma unroll
-          for (int i = k + 1; i < D; ++i) {
-            const double lik = PHF_LGET(i, k);
-            w[i] = phf_fma(-w[k], lik, w[i]);
-            PHF_LSET(i, k, phf_fma(beta, w[i], lik));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        sc = phf_exp_fast_k(0.5 * loga, k_exp);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      log_u = phf_hier_draws_k(D, cid, pid, (uint32_t)(t + 1), seed_lo, seed_hi, k_log, zn, 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < D; ++i) zn[i] = phf_sqrt_nonneg(dg[i]) * zn[i];
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        double v_ = 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) v_ = phf_fma(PHF_LGET(i, k), zn[k], v_);
-        y[i] = v_ + zn[i];
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
     // ---- thinning + sample store (:502-503) ----
     if (--until_save == 0) {
@@ -328,13 +273,13 @@ __device__ __forceinline__ void hier_advance_body(const HierArgs& a, double* s_m
 #undef PHF_SP
 }
 
-template <int NE, int WPS = 1>
-__global__ __launch_bounds__(kBlock, WPS) void hier_advance_kernel(const HierArgs a) {
+template <int NE>
+__global__ __launch_bounds__(kBlock, 1) void hier_advance_kernel(const HierArgs a) {
   extern __shared__ double s_mem[];
   PHF_MATH_TABLES_TO_LDS();
   PHF_ERFC_TABLE_TO_LDS();
   PHF_NORMAL_TABLE_TO_LDS();
-  double* s_lc = s_mem + (size_t)Lds<NE, WPS>::slots * kBlock;
+  double* s_lc = s_mem + (size_t)Lds<NE>::slots * kBlock;
   double* s_y = s_lc + a.pts.stride;
   int* s_es = reinterpret_cast<int*>(s_y + a.pts.stride);
   const int slot = blockIdx.x / a.blocks_per_problem;
@@ -352,11 +297,11 @@ __global__ __launch_bounds__(kBlock, WPS) void hier_advance_kernel(const HierArg
     four_each = four_each && (e == 4 * i);
     four_then_one = four_then_one && (e == (i < NE ? 4 * i : 4 * (NE - 1) + 1));
   }
-  if (four_each) { hier_advance_body<NE, PHF_HIER_SHAPE(4, 0), WPS>(a, s_mem, s_lc, s_y, s_es, q, c); return; }
+  if (four_each) { hier_advance_body<NE, PHF_HIER_SHAPE(4, 0)>(a, s_mem, s_lc, s_y, s_es, q, c); return; }
   if constexpr (NE == 4) {
-    if (four_then_one) { hier_advance_body<NE, PHF_HIER_SHAPE(4, 1), WPS>(a, s_mem, s_lc, s_y, s_es, q, c); return; }
+    if (four_then_one) { hier_advance_body<NE, PHF_HIER_SHAPE(4, 1)>(a, s_mem, s_lc, s_y, s_es, q, c); return; }
   }
-  hier_advance_body<NE, 0, WPS>(a, s_mem, s_lc, s_y, s_es, q, c);
+  hier_advance_body<NE, 0>(a, s_mem, s_lc, s_y, s_es, q, c);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1022,19 +967,7 @@ int allow_big_lds(K kernel, bool* configured) {                   // the attribu
 }
 
 template <int NE>
-int launch_advance1_w2(const HierArgs& a, hipStream_t stream) {
-  const size_t lds = Lds<NE, 2>::bytes(a.pts.stride);
-  if (lds > kMaxDynamicLds) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
-  const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
-  static bool configured[kMaxDevices] = {};
-  if (int rc = allow_big_lds(&hier_advance_kernel<NE, 2>, configured)) return rc;
-  hipLaunchKernelGGL((hier_advance_kernel<NE, 2>), grid, block, lds, stream, a);
-  return phf_check_launch("phf_hierarchical_advance (two wavefronts per SIMD)");
-}
-
-template <int NE>
 int launch_advance1(const HierArgs& a, hipStream_t stream) {
-  if constexpr (NE == 3) { if (hier_wps_override() == 2) return launch_advance1_w2<NE>(a, stream); }
   const size_t lds = Lds<NE>::bytes(a.pts.stride);
   if (lds > kMaxDynamicLds) return phf_fail(PHF_ERR_UNSUPPORTED, "proposal factor does not fit in LDS");
   const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);

@@ -194,7 +194,8 @@ def test_bench_line_keeps_the_contract(workload):
 
 def test_bench_default_line_carries_the_other_configurations():
     """the driver's command (N = 1, defaults): the headline keys are c3's, and `other_workloads` holds driver-timed short regions of
-    c2, c4 and c5 — value, ms_per_step, kernel_ms and the two roofline fractions each"""
+    c2, c4, c5 and of the kernels the command lines and the thermodynamic-integration path launch — c5 with the on-device moments and
+    <log L> (`c5_moments`), c3 with model 1 (`c3_model1`) — value, ms_per_step, kernel_ms and the two roofline fractions each"""
     import subprocess
     import sys
     if not torch.cuda.is_available():
@@ -209,8 +210,12 @@ def test_bench_default_line_carries_the_other_configurations():
     assert d["value"] == pytest.approx(210 * 4096 * d["config"]["iterations_per_step"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
     assert d["ms_per_step"] * d["steps"] > 300              # a timed region of the default size is no blink
     ow = d["other_workloads"]
-    assert sorted(ow) == ["c2", "c4", "c5"]
-    for w, chains in (("c2", 65536), ("c4", 210 * 1024), ("c5", 32 * 210 * 1024)):
+    assert sorted(ow) == ["c2", "c3_model1", "c4", "c5", "c5_moments"]
+    assert "model 1" in ow["c3_model1"]["workload"] and ow["c3_model1"]["kernel"].startswith("mh_advance_kernel<1")
+    assert "moments" in ow["c5_moments"]["workload"] and ow["c5_moments"]["kernel"] == "mh_advance_kernel<2, moments>"
+    assert ow["c5_moments"]["algorithmic_bytes_per_launch"] == ow["c5"]["algorithmic_bytes_per_launch"]      # the same rows are written
+    assert ow["c3_model1"]["algorithmic_bytes_per_launch"] == pytest.approx(0.75 * d["roofline"]["algorithmic_bytes_per_launch"])   # 3 columns, not 4
+    for w, chains in (("c2", 65536), ("c4", 210 * 1024), ("c5", 32 * 210 * 1024), ("c5_moments", 32 * 210 * 1024), ("c3_model1", 210 * 4096)):
         e = ow[w]
         assert e["chains"] == chains and e["value"] == pytest.approx(chains * e["iterations_per_step"] * e["steps"] / (e["ms_per_step"] * e["steps"] * 1e-3), rel=1e-6)
         assert 0 < e["kernel_ms"] <= e["ms_per_step"] * 1.05 and 0 < e["roofline_frac"] < 1 and 0.05 < e["mean_acceptance"] < 0.6
