@@ -27,7 +27,6 @@ import argparse
 import gc
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -148,26 +147,17 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def spawn_ranks(a):
     """--gpus N without a torchrun environment: start the N ranks as a fresh child (no GPU call has been made by this
     process; it is a child process, not an exec) and hand back its exit code."""
-    import torch
+    from pyhillfit_amd import distributed as D
     backend = os.environ.get("PHF_BENCH_BACKEND", "nccl")
-    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    have = D.visible_gpu_count()              # from the driver's topology files: the HIP runtime stays untouched in this process
     if backend == "nccl" and have < a.gpus:
         sys.stderr.write("bench.py: --gpus %d asked for but %d GPU(s) visible (RCCL needs one GPU per rank; "
                          "PHF_BENCH_BACKEND=gloo rehearses several ranks on one GPU)\n" % (a.gpus, have))
         return 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = D.torchrun_command(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:])   # --standalone: the launcher picks the rendezvous port
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
@@ -211,7 +201,7 @@ class HierarchicalBatch(object):
         self.adapt_start = max(h.adapt_start for h in self.samplers)
         self.bytes_per_iter = sum(h.Q * h.C * 8.0 * (h.d + 1) for h in self.samplers) / thinning
         self.chains = sum(h.Q * h.C for h in self.samplers)
-        H.set_kernel_policy_for(self.chains)               # the groups run side by side: one lane per chain once they fill the chip together
+        H.hint_side_by_side(self.samplers)                 # the groups run side by side: one lane per chain once they fill the chip together
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.samplers]
 
     def enable_moments(self):

@@ -14,10 +14,13 @@
  *     host thread/process per GPU may call it concurrently.
  *   - all arithmetic is IEEE fp64.  Chain-major arrays are struct-of-arrays with the chain index fastest
  *     ("[f][chain]"), so that the 64 lanes of a wavefront touch 512 contiguous bytes.
- *   - MEMORY KIND: state, rows, moments, sums and the queue workspace must be ordinary coarse-grained device memory
- *     (hipMalloc / torch.empty(device="cuda")).  The hierarchical kernels accumulate moments with hardware fp64 atomics
- *     (global_atomic_add_f64 without return) and the queued launch hands blocks over with agent-scope release/acquire: on
- *     fine-grained, managed or host-pinned memory neither is guaranteed to take effect.
+ *   - MEMORY KIND: state, moments and the queue workspace must be ordinary coarse-grained device memory (hipMalloc /
+ *     torch.empty(device="cuda")): the hierarchical kernels accumulate moments with hardware fp64 atomics (global_atomic_add_f64
+ *     without return) and the queued launch hands a block's state over with agent-scope release/acquire — on fine-grained, managed
+ *     or host-pinned memory neither is guaranteed to take effect.  The advance calls CHECK these three (hipPointerGetAttributes:
+ *     host, managed and fine-grained allocations are refused with PHF_ERR_INVALID_ARGUMENT; an address the runtime cannot classify
+ *     passes).  rows and sums are written with plain stores and read by nobody inside a launch: any device-accessible memory works,
+ *     and they are not checked.
  */
 #ifndef PYHILLFIT_AMD_H
 #define PYHILLFIT_AMD_H
@@ -73,7 +76,12 @@ typedef struct phf_problems {
   const double* temperature;     /* device [Q]  power the likelihood is raised to */
   const uint32_t* problem_id;    /* device [Q]  global problem number (Philox counter word 1) */
   uint32_t chain_id_base;        /* global number of local chain 0 (Philox counter word 0) */
-  uint32_t reserved;
+  uint32_t kernel_hint;          /* hierarchical launches (ABI 5; was `reserved`, must be 0 for single-level): which kernel THIS launch
+                                    should get — bits 0-1 lanes per chain (1 | 2), bits 2-3 register build of the two-lane kernel (1 | 2
+                                    wavefronts per SIMD); 0 = the library decides from the launch size.  A host that runs several
+                                    groups side by side sets it per launch (the groups together fill the chip although each alone
+                                    would not); a process-wide policy (phf_hierarchical_set_kernel_policy, PHF_HIER_LANES / _WPS) overrides it.
+                                    Every choice gives the same numbers bit for bit. */
   const int32_t* launch_order;   /* device [Q] or NULL: a permutation of 0..Q-1 — the order in which the problems' wavefronts are
                                     handed to the GPU (ABI 3).  Results do not depend on it (every problem writes its own rows and
                                     state); what does is the tail of a launch whose problems differ in cost: pairs have 2..8 entries,
@@ -221,9 +229,10 @@ int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* pro
                              const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
                              double* moments, int64_t moments_after, void* stream);
 
-/* Which kernel runs groups with Ne = 3..6 (ABI 4; A/B timing and the bit-identity tests): lanes 1 | 2 = one | two lanes per chain,
- * wps 1 | 2 = the register build of the two-lane kernel (512 | 256 registers); 0 = decide from the launch size (default).  The
- * environment variables PHF_HIER_LANES / PHF_HIER_WPS give the process-wide initial values and are read ONCE, at the first use. */
+/* Which kernel runs groups with Ne = 3..6, PROCESS-WIDE (ABI 4; A/B timing and the bit-identity tests): lanes 1 | 2 = one | two lanes
+ * per chain, wps 1 | 2 = the register build of the two-lane kernel (512 | 256 registers); 0 = not forced: the launch's own
+ * phf_problems.kernel_hint, else the launch size, decides.  The environment variables PHF_HIER_LANES / PHF_HIER_WPS give the initial
+ * values and are read ONCE, here in the library, at the first use; the two words are plain atomics (any thread may set them). */
 int phf_hierarchical_set_kernel_policy(int lanes, int wps);
 
 /* log_target_distribution (python/PyHillFit.py:173-193) at M parameter vectors: theta device [dim][M]. */

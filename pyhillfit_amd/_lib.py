@@ -27,7 +27,7 @@ class Points(C.Structure):
 class Problems(C.Structure):
     _fields_ = [("num_problems", C.c_int32), ("chains_per_problem", C.c_int32), ("pair_index", C.c_void_p),
                 ("temperature", C.c_void_p), ("problem_id", C.c_void_p), ("chain_id_base", C.c_uint32),
-                ("reserved", C.c_uint32), ("launch_order", C.c_void_p), ("chain_offset", C.c_void_p)]
+                ("kernel_hint", C.c_uint32), ("launch_order", C.c_void_p), ("chain_offset", C.c_void_p)]
 
 
 class MhConfig(C.Structure):

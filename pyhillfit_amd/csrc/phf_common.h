@@ -26,21 +26,34 @@ inline int phf_check_launch(const char* what) {
 
 // The kernels advance moments with hardware fp64 atomics (global_atomic_add_f64 without return) and hand blocks of a queued launch
 // over with agent-scope release / acquire: both are only guaranteed on ordinary (coarse-grained) device memory.  A buffer that is
-// host-pinned or managed is refused here instead of giving silently wrong sums (include/pyhillfit_amd.h,
-// "MEMORY KIND").  NULL passes: optional buffers are checked for NULL by their callers.
+// host-pinned, managed or fine-grained (hipExtMallocWithFlags(hipDeviceMallocFinegrained)) is refused here instead of giving
+// silently wrong sums (include/pyhillfit_amd.h, "MEMORY KIND").  NULL passes: optional buffers are checked for NULL by their
+// callers.  What the runtime cannot classify at all (hipPointerGetAttributes fails: e.g. a range mapped through the
+// virtual-memory API) passes too — nothing is known against it, and the header says so.
+// The verdict of the last few distinct addresses is remembered (a steady-state launch loop passes the same three buffers every
+// time: one runtime query per buffer, not per launch); an address is forgotten when it falls out of that window, so a buffer freed
+// and re-allocated as another kind at the same address is re-examined unless it comes back within the next few calls.
 inline int phf_require_device_memory(const void* p, const char* what) {
   if (!p) return PHF_OK;
+  constexpr int kRemembered = 8;
+  static thread_local const void* ok_ptr[kRemembered] = {};
+  static thread_local int next = 0;
+  for (int i = 0; i < kRemembered; ++i)
+    if (ok_ptr[i] == p) return PHF_OK;
   hipPointerAttribute_t attr;
   if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-    (void)hipGetLastError();       // the runtime cannot classify the address (e.g. a range mapped through the virtual-memory API):
-    return PHF_OK;                 // nothing is known against it
+    (void)hipGetLastError();
+    return PHF_OK;
   }
-  if (attr.type != hipMemoryTypeDevice) {
+  const bool fine_grained = (attr.allocationFlags & hipDeviceMallocFinegrained) != 0;
+  if (attr.type != hipMemoryTypeDevice || attr.isManaged || fine_grained) {
     std::snprintf(phf_error_buffer(), kPhfErrorBufferSize,
-                  "%s: must be ordinary device memory (hipMalloc), not host-pinned or managed memory: fp64 atomics and "
-                  "release/acquire hand-overs are not guaranteed there", what);
+                  "%s: must be ordinary coarse-grained device memory (hipMalloc), not host-pinned, managed or fine-grained memory: "
+                  "fp64 atomics and release/acquire hand-overs are not guaranteed there", what);
     return PHF_ERR_INVALID_ARGUMENT;
   }
+  ok_ptr[next] = p;
+  next = (next + 1) % kRemembered;
   return PHF_OK;
 }
 

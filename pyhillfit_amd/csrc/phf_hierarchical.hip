@@ -9,6 +9,7 @@
 // traffic at all.  HBM sees the state once per launch and the thinned samples.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 
 #define PHF_FMA_K_AS_BUILTIN 1   // one wavefront per SIMD: every s_nop is a lost issue slot (phf_math.h)
@@ -944,13 +945,22 @@ int env_1_or_2(const char* name) {
   const char* e = getenv(name);
   return (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) ? e[0] - '0' : 0;
 }
-struct HierPolicy { int lanes, wps; };
+struct HierPolicy { std::atomic<int> lanes, wps; };
 HierPolicy& hier_policy() {                                       // first use reads the environment; later changes through the ABI only
-  static HierPolicy p{env_1_or_2("PHF_HIER_LANES"), env_1_or_2("PHF_HIER_WPS")};
+  static HierPolicy p{{env_1_or_2("PHF_HIER_LANES")}, {env_1_or_2("PHF_HIER_WPS")}};
   return p;
 }
-int hier_lanes_override() { return hier_policy().lanes; }
-int hier_wps_override() { return hier_policy().wps; }
+// process-wide policy first, then the launch's own hint (phf_problems.kernel_hint), then 0 = decide from the launch size
+int hier_lanes_override(const HierArgs& a) {
+  const int forced = hier_policy().lanes.load(std::memory_order_relaxed);
+  const int hint = (int)(a.prob.kernel_hint & 3u);
+  return forced ? forced : (hint <= 2 ? hint : 0);
+}
+int hier_wps_override(const HierArgs& a) {
+  const int forced = hier_policy().wps.load(std::memory_order_relaxed);
+  const int hint = (int)((a.prob.kernel_hint >> 2) & 3u);
+  return forced ? forced : (hint <= 2 ? hint : 0);
+}
 
 // a workgroup's 160 KB of LDS less the static part every kernel here has: the exp / log, erfc and normal tables of phf_math.h
 constexpr size_t kMaxDynamicLds = 160 * 1024 - PHF_MATH_LDS_BYTES - PHF_ERFC_TAB_N * sizeof(phf_erfctab) - PHF_NORMAL_TAB_N * sizeof(phf_normtab);
@@ -993,7 +1003,7 @@ int launch_advance2(HierArgs a, hipStream_t stream) {
   a.blocks_per_problem = (a.prob.chains_per_problem + kChains2 - 1) / kChains2;
   const int64_t blocks = (int64_t)a.blocks_per_problem * a.prob.num_problems;
   if (blocks > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
-  const int wps = hier_wps_override();
+  const int wps = hier_wps_override(a);
   if (wps ? wps == 1 : blocks <= phf_simd_count()) return launch_advance2_wps<NE, 1>(a, lds, stream);
   return launch_advance2_wps<NE, 2>(a, lds, stream);
 }
@@ -1002,7 +1012,7 @@ template <int NE>
 int launch_advance(const HierArgs& a, hipStream_t stream) {
 #ifndef PHF_EXP_NO_TWO_LANE
   if constexpr (NE >= kMinNe2 && NE <= kMaxNe2) {
-    const int force = hier_lanes_override();
+    const int force = hier_lanes_override(a);
     const int64_t blocks2 = (int64_t)((a.prob.chains_per_problem + kChains2 - 1) / kChains2) * a.prob.num_problems;
     const bool two = force ? force == 2 : blocks2 <= phf_simd_count();
     if (two) return launch_advance2<NE>(a, stream);
@@ -1091,7 +1101,8 @@ int phf_hierarchical_state_size(int n_expts) {
 
 int phf_hierarchical_set_kernel_policy(int lanes, int wps) {
   if (lanes < 0 || lanes > 2 || wps < 0 || wps > 2) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "kernel policy: lanes and wps must be 0 (automatic), 1 or 2");
-  hier_policy() = HierPolicy{lanes, wps};
+  hier_policy().lanes.store(lanes, std::memory_order_relaxed);
+  hier_policy().wps.store(wps, std::memory_order_relaxed);
   return PHF_OK;
 }
 

@@ -18,6 +18,44 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def visible_gpu_count():
+    """GPUs this process (and the ranks it starts) can use, WITHOUT touching the HIP runtime: the topology the kernel driver
+    publishes (/sys/class/kfd: a node with SIMDs is a GPU), cut down by the visibility variables the runtime honours
+    (ROCR_VISIBLE_DEVICES, then HIP_/CUDA_VISIBLE_DEVICES select from what ROCR left).  Only if the driver's topology is not
+    readable: torch.cuda.device_count(), which MAY initialise the runtime in this process when amdsmi is absent — tolerable only
+    because the ranks are then started as a child process, never by an exec."""
+    import glob
+    n = None
+    try:
+        gpus = 0
+        for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            with open(props) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        gpus += int(line.split()[1]) > 0
+                        break
+        n = gpus if gpus > 0 else None
+    except (OSError, ValueError):
+        n = None
+    if n is None:
+        import torch
+        return torch.cuda.device_count()
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def torchrun_command(n, tail):
+    """`python -m torch.distributed.run` for n ranks on this node: --standalone lets the launcher pick a free rendezvous port itself
+    (a port found by bind-and-close could be taken again before the ranks bind it); --local-addr 127.0.0.1 because the container's
+    host name may not resolve."""
+    import sys
+    return [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+            "--nproc-per-node", str(int(n))] + list(tail)
+
+
 def ranks_for_cores(num_cores):
     """How many ranks a command line's `-c/--num-cores N` (PyHillFit.py:40) / `-nc N` (PyHillTemp.py:25) starts: the reference
     sizes its process pool with that flag (python/PyHillFit.py:997-1003: min(N, cpu_count - 1) workers; PyHillTemp.py:155-159);
@@ -27,20 +65,15 @@ def ranks_for_cores(num_cores):
         return 0
     if os.environ.get("PHF_DIST_BACKEND") == "gloo":
         return int(num_cores)
-    import torch
-    n = min(int(num_cores), torch.cuda.device_count())     # counting devices does not initialise the GPU
+    n = min(int(num_cores), visible_gpu_count())
     return n if n > 1 else 0
 
 
 def spawn_ranks(module, argv, n):
     """Start `python -m torch.distributed.run --nproc-per-node n -m <module> <argv>` as a CHILD process — this process has made no
     GPU call yet, and it is a child, never an exec — and return its exit code (as bench.py --gpus N does)."""
-    import socket
     import subprocess
-    import sys
-    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "-m", module] + list(argv)
+    cmd = torchrun_command(n, ["-m", module] + list(argv))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")

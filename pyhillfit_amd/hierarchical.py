@@ -102,9 +102,10 @@ def _bind(lib):
 
 
 def set_kernel_policy(lanes=0, wps=0):
-    """Which kernel runs Ne = 3..6 groups (phf_hierarchical_set_kernel_policy): lanes per chain 1 | 2, register build of the two-lane
-    kernel 1 | 2 (wavefronts per SIMD), 0 = decided from the launch size.  Every choice gives the same numbers bit for bit; used by
-    the bit-identity tests and for A/B timing.  (PHF_HIER_LANES / PHF_HIER_WPS in the environment set the process's initial values.)"""
+    """PROCESS-WIDE: which kernel runs Ne = 3..6 groups (phf_hierarchical_set_kernel_policy): lanes per chain 1 | 2, register build of
+    the two-lane kernel 1 | 2 (wavefronts per SIMD), 0 = not forced (a sampler's own kernel_hint, else the launch size, decides).  Every
+    choice gives the same numbers bit for bit; used by the bit-identity tests and for A/B timing.  (PHF_HIER_LANES / PHF_HIER_WPS in the
+    environment set the process's initial values; they are read by the library, once.)"""
     lib = _lib.load(); _bind(lib)
     _lib.check(lib.phf_hierarchical_set_kernel_policy(int(lanes), int(wps)), "phf_hierarchical_set_kernel_policy")
 
@@ -114,16 +115,19 @@ def simd_count():
     return int(_lib.load().phf_simd_count())
 
 
-def set_kernel_policy_for(concurrent_chains):
+def hint_side_by_side(samplers):
     """Called by whoever runs SEVERAL samplers side by side (one per Ne group, one stream each): the library decides one launch
     at a time — two lanes per chain when that group's wavefronts would leave SIMDs idle —, but when the groups TOGETHER give every
     SIMD a one-lane wavefront, a two-lane wavefront (half the latency, 1.7x the SIMD time) only takes slots from the others:
-    C4 15.15 -> 14.5 ms with one lane everywhere.  concurrent_chains: chains of all the samplers running concurrently.
-    PHF_HIER_LANES in the environment keeps the last word."""
-    import os
-    if os.environ.get("PHF_HIER_LANES"):
-        return
-    set_kernel_policy(lanes=1 if -(-int(concurrent_chains) // 64) >= simd_count() else 0)
+    C4 15.15 -> 14.5 ms with one lane everywhere.  The choice travels with each sampler's launches (phf_problems.kernel_hint) — no
+    process-wide state is touched, later samplers of the process decide for themselves again — and a process-wide
+    policy (set_kernel_policy, PHF_HIER_LANES) keeps the last word inside the library."""
+    samplers = list(samplers)
+    chains = sum(s.Q * s.C for s in samplers)
+    lanes = 1 if -(-int(chains) // 64) >= simd_count() else 0
+    for s in samplers:
+        s.set_kernel_hint(lanes=lanes)
+    return lanes
 
 
 def log_target_batch(packed, pair_index, theta, prior=None, device="cuda"):
@@ -178,6 +182,13 @@ class HierarchicalSampler(object):
             raise _lib.PhfError(self.lib.phf_last_error().decode())
         self.state = torch.zeros((self.S, self.Q * self.C), dtype=torch.float64, device=dev)
         self.moments, self.moments_after, self.t, self.row0, self._gamma = None, 0, 0, None, None
+
+    def set_kernel_hint(self, lanes=0, wps=0):
+        """which kernel THIS sampler's launches should get (phf_problems.kernel_hint: lanes per chain 1 | 2, register build of the two-lane
+        kernel 1 | 2; 0 = the library decides from the launch size).  Same numbers either way; a process-wide policy overrides it."""
+        if lanes not in (0, 1, 2) or wps not in (0, 1, 2):
+            raise ValueError("kernel hint: lanes and wps must be 0 (automatic), 1 or 2")
+        self.prob.kernel_hint = int(lanes) | (int(wps) << 2)
 
     def init(self, theta0, cov_scale=0.01):
         """theta0: [dim], [Q][dim] or [Q][C][dim]"""
@@ -311,7 +322,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
                 curves.accumulate(s.row0.unsqueeze(0).contiguous(), cdf_chains(args, C))
         runs.append(dict(ne=ne, members=members, theta0=theta0, s=s, kept=kept, buf=buf, seg=seg, r=1, curves=curves, files=files,
                          stream=torch.cuda.Stream(device=device)))
-    set_kernel_policy_for(sum(r["s"].Q * r["s"].C for r in runs))
+    hint_side_by_side(r["s"] for r in runs)
     torch.cuda.synchronize(device)
     start = time.time()
     done = 0

@@ -169,9 +169,10 @@ def test_zero_variance_direction_behaves_like_the_twin(lanes, gpu, oracle_pair):
         assert np.all(cov[8] == 0.0) and np.all(np.delete(np.diag(cov), 8) > 0.0)
 
 
-def test_policy_for_groups_running_side_by_side(gpu, oracle_pair, monkeypatch):
-    """set_kernel_policy_for: one lane per chain once the concurrent groups give every SIMD a wavefront, the library's own choice
-    below that, PHF_HIER_LANES keeps the last word — and whichever kernel runs, the chain is the same bit for bit"""
+def test_policy_for_groups_running_side_by_side(gpu, oracle_pair):
+    """hint_side_by_side: one lane per chain once the concurrent groups give every SIMD a wavefront, the library's own choice below
+    that; the hint travels with the SAMPLER (phf_problems.kernel_hint) — another sampler of the same process is not affected —, a
+    process-wide policy keeps the last word — and whichever kernel runs, the chain is the same bit for bit"""
     from pyhillfit_amd import hierarchical as H
     shapes, scales, locs = H.prior_params()
     p = oracle_pair("Amiodarone", "hERG")
@@ -179,22 +180,34 @@ def test_policy_for_groups_running_side_by_side(gpu, oracle_pair, monkeypatch):
     theta0 = np.array([H.first_iteration(p.experiments, locs)])
     assert H.simd_count() >= 64
 
-    def run():
+    class Many(object):                                             # stands for the other groups of a full chip
+        Q, C = H.simd_count(), 64
+
+        def set_kernel_hint(self, lanes=0, wps=0):
+            self.lanes = lanes
+
+    def make():
         s = H.HierarchicalSampler(packed, [0], 64, thinning=5, seed=3, adapt_start=30, device=gpu)
         s.init(theta0, cov_scale=0.01)
-        return s.advance(100).cpu().numpy()
-    monkeypatch.delenv("PHF_HIER_LANES", raising=False)
+        return s
+    H.set_kernel_policy(0, 0)
     try:
-        H.set_kernel_policy_for(64 * H.simd_count())               # the chip is full: one lane
-        full = run()
-        H.set_kernel_policy_for(64)                                 # one wavefront: the library's choice (two lanes)
-        small = run()
-        monkeypatch.setenv("PHF_HIER_LANES", "2")
-        H.set_kernel_policy_for(64 * H.simd_count())               # no-op: the environment keeps the last word
-        assert np.array_equal(run(), small)
+        a, many = make(), Many()
+        assert H.hint_side_by_side([a, many]) == 1 and a.prob.kernel_hint == 1 and many.lanes == 1     # the chip is full: one lane
+        full = a.advance(100).cpu().numpy()
+        b = make()
+        assert b.prob.kernel_hint == 0                              # a later sampler decides for itself: nothing process-wide was set
+        assert H.hint_side_by_side([b]) == 0                        # one wavefront: the library's choice (two lanes)
+        small = b.advance(100).cpu().numpy()
+        c = make()
+        c.set_kernel_hint(lanes=1)
+        H.set_kernel_policy(2, 0)                                   # the process-wide policy overrides the hint
+        forced = c.advance(100).cpu().numpy()
+        with pytest.raises(ValueError):
+            c.set_kernel_hint(lanes=3)
     finally:
         H.set_kernel_policy(0, 0)
-    assert np.array_equal(full, small)
+    assert np.array_equal(full, small) and np.array_equal(forced, small)
 
 
 @pytest.mark.parametrize("C", [1, 33])

@@ -259,18 +259,47 @@ def test_bench_gpus_n_starts_n_ranks_as_a_child(monkeypatch):
     def fake_call(cmd, env=None):
         seen["cmd"], seen["env"] = cmd, env
         return 7
+    from pyhillfit_amd import distributed as D
     monkeypatch.setattr(bench.subprocess, "call", fake_call)
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(D, "visible_gpu_count", lambda: 4)
     assert bench.spawn_ranks(a) == 7
     cmd = seen["cmd"]
-    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == sys.argv[1:]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd   # the launcher picks the port
+    assert cmd[-6:] == sys.argv[1:]
     assert os.path.basename(cmd[-7]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(D, "visible_gpu_count", lambda: 1)
     seen.clear()
     assert bench.spawn_ranks(a) == 2 and not seen                            # one GPU, four RCCL ranks: refused, nothing started
     monkeypatch.setenv("PHF_BENCH_BACKEND", "gloo")                          # rehearsal: ranks share the one GPU
     assert bench.spawn_ranks(a) == 7 and seen
+
+
+def test_visible_gpu_count_reads_the_driver_topology_not_the_runtime(monkeypatch, tmp_path):
+    """distributed.visible_gpu_count: GPUs = nodes with SIMDs in /sys/class/kfd, cut by ROCR_/HIP_/CUDA_VISIBLE_DEVICES; torch's
+    device_count (which may initialise the HIP runtime) only when the topology cannot be read"""
+    import glob as _glob
+    import torch
+    from pyhillfit_amd import distributed as D
+    nodes = []
+    for k, simds in enumerate([0, 0, 1024, 1024, 1024]):            # two CPU nodes, three GPUs
+        d = tmp_path / str(k); d.mkdir()
+        (d / "properties").write_text("cpu_cores_count 64\nsimd_count %d\nmem_banks_count 1\n" % simds)
+        nodes.append(str(d / "properties"))
+    monkeypatch.setattr(_glob, "glob", lambda pattern: nodes if "kfd" in pattern else [])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: pytest.fail("the runtime must not be asked"))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert D.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert D.visible_gpu_count() == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert D.visible_gpu_count() == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert D.visible_gpu_count() == 0
+    monkeypatch.setattr(_glob, "glob", lambda pattern: [])          # no topology (not an AMD host): fall back to torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 5)
+    assert D.visible_gpu_count() == 5
 
 
 def test_writer_pool_files_equal_the_synchronous_ones(tmp_path):
