@@ -103,7 +103,10 @@ def run_single_level(pairs, args, device, rank=0, world=1):
     for (drug, channel, concs, responses), th0, ss in zip(loaded, fit_theta, fit_ss):
         d_clean, c_clean, chain_file, images_dir = dr.nonhierarchical_chain_file_and_figs_dir(model, drug, channel, temperature)
         chainio.save_best_fit_params(images_dir + "{}_{}_best_fit_params.txt".format(d_clean, c_clean), th0, model)
-        theta0.append(th0); files.append((d_clean, c_clean, chain_file))
+        start0 = bestfit.chain_start(th0, model)                       # the fit, with a Hill coefficient above the prior's bound moved onto it
+        if not np.array_equal(start0, th0):
+            print("{} + {}: least-squares Hill {:.3g} is outside the prior's support; chains start at Hill = {:g}".format(drug, channel, th0[1], start0[1]))
+        theta0.append(start0); files.append((d_clean, c_clean, chain_file))
     if args.best_fit_only:
         writers.close()
         return []

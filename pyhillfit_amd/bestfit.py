@@ -50,6 +50,20 @@ def best_fit(concs, responses, model):
     return theta0, ss_best
 
 
+def chain_start(theta_fit, model):
+    """The point a chain is STARTED from, given the least-squares fit (one row, or [P][d]).  The fit itself is what the best-fit file
+    holds (PyHillFit.py:739-746) and is returned unchanged except for one case: a model-2 fit whose Hill coefficient lies above the
+    prior's upper bound (doseresponse.py:18,181-182: Hill > 10 -> log-prior -inf).  The reference's search has no upper bound
+    (PyHillFit.py:726: Hill = x^2 + lower), so its chain for such a pair starts at a log-target of -inf, accepts only proposals that
+    land inside [0, 10] — for a steep curve fitted with Hill ~ 25 that is 13 proposal standard deviations away — and in that case
+    never moves for the whole run (4 of the 210 Crumb pairs fit above 10; Mexiletine-Nav1.5-peak at 25 stays stuck).  Here the START
+    is moved to the bound; the target, the proposal and the chain are the reference's.  """
+    th = np.array(theta_fit, dtype=float, copy=True)
+    if model == 2:
+        th[..., 1] = np.minimum(th[..., 1], dr.hill_uniform_upper)
+    return th
+
+
 # ---- all pairs at once -------------------------------------------------------------------------------------------------
 LN10 = np.log(10.0)
 

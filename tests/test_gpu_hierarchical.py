@@ -315,30 +315,21 @@ def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):
     assert np.isfinite(chain).all() and (np.diff(chain[:, 0, 0, :], axis=0) != 0).any()
 
 
-def test_hierarchical_posterior_of_every_column_matches_the_reference_loop(gpu, dr_setup):
-    """Golden G10 (tests/golden/make_golden_posteriors_hier.py): the reference's OWN hierarchical loop (python/PyHillFit.py:431-511
-    with the target :173-193, lifted statement by statement) run at its default length — 500 000 iterations, thinning 5, first
-    quarter of the saved rows dropped — with four seeds on one pair of every Ne (3, 4, 5, 6) and two weakly informative pairs.
-    Here: 1 024 chains per pair from the same start point, same length, same burn-in, moments on the device.  EVERY column of the
-    chain — alpha, beta, mu, s, each pIC50_i and Hill_i, sigma and the log-target — has its pooled mean within 1 % of the
-    reference's + 4 of its standard errors (the larger of: batch means pooled over the seeds, scatter between the seeds), and its
-    pooled sd within 20 %."""
+def _hier_posteriors_against_reference_loop(gpu, dr, fixture, C, seed, report_name):
+    """every pair of a G10-style fixture: C chains from the fixture's start point, the reference's run length and burn-in, moments on
+    the device; EVERY column's pooled mean within 1 % + 4 standard errors of the reference's (the larger of: batch means pooled over the
+    seeds, scatter between the seeds), every sd within 20 %, acceptance within 0.02.  Returns the per-pair report."""
     from pyhillfit_amd import hierarchical as H
-    dr = dr_setup
-    with open(os.path.join(GOLDEN, "g10_hier_posteriors.json")) as f:
-        g10 = json.load(f)
-    assert sorted(e["Ne"] for e in g10) == [3, 3, 4, 5, 6, 6]
     groups = {}
-    for e in g10:
+    for e in fixture:
         groups.setdefault(e["Ne"], []).append(e)
-    C = 1024
     report = []
     for ne, entries in sorted(groups.items()):
         T, thin = entries[0]["iterations"], entries[0]["thinning"]
         assert all(e["iterations"] == T and e["thinning"] == thin for e in entries) and T >= 300000
         exs = [dr.load_crumb_data(e["drug"], e["channel"])[2] for e in entries]
         assert all(len(x) == ne for x in exs)
-        s = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(len(exs))), C, thinning=thin, seed=2024, device=gpu)
+        s = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(len(exs))), C, thinning=thin, seed=seed, device=gpu)
         s.init(np.array([e["first_iteration"] for e in entries]), cov_scale=0.01)                   # PyHillFit.py:431
         burn_rows = (T // thin + 1) // 4                                                            # :467-471
         s.enable_moments(after_iteration=burn_rows * thin - 1)
@@ -355,15 +346,43 @@ def test_hierarchical_posterior_of_every_column_matches_the_reference_loop(gpu, 
             se = np.maximum(p["se_batch_means"], p["se_between_seeds"])
             ratio = np.abs(pooled[:, q] - want) / (0.01 * np.abs(want) + 4 * se)
             sd_ratio = pooled_sd[:, q] / want_sd
+            ref_acc = float(np.mean([r["acceptance"] for r in e["runs"]]))
             report.append((e["drug"], e["channel"], ne, float(ratio.max()), int(ratio.argmax()), float(sd_ratio.min()), float(sd_ratio.max()), float(acc[q])))
-            print("G10 %s-%s Ne=%d: worst mean ratio %.2f (column %d), sd ratios %.3f..%.3f, acceptance %.3f (reference %.3f)"
-                  % (report[-1] + (float(np.mean([r["acceptance"] for r in e["runs"]])),)))
+            print("%s %s-%s Ne=%d: worst mean ratio %.2f (column %d), sd ratios %.3f..%.3f, acceptance %.3f (reference %.3f)"
+                  % ((report_name,) + report[-1] + (ref_acc,)))
             assert ratio.max() < 1.0, (e["drug"], e["channel"], int(ratio.argmax()), pooled[:, q], want, se)
             assert sd_ratio.min() > 0.8 and sd_ratio.max() < 1.2, (e["drug"], e["channel"], sd_ratio)
-            assert abs(acc[q] - np.mean([r["acceptance"] for r in e["runs"]])) < 0.02
+            assert abs(acc[q] - ref_acc) < 0.02
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(REPO, "gpurun_out", "g10_report.json"), "w") as f:
+    with open(os.path.join(REPO, "gpurun_out", report_name + "_report.json"), "w") as f:
         json.dump(report, f)
+    return report
+
+
+def test_hierarchical_posterior_of_every_column_matches_the_reference_loop(gpu, dr_setup):
+    """Golden G10 (tests/golden/make_golden_posteriors_hier.py): the reference's OWN hierarchical loop (python/PyHillFit.py:431-511
+    with the target :173-193, lifted statement by statement) run at its default length — 500 000 iterations, thinning 5, first
+    quarter of the saved rows dropped — with four seeds on one pair of every Ne (3, 4, 5, 6) and two weakly informative pairs.
+    Here: 1 024 chains per pair from the same start point, same length, same burn-in, moments on the device.  EVERY column of the
+    chain — alpha, beta, mu, s, each pIC50_i and Hill_i, sigma and the log-target — has its pooled mean within 1 % of the
+    reference's + 4 of its standard errors (the larger of: batch means pooled over the seeds, scatter between the seeds), and its
+    pooled sd within 20 %."""
+    with open(os.path.join(GOLDEN, "g10_hier_posteriors.json")) as f:
+        g10 = json.load(f)
+    assert sorted(e["Ne"] for e in g10) == [3, 3, 4, 5, 6, 6]
+    _hier_posteriors_against_reference_loop(gpu, dr_setup, g10, 1024, 2024, "g10")
+
+
+def test_hierarchical_posterior_of_one_pair_per_drug_matches_the_reference_loop(gpu, dr_setup):
+    """Golden G10b (make_golden_posteriors_hier.py --per-drug, round 4): the same lifted reference loop on ONE PAIR OF EVERY DRUG — 30
+    pairs fixed by a rule written into the generator before any GPU number was seen (drug i takes channel i mod 7), two seeds each,
+    500 000 iterations.  Same strict bar as G10 on every one of the 12..16 columns of every pair: with G10 that is 36 of the 210 pairs
+    pinned column by column to the reference's own sampler; the other 174 rest on (alpha, mu) against the reference's stored draws
+    (next test)."""
+    with open(os.path.join(GOLDEN, "g10b_hier_posteriors_per_drug.json")) as f:
+        g10b = json.load(f)
+    assert len(g10b) == 30 and len({e["drug"] for e in g10b}) == 30 and all(len(e["runs"]) == 2 for e in g10b)
+    _hier_posteriors_against_reference_loop(gpu, dr_setup, g10b, 512, 2025, "g10b")
 
 
 def test_all_pairs_alpha_mu_against_the_reference_stored_samples(gpu):
@@ -405,5 +424,6 @@ def test_all_pairs_alpha_mu_against_the_reference_stored_samples(gpu):
             names.append((d, c))
     z, sd_ratio = np.array(z), np.array(sd_ratio)
     assert len(names) == 210
-    assert z.max() < 6 and np.mean(z < 4) >= 0.98, (names[int(z.argmax())], z.max(), np.mean(z < 4))
+    print("chaste/samples: worst z %.2f at %s; pairs beyond 3: %s" % (z.max(), names[int(z.argmax())], [(names[k], round(float(z[k]), 2)) for k in np.flatnonzero(z > 3)]))
+    assert z.max() < 4, (names[int(z.argmax())], z.max(), [(names[k], float(z[k])) for k in np.flatnonzero(z >= 4)])       # no pair allowed outside (round 4: was max < 6 and 98 % below 4)
     assert np.all(sd_ratio > 0.6) and np.all(sd_ratio < 1.6), (sd_ratio.min(), sd_ratio.max())   # posterior widths too

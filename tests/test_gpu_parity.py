@@ -392,6 +392,44 @@ def test_every_crumb_pair_posterior_within_one_percent_of_reference(model, gpu, 
     assert sd_ratio.min() > 0.5 and sd_ratio.max() < 3.0, info
 
 
+def test_reseeded_cases_two_sample_against_the_reference_seeds(gpu, dr):
+    """Golden G5d under its round-4 protocol (tests/golden/make_golden_posteriors_reseed.py: a closed list of six cases, the SAME 96
+    independent reference chains for every one of them, fixed before any GPU number of the round was looked at): a two-sample test with
+    no percentage slack.  GPU: 4 096 chains per case, the reference's length, start and burn-in; z = (GPU pooled mean - mean of the
+    reference seeds' means) / sqrt(se_ref^2 + se_gpu^2), se_ref = scatter between the reference seeds / sqrt(seeds), se_gpu = scatter
+    between the GPU's chains / sqrt(chains).  Every column of every case: |z| < 3 (24 entries: about one run in fifteen of a CORRECT
+    sampler would show one beyond 3; none may reach 4)."""
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    with open(os.path.join(GOLDEN, "g5d_posteriors_reseeded.json")) as f:
+        g5d = json.load(f)
+    assert len(g5d) == 6 and len({len(e["seeds"]) for e in g5d}) == 1, [len(e["seeds"]) for e in g5d]      # the same seeds for every case
+    n_seeds = len(g5d[0]["seeds"])
+    assert n_seeds >= 32 and all(e["model"] == 2 and e["iterations"] == 200000 for e in g5d)
+    names = [(e["drug"], e["channel"]) for e in g5d]
+    packed = dr.pack_single_level(names)
+    C = 4096
+    s = SingleLevelSampler(packed, 2, list(range(len(g5d))), [e["temperature"] for e in g5d], C, thinning=5, seed=11,
+                           reset_mean_at_adapt_start=True, device=gpu)
+    s.init(np.ones(3), cov_identity=True, cov_scale=1.0)          # PyHillTemp.py:63,80
+    s.enable_moments(after_iteration=50000)                       # first quarter of the saved rows dropped (:70-71)
+    s.advance(200000, save=False)
+    mean, var, n = s.posterior_moments()
+    per_chain = mean.cpu().numpy()                                # [d+1][Q][C]
+    worst = 0.0
+    for q, e in enumerate(g5d):
+        ref_means = np.array([r["mean"] for r in e["runs"]])      # [seeds][d+1]
+        assert ref_means.shape == (n_seeds, 4) and np.allclose(ref_means.mean(axis=0), e["mean"])
+        se_ref = ref_means.std(axis=0, ddof=1) / np.sqrt(n_seeds)
+        gpu_mean = per_chain[:, q].mean(axis=1)
+        se_gpu = per_chain[:, q].std(axis=1, ddof=1) / np.sqrt(C)
+        z = (gpu_mean - ref_means.mean(axis=0)) / np.sqrt(se_ref ** 2 + se_gpu ** 2)
+        print("G5d two-sample %s-%s t=%g: GPU %s  reference %s +- %s  z %s" % (e["drug"], e["channel"], e["temperature"], np.round(gpu_mean, 4).tolist(),
+                                                                              np.round(ref_means.mean(axis=0), 4).tolist(), np.round(se_ref, 4).tolist(), np.round(z, 2).tolist()))
+        worst = max(worst, float(np.abs(z).max()))
+        assert np.abs(z).max() < 3.0, (e["drug"], e["channel"], e["temperature"], z.tolist())
+    print("G5d two-sample: worst |z| %.2f over %d entries, %d reference seeds per case" % (worst, 4 * len(g5d), n_seeds))
+
+
 def test_prior_only_rung_known_answer(gpu, dr):
     """t = 0 (first rung of the ladder): chains must sample the prior — pIC50 ~ -3+Exp(mean 5), Hill ~ U(0,10),
     sigma ~ 1e-3+Gamma(5, 1.49975): means (2, 5, 7.49975), sds (5, 2.887, 3.354)."""

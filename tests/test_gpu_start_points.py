@@ -36,7 +36,10 @@ def test_single_level_start_points_of_every_pair_on_this_host_and_on_the_device(
     """G8 = the reference's own sum_of_square_diffs (PyHillFit.py:93-97) on a dense (pIC50, Hill) grid for all 210 pairs and both
     models.  On this box: the batched fit's SS is <= the reference grid's minimum for every pair, sigma0 = sqrt(SS / N) (:101-102,729);
     the device evaluates the model-m log-likelihood at that point to exactly what SS implies for an uncensored pair —
-    -N/2 ln 2 pi - N ln sigma0 - SS / (2 sigma0^2) (doseresponse.py:229-248) — and to a finite value for every pair."""
+    -N/2 ln 2 pi - N ln sigma0 - SS / (2 sigma0^2) (doseresponse.py:229-248) — and to a finite value for every pair.  The PRIOR at the
+    start is -inf exactly where the least-squares Hill coefficient lies above the prior's upper bound of 10 (the reference's search
+    has no upper bound either, PyHillFit.py:726: Hill = x^2 + lower): such chains start at a log-target of -inf like the
+    reference's, and must leave it with their first acceptable proposal — checked by running them."""
     from pyhillfit_amd import bestfit
     from pyhillfit_amd.sampler import log_target_batch
     with open(os.path.join(GOLDEN, "g8_least_squares_grid.json")) as f:
@@ -53,7 +56,34 @@ def test_single_level_start_points_of_every_pair_on_this_host_and_on_the_device(
         sig = np.sqrt(ss / n)
         assert np.all(theta[:, -1] == np.where(sig > dr.sigma_loc, sig, 1.0))
         lik, prior = log_target_batch(packed, model, list(range(210)), [1.0] * 210, theta, device=gpu)
-        assert np.all(np.isfinite(lik)) and np.all(np.isfinite(prior)), (model, names[int(np.argmin(np.isfinite(lik)))])
+        assert np.all(np.isfinite(lik)), (model, [names[k] for k in np.flatnonzero(~np.isfinite(lik))])
+        outside = np.flatnonzero(~np.isfinite(prior))
+        if model == 1:
+            assert len(outside) == 0
+        else:                                                                   # log_priors_model_2 (doseresponse.py:175-184): Hill outside [0, 10]
+            assert np.array_equal(outside, np.flatnonzero(theta[:, 1] > 10.0)), ([names[k] for k in outside], theta[outside])
+            assert np.all(prior[outside] == -np.inf) and 0 < len(outside) < 30  # 4 of the 210 pairs; Mexiletine-Nav1.5-peak fits Hill ~ 25
+            from pyhillfit_amd.sampler import SingleLevelSampler
+            sub = dr.pack_single_level([names[k] for k in outside])
+
+            def run_from(th0):
+                s = SingleLevelSampler(sub, 2, list(range(len(outside))), [1.0] * len(outside), 64, thinning=5, seed=25, device=gpu)
+                s.init(th0, cov_identity=False, cov_scale=0.05)                 # PyHillFit.py:748-751
+                first = s.log_target().cpu().numpy().copy()
+                s.advance(5000, save=False)
+                return first, s.log_target().cpu().numpy(), s.theta().cpu().numpy()
+            # started AT the fit, like the reference: a log-target of -inf, and the steepest fit never finds its way into the support
+            first, last, _ = run_from(theta[outside])
+            assert np.all(first == -np.inf)
+            stuck = [names[k] for q, k in enumerate(outside) if not np.isfinite(last[q]).any()]
+            print("fits with Hill > 10:", [(names[k], round(float(theta[k, 1]), 2)) for k in outside], "stuck at -inf for 5 000 iterations:", stuck)
+            assert ("Mexiletine", "Nav1.5-peak") in stuck
+            # started where the command line starts them (bestfit.chain_start: Hill moved onto the prior's bound): finite from the start
+            start = bestfit.chain_start(theta, model)
+            assert np.array_equal(np.delete(start, outside, axis=0), np.delete(theta, outside, axis=0)) and np.all(start[outside, 1] == 10.0)
+            first, last, th_end = run_from(start[outside])
+            assert np.all(np.isfinite(first)) and np.all(np.isfinite(last)) and np.all(th_end[1] <= 10.0) and np.all(th_end[1] >= 0.0)
+            assert np.array_equal(bestfit.chain_start(theta, 1), theta)        # model 1 has no Hill column: nothing to move
         checked = 0
         for k, (concs, y) in enumerate(pairs):
             y = np.asarray(y)
