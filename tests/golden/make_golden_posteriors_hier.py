@@ -17,9 +17,16 @@ written down before any GPU number was looked at: drug i (the data file's order)
 already in G10 the next channel; seeds 201 and 202 for every pair, no pair gets more.  Written to a fixture of its own
 (g10b_hier_posteriors_per_drug.json) so that G10 stays what it was.
 
+G10c (--all-remaining, round 4): every pair that is in neither G10 nor G10b — the other 174 of the 210 — two seeds each (301, 302), so
+that EVERY Crumb pair's hierarchical posterior is pinned column by column to the reference's own loop.  The rule (all remaining pairs,
+the same two seeds for each, no pair topped up) is fixed here before any run or GPU number exists.  Runs are appended to
+g10c_runs.jsonl as they finish (an interrupted generation can be resumed: finished (pair, seed) runs are not repeated); the fixture
+g10c_hier_posteriors_all_remaining.json holds the pairs of which BOTH seeds are done, in the data file's order.
+
 TEST INFRASTRUCTURE, generator side only (needs /root/reference; 18 runs of 3-6 minutes spread over worker processes).
     python tests/golden/make_golden_posteriors_hier.py [--iterations 500000] [--seeds 3] [--workers 7]
     python tests/golden/make_golden_posteriors_hier.py --per-drug [--workers 5]          (60 runs of 4-8 minutes)
+    python tests/golden/make_golden_posteriors_hier.py --all-remaining [--workers 7]     (348 runs: ~4 hours on 7 cores)
 """
 import argparse
 import contextlib
@@ -92,6 +99,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--workers", type=int, default=7)
     ap.add_argument("--per-drug", action="store_true", help="G10b: one pair of every drug (rule in the docstring), seeds 201, 202")
+    ap.add_argument("--all-remaining", action="store_true", help="G10c: every pair in neither G10 nor G10b, seeds 301, 302 (resumable)")
     a = ap.parse_args()
     import _ref_loader as R
     import make_golden as G
@@ -100,6 +108,8 @@ def main():
     _, _, locs, _ = G.elkins_prior_params()
     global PAIRS
     first_seed, out_name = 101, "g10_hier_posteriors.json"
+    if a.all_remaining:
+        return all_remaining(a, dr, locs)
     if a.per_drug:
         drugs, channels = list(dr.drugs), list(dr.channels)
         chosen = []
@@ -141,6 +151,68 @@ def main():
     with open(os.path.join(HERE, out_name), "w") as f:
         json.dump(out, f, indent=1)
     print(out_name + " written: %d pairs x %d seeds in %.0f s" % (len(PAIRS), a.seeds, time.time() - t0))
+
+
+def _pool_entry(d, c, start, mine, iterations, thinning):
+    means = np.array([r["mean"] for r in mine]); sds = np.array([r["sd"] for r in mine]); ses = np.array([r["batch_means_se"] for r in mine])
+    n = len(mine)
+    pooled = {"mean": means.mean(axis=0).tolist(), "sd": np.sqrt((sds ** 2).mean(axis=0) + means.var(axis=0)).tolist(),
+              "se_batch_means": (np.sqrt((ses ** 2).sum(axis=0)) / n).tolist(),
+              "se_between_seeds": (means.std(axis=0, ddof=1) / np.sqrt(n)).tolist() if n > 1 else None}
+    return {"drug": d, "channel": c, "Ne": (len(start) - 5) // 2, "dim": len(start), "first_iteration": list(start), "iterations": iterations,
+            "thinning": thinning, "burn": "first quarter of the saved rows", "columns": "alpha, beta, mu, s, (pIC50_i, Hill_i) x Ne, sigma, log-target",
+            "pooled": pooled, "runs": mine}
+
+
+def all_remaining(a, dr, locs):
+    """G10c: see the module docstring"""
+    import make_golden as G
+    from pyhillfit_amd import bestfit
+    done = set()
+    for name in ("g10_hier_posteriors.json", "g10b_hier_posteriors_per_drug.json"):
+        with open(os.path.join(HERE, name)) as f:
+            done |= {(e["drug"], e["channel"]) for e in json.load(f)}
+    pairs = [(d, c) for d in dr.drugs for c in dr.channels if (d, c) not in done]
+    starts = {}
+    for d, c in pairs:
+        starts[(d, c)] = np.asarray(bestfit.hierarchical_first_iteration(G.concat_pair(dr, d, c)["experiments"], locs), dtype=float)
+    log_path = os.path.join(HERE, "g10c_runs.jsonl")
+    runs = []
+    if os.path.exists(log_path):                              # the scratch log of an interrupted generation (git-ignored) ...
+        with open(log_path) as f:
+            runs = [json.loads(l) for l in f if l.strip()]
+    fixture_path = os.path.join(HERE, "g10c_hier_posteriors_all_remaining.json")
+    if os.path.exists(fixture_path):                          # ... and the runs the committed fixture already holds
+        with open(fixture_path) as f:
+            known = {(r["drug"], r["channel"], r["seed"]) for r in runs}
+            runs += [r for e in json.load(f) for r in e["runs"] if (r["drug"], r["channel"], r["seed"]) not in known]
+    have = {(r["drug"], r["channel"], r["seed"]) for r in runs}
+    seeds = (301, 302)
+    jobs = [(d, c, s, a.iterations, a.thinning, starts[(d, c)].tolist()) for d, c in pairs for s in seeds if (d, c, s) not in have]   # pair-major
+    print("G10c: %d pairs, %d runs to do (%d already in %s)" % (len(pairs), len(jobs), len(runs), os.path.basename(log_path)), flush=True)
+    t0 = time.time()
+
+    def write_fixture():
+        out = []
+        for d, c in pairs:
+            mine = sorted([r for r in runs if (r["drug"], r["channel"]) == (d, c)], key=lambda r: r["seed"])
+            if [r["seed"] for r in mine] == list(seeds):
+                out.append(_pool_entry(d, c, starts[(d, c)].tolist(), mine, a.iterations, a.thinning))
+        with open(os.path.join(HERE, "g10c_hier_posteriors_all_remaining.json"), "w") as f:
+            json.dump(out, f, separators=(",", ":"))
+        return len(out)
+    with mp.get_context("fork").Pool(a.workers) as pool, open(log_path, "a") as log:
+        for k, r in enumerate(pool.imap_unordered(_run, jobs)):
+            for key in ("q05", "q50", "q95"):                 # the quantiles are not used by any test: keep the fixture small
+                r.pop(key, None)
+            runs.append(r)
+            log.write(json.dumps(r) + "\n"); log.flush()
+            print("  G10c %-14s %-12s seed %d: acceptance %.3f, %.0f s (%.0f s elapsed, %d of %d)"
+                  % (r["drug"], r["channel"], r["seed"], r["acceptance"], r["seconds"], time.time() - t0, k + 1, len(jobs)), flush=True)
+            if (k + 1) % 28 == 0:
+                write_fixture()
+    n = write_fixture()
+    print("g10c_hier_posteriors_all_remaining.json written: %d pairs complete of %d in %.0f s" % (n, len(pairs), time.time() - t0))
 
 
 if __name__ == "__main__":
