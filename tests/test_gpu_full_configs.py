@@ -214,6 +214,32 @@ def test_queued_launch_at_the_bench_shape(gpu, dr):
     assert 0.15 < float(acc.mean()) < 0.45
 
 
+def test_one_long_queued_advance_is_cut_into_bounded_quanta(gpu, dr):
+    """ONE advance() of 120 000 iterations on a queued launch (210 pairs x 1 024 chains = 3 360 blocks over 2 048 persistent wavefronts):
+    the host cuts it into quanta of at most MAX_QUANTUM_ITERATIONS (30 here, not the 4 of `queue_quanta`), so that a wavefront's wait
+    for its block's previous quantum stays far below the kernel's give-up limit however long the call — no fault word,
+    every block's progress word at the quantum count, and the same final state, bit for bit, as twelve calls of 10 000."""
+    from pyhillfit_amd.sampler import MAX_QUANTUM_ITERATIONS, SingleLevelSampler, queue_quantum
+    names = _all_names(dr)
+    packed = dr.pack_single_level(names)
+    Q, T = len(names), 120000
+    assert queue_quantum(T, 4, 5) == MAX_QUANTUM_ITERATIONS == 4000
+    got = []
+    for calls in (1, 12):
+        s = SingleLevelSampler(packed, 2, list(range(Q)), [1.0] * Q, 1024, thinning=5, seed=25, device=gpu, queue_quanta=4)
+        s.init([6.0, 0.8, 8.0], cov_identity=False, cov_scale=0.05)
+        s.enable_moments(after_iteration=20000)
+        s.reserve(T)
+        for _ in range(calls):
+            s.advance(T // calls, save=False)
+        s.check_queue()                                               # raises if any wavefront gave up waiting
+        q_ = s._queue.cpu().numpy()
+        quanta_last_call = -(-(T // calls) // queue_quantum(T // calls, 4, 5))
+        assert q_[-1] == 0 and np.all(q_[1:-1] == quanta_last_call) and q_[0] < 0x40000000, (calls, q_[0], q_[-1])
+        got.append((s.state.clone(), s.moments.clone()))
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+
+
 # ------------------------------------------------------------------------------------- C3 / C4 at full width
 def test_c3_full_width_shard_invariance_and_checkpoint(gpu, dr):
     """210 pairs x 4 096 chains (BASELINE configs[2]): one launch == the pairs split over 3 'ranks' by cost
