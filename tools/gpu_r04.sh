@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 GPU pass F: the whole GPU suite, ONE default bench (the driver's command), the 2-rank rehearsal, the host-side profile of the
+# Round-4 GPU pass: the whole GPU suite, ONE default bench (the driver's command), the 2-rank rehearsal, the host-side profile of the
 # command lines.  PHF_STEPS selects.
 set -u
 mkdir -p gpurun_out
