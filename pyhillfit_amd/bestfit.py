@@ -7,10 +7,15 @@ Deterministic: coarse grid + Nelder-Mead polish.  Deviation (SURVEY.md section 7
 zero) the reference starts at sigma = 0, a point of -inf log-target with a zero-variance sigma proposal that its
 chain can never leave; here such starts use sigma0 = 1."""
 import numpy as np
-from scipy.optimize import minimize
-import scipy.stats as st
 
 from . import doseresponse as dr
+
+
+def minimize(*args, **kwargs):
+    """scipy.optimize.minimize, imported at first use: only the scalar fits (tests, the cross-checks of the batched path) need it, and
+    importing scipy.optimize + scipy.stats costs 0.3 s of a 3 s command-line run (profiles/r04/cli_host_profile_single_level.txt)"""
+    from scipy.optimize import minimize as _minimize
+    return _minimize(*args, **kwargs)
 
 
 def _curve(concs, pic50, hill):
@@ -276,6 +281,7 @@ def _hyper_start(best_fits, locs):
         alpha_cur = locs[0] + 0.1
     if beta_cur <= locs[1]:
         beta_cur = locs[1] + 0.1
+    import scipy.stats as st
     mu_cur, s_cur = st.logistic.fit(best_fits[:, 0])                 # :330
     if mu_cur <= locs[2]:
         mu_cur = locs[2] + 0.1

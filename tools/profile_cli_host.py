@@ -28,12 +28,12 @@ def main():
     t1 = time.perf_counter()
     import torch
     t2 = time.perf_counter()
-    import pandas  # noqa: F401  (the data reader)
+    import csv  # noqa: F401  (the data reader is the stdlib csv module: nothing to time)
     t3 = time.perf_counter()
     from pyhillfit_amd import PyHillFit
     from pyhillfit_amd import hierarchical  # noqa: F401
     t4 = time.perf_counter()
-    say("imports: numpy %.2f s, torch %.2f s, pandas %.2f s, pyhillfit_amd (+ scipy) %.2f s" % (t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+    say("imports: numpy %.2f s, torch %.2f s, pyhillfit_amd %.2f s (scipy is imported only by the scalar fits)" % (t1 - t0, t2 - t1, t4 - t3))
     t5 = time.perf_counter()
     torch.zeros(1, device="cuda:0"); torch.cuda.synchronize()
     say("first GPU call (HIP runtime + context): %.2f s" % (time.perf_counter() - t5))
