@@ -17,8 +17,16 @@ brought to the same 96.)  The GPU tests use the pooled runs in two ways: as the 
 pairs, and in a two-sample test of their own — GPU pooled mean against the 96 reference chains, |z| < 3 with the standard error from
 the scatter between the reference seeds, no percentage slack (tests/test_gpu_parity.py).
 
+G5e (--widths, round 4): a follow-up for posterior WIDTHS.  With 256 GPU chains per pair against G5c's single reference chain, 12 of
+the 1 050 (pair, model, column) sd ratios lie outside [0.8, 1.25] (tools/diag_sd_ratios.py; none of them a G5d pair): a single 200 000-iteration
+chain estimates the sd of a long-tailed marginal poorly.  Rule, fixed before any of these runs existed: every (pair, model) that shows
+such an entry — the twelve cases listed in CASES_WIDTHS — gets seeds 1..32, all of them the same number, none topped up afterwards;
+whatever the pooled sd then says is what the test holds the GPU to (tests/test_gpu_parity.py), and an entry that still disagrees is
+reported as such, not reseeded again.
+
 TEST INFRASTRUCTURE, generator side only (needs /root/reference; 576 runs of 15-50 s over worker processes, runs already in the fixture are kept).
     python tests/golden/make_golden_posteriors_reseed.py [--workers 5]
+    python tests/golden/make_golden_posteriors_reseed.py --widths [--workers 7]        (12 cases x 32 seeds: ~45 minutes on 7 cores)
 """
 import argparse
 import json
@@ -36,6 +44,12 @@ CASES = [("Ranolazine", "Nav1.5-peak", 2, 1.0), ("Nilotinib", "KvLQT1/mink", 2, 
          ("Sotalol", "Kv4.3", 2, 1.0), ("Amitriptyline", "Kir2.1", 2, 1.0),
          ("Amiodarone", "hERG", 2, 0.0)]                 # prior-only rung: analytic answer known, reached slowly
 SEEDS = 96                                               # the same for every case (see PROTOCOL above)
+# G5e: the (pair, model) cases with a posterior-width ratio outside [0.8, 1.25] against G5c's single chain (tools/diag_sd_ratios.py, round 4)
+CASES_WIDTHS = [("Chloroquine", "Nav1.5-late", 2, 1.0), ("Mibefradil", "Nav1.5-peak", 2, 1.0), ("Toremifene", "hERG", 2, 1.0),
+                ("Nilotinib", "Cav1.2", 2, 1.0), ("Rufinamide", "Cav1.2", 2, 1.0), ("Flecainide", "KvLQT1/mink", 2, 1.0),
+                ("Propafenone", "Kv4.3", 2, 1.0), ("Lidocaine", "Kv4.3", 2, 1.0), ("Diltiazem", "Kv4.3", 2, 1.0),
+                ("Bepridil", "KvLQT1/mink", 1, 1.0), ("Chloroquine", "Nav1.5-peak", 1, 1.0), ("Nilotinib", "Cav1.2", 1, 1.0)]
+SEEDS_WIDTHS = 32
 
 _dr = None
 
@@ -65,8 +79,13 @@ def main():
     ap.add_argument("--seeds", type=int, default=SEEDS, help="seeds 1..N for EVERY case (the fixture the tests read has N = %d)" % SEEDS)
     ap.add_argument("--workers", type=int, default=5)
     ap.add_argument("--fresh", action="store_true", help="recompute every run instead of adding the missing ones to the fixture")
+    ap.add_argument("--widths", action="store_true", help="G5e: the posterior-width follow-up cases, %d seeds each" % SEEDS_WIDTHS)
     a = ap.parse_args()
+    global CASES
     out_path = os.path.join(HERE, "g5d_posteriors_reseeded.json")
+    if a.widths:
+        CASES, out_path = CASES_WIDTHS, os.path.join(HERE, "g5e_posterior_widths_reseeded.json")
+        a.seeds = SEEDS_WIDTHS
     runs = []
     if os.path.exists(out_path) and not a.fresh:          # runs already made are kept: only the missing (case, seed) are computed
         with open(out_path) as f:
@@ -94,7 +113,7 @@ def main():
                     "runs": mine})
     with open(out_path, "w") as f:
         json.dump(out, f, indent=1)
-    print("G5d written: %d cases x %d seeds in %.0f s" % (len(CASES), a.seeds, time.time() - t0))
+    print("%s written: %d cases x %d seeds in %.0f s" % (os.path.basename(out_path), len(CASES), a.seeds, time.time() - t0))
 
 
 if __name__ == "__main__":

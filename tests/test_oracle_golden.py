@@ -281,6 +281,20 @@ def test_g10_and_g5d_fixtures_are_what_their_generators_say():
         z = np.abs(means[0] - means[1]) / np.sqrt(ses[0] ** 2 + ses[1] ** 2)
         assert z.max() < 5.0, (e["drug"], e["channel"], float(z.max()))     # the two seeds agree within their own errors (observed max 3.4)
         assert np.allclose(e["pooled"]["se_between_seeds"], np.abs(means[0] - means[1]) / 2)
+    path = os.path.join(GOLDEN, "g10c_hier_posteriors_all_remaining.json")          # G10c: every pair in neither G10 nor G10b, seeds 301, 302
+    if os.path.exists(path):
+        with open(path) as f:
+            g10c = json.load(f)
+        pinned = in_g10 | set(want)
+        rest = [(d, c) for d in drugs for c in channels if (d, c) not in pinned]
+        mine = [(e["drug"], e["channel"]) for e in g10c]
+        assert len(rest) == 174 and mine == [pc for pc in rest if pc in set(mine)]   # a subset of the remaining pairs, in the data file's order
+        for e in g10c:
+            assert e["iterations"] == 500000 and e["thinning"] == 5 and [r["seed"] for r in e["runs"]] == [301, 302] and e["dim"] == 5 + 2 * e["Ne"]
+            assert all(r["reference_lines"] == [[431, 511]] and r["rows"] == 75001 and 0.23 < r["acceptance"] < 0.27 for r in e["runs"])
+            means = np.array([r["mean"] for r in e["runs"]]); ses = np.array([r["batch_means_se"] for r in e["runs"]])
+            z = np.abs(means[0] - means[1]) / np.sqrt(ses[0] ** 2 + ses[1] ** 2)
+            assert z.max() < 6.0, (e["drug"], e["channel"], float(z.max()))
     with open(os.path.join(GOLDEN, "g5d_posteriors_reseeded.json")) as f:
         g5d = json.load(f)
     assert len(g5d) == 6 and all(e["seeds"] == list(range(1, 97)) and e["iterations"] == 200000 for e in g5d)      # the same seeds for every case
