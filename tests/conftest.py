@@ -77,9 +77,13 @@ def reference_posteriors(model, temperature=1.0):
     mean = np.array([w["mean"] for w in g5c]).T
     se = np.array([w["batch_means_se"] for w in g5c]).T
     sd = np.array([w["sd"] for w in g5c]).T
-    path = os.path.join(GOLDEN, "g5d_posteriors_reseeded.json")
     reseeded = []
-    if os.path.exists(path):
+    # G5d: the closed list of cases with 96 reference seeds each; G5e (round 4): the posterior-width follow-up, 32 seeds for each of the
+    # twelve (pair, model) cases whose sd ratio against G5c's single chain lay outside [0.8, 1.25] (make_golden_posteriors_reseed.py --widths)
+    for fixture in ("g5d_posteriors_reseeded.json", "g5e_posterior_widths_reseeded.json"):
+        path = os.path.join(GOLDEN, fixture)
+        if not os.path.exists(path):
+            continue
         with open(path) as f:
             for e in json.load(f):
                 if e["model"] == model and e["temperature"] == temperature and (e["drug"], e["channel"]) in names:

@@ -359,11 +359,14 @@ def test_every_crumb_pair_posterior_within_one_percent_of_reference(model, gpu, 
     1 % of the reference mean + 4 standard errors of the reference — the batch-means s.e. of its single chain, or, for the five
     weakly informative pairs whose single chain proved too short to say what the mean is (golden G5d: eight and more independent
     reference chains each; Ranolazine-Nav1.5-peak's seed-1 chain sits 3.5 of the others' standard errors from their mean), the
-    pooled mean and the s.e. of the reseeded runs (conftest.reference_posteriors)."""
+    pooled mean and the s.e. of the reseeded runs (conftest.reference_posteriors).  Posterior WIDTHS: every sd within [0.8, 1.25] of the
+    reference's, no entry excepted, with golden G5e (32 reference seeds for each of the twelve (pair, model) cases whose single G5c chain
+    gave a width outside that band; rule fixed before the runs) standing in for those cases' single chains."""
     from conftest import reference_posteriors
     from pyhillfit_amd.sampler import SingleLevelSampler
     names, want, se, want_sd, reseeded = reference_posteriors(model)
-    assert len(names) == 210 and (model == 1 or len(reseeded) == 5)
+    have_g5e = os.path.exists(os.path.join(GOLDEN, "g5e_posterior_widths_reseeded.json"))
+    assert len(names) == 210 and len(reseeded) == ((5 if model == 2 else 0) + ((9 if model == 2 else 3) if have_g5e else 0))
     packed = dr.pack_single_level(names)
     s = SingleLevelSampler(packed, model, list(range(len(names))), [1.0] * len(names), 256, thinning=5, seed=5,
                            reset_mean_at_adapt_start=True, device=gpu)
@@ -383,13 +386,19 @@ def test_every_crumb_pair_posterior_within_one_percent_of_reference(model, gpu, 
                     "reference": float(want[k, q]), "reference_se": float(se[k, q]), "gpu_sd": float(pooled_sd[k, q])} for k, q in order], f, indent=1)
     # EVERY (pair, column): within 1 % of the reference's mean + 4 of its standard errors — no fraction allowed to fail
     assert ratio.max() < 1.0, (ratio.max(), names[worst[1]], worst[0], pooled[worst], want[worst], se[worst])
-    # posterior widths: the reference's single 200k chain estimates an sd poorly where the posterior has a long thin tail
-    # (Hill of weakly informative pairs), so the bulk is checked tightly and the extremes loosely
+    # posterior widths.  The reference's single 200k chain estimates an sd poorly where the posterior has a long thin tail (Hill of weakly
+    # informative pairs): against G5c alone 12 of the 1 050 ratios lay outside [0.8, 1.25] (tools/diag_sd_ratios.py).  Golden G5e gives each of
+    # those (pair, model) cases 32 reference seeds (rule fixed before the runs): with it EVERY width is held to [0.8, 1.25]
     sd_ratio = pooled_sd[:s.d] / want_sd[:s.d]
     lo, hi = np.unravel_index(np.argmin(sd_ratio), sd_ratio.shape), np.unravel_index(np.argmax(sd_ratio), sd_ratio.shape)
     info = (sd_ratio.min(), names[lo[1]], lo[0], sd_ratio.max(), names[hi[1]], hi[0], np.mean((sd_ratio > 0.8) & (sd_ratio < 1.25)))
-    assert np.mean((sd_ratio > 0.8) & (sd_ratio < 1.25)) >= 0.97, info
-    assert sd_ratio.min() > 0.5 and sd_ratio.max() < 3.0, info
+    print("posterior widths model %d: sd ratios %.3f (%s column %d) .. %.3f (%s column %d)" % (model, info[0], info[1], info[2], info[3], info[4], info[5]))
+    if have_g5e:
+        outside = [(names[q], int(k), round(float(sd_ratio[k, q]), 3)) for k, q in zip(*np.nonzero((sd_ratio <= 0.8) | (sd_ratio >= 1.25)))]
+        assert not outside, outside
+    else:
+        assert np.mean((sd_ratio > 0.8) & (sd_ratio < 1.25)) >= 0.97, info
+        assert sd_ratio.min() > 0.5 and sd_ratio.max() < 3.0, info
 
 
 def test_reseeded_cases_two_sample_against_the_reference_seeds(gpu, dr):

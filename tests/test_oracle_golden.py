@@ -298,6 +298,13 @@ def test_g10_and_g5d_fixtures_are_what_their_generators_say():
     with open(os.path.join(GOLDEN, "g5d_posteriors_reseeded.json")) as f:
         g5d = json.load(f)
     assert len(g5d) == 6 and all(e["seeds"] == list(range(1, 97)) and e["iterations"] == 200000 for e in g5d)      # the same seeds for every case
+    path = os.path.join(GOLDEN, "g5e_posterior_widths_reseeded.json")               # G5e: the width follow-up, 12 cases x seeds 1..32
+    if os.path.exists(path):
+        with open(path) as f:
+            g5e = json.load(f)
+        assert len(g5e) == 12 and all(e["seeds"] == list(range(1, 33)) and e["iterations"] == 200000 and e["temperature"] == 1.0 for e in g5e)
+        assert sorted(e["model"] for e in g5e) == [1] * 3 + [2] * 9
+        assert not {(e["drug"], e["channel"], e["model"]) for e in g5e} & {(e["drug"], e["channel"], e["model"]) for e in g5d}
     rano = [e for e in g5d if e["drug"] == "Ranolazine"][0]
     p = np.array([r["mean"][0] for r in rano["runs"]])
     with open(os.path.join(GOLDEN, "g5c_posteriors_all_pairs_model_2.json")) as f:
