@@ -23,10 +23,19 @@ the same two seeds for each, no pair topped up) is fixed here before any run or 
 g10c_runs.jsonl as they finish (an interrupted generation can be resumed: finished (pair, seed) runs are not repeated); the fixture
 g10c_hier_posteriors_all_remaining.json holds the pairs of which BOTH seeds are done, in the data file's order.
 
+G10d (--follow-up, round 4): the first GPU comparison against G10c (512 chains per pair) left 8 of the 174 pairs with an entry outside
+the bar — all of them in a Hill_i column (or beta) of a pair with a steep experiment, where that coefficient's posterior is the
+log-logistic level's heavy tail and two reference chains cannot say what its mean and width are (GPU widths 1.5 .. 4.8 x the
+reference's).  Follow-up, fixed before any of its runs existed: exactly those 8 pairs (FOLLOW_UP below) get 8 further seeds (311..318) —
+the same number each, pooled with their seeds 301, 302 —; the test then holds the GPU to the ten-seed reference (whose between-seed
+scatter is what says how well the reference itself knows a heavy-tailed mean), and whatever still lies outside is REPORTED, not reseeded
+again.
+
 TEST INFRASTRUCTURE, generator side only (needs /root/reference; 18 runs of 3-6 minutes spread over worker processes).
     python tests/golden/make_golden_posteriors_hier.py [--iterations 500000] [--seeds 3] [--workers 7]
     python tests/golden/make_golden_posteriors_hier.py --per-drug [--workers 5]          (60 runs of 4-8 minutes)
     python tests/golden/make_golden_posteriors_hier.py --all-remaining [--workers 7]     (348 runs: ~4 hours on 7 cores)
+    python tests/golden/make_golden_posteriors_hier.py --follow-up [--workers 7]         (64 runs: ~50 minutes)
 """
 import argparse
 import contextlib
@@ -51,6 +60,11 @@ PAIRS = [("Amiodarone", "hERG"),          # Ne = 3: 4+4+4 points, informative
          ("Amitriptyline", "Kv4.3"),      # Ne = 6: 4+4+4+4+2+1 (one response out of range)
          ("Sertindole", "Kir2.1"),        # Ne = 3, weakly informative: 11 of 12 responses are exactly 0
          ("Cibenzoline", "Kv4.3")]        # Ne = 6, weakly informative: 4+4+4+1+1+1, 10 of 15 zero
+
+# G10d: the pairs with an entry outside the bar in the first GPU comparison against G10c (see the docstring), 8 further seeds each
+FOLLOW_UP = [("Azithromycin", "Kir2.1"), ("Mexiletine", "Nav1.5-peak"), ("Moxifloxacin", "Cav1.2"), ("Nilotinib", "Kir2.1"),
+             ("Ondansetron", "Kir2.1"), ("Propafenone", "Kir2.1"), ("Ranolazine", "Cav1.2"), ("Dofetilide", "Cav1.2")]
+FOLLOW_UP_SEEDS = tuple(range(311, 319))
 
 NB = 25                                   # batches for the batch-means standard error
 
@@ -100,6 +114,7 @@ def main():
     ap.add_argument("--workers", type=int, default=7)
     ap.add_argument("--per-drug", action="store_true", help="G10b: one pair of every drug (rule in the docstring), seeds 201, 202")
     ap.add_argument("--all-remaining", action="store_true", help="G10c: every pair in neither G10 nor G10b, seeds 301, 302 (resumable)")
+    ap.add_argument("--follow-up", action="store_true", help="G10d: the FOLLOW_UP pairs, seeds 311..318 (resumable)")
     a = ap.parse_args()
     import _ref_loader as R
     import make_golden as G
@@ -110,6 +125,9 @@ def main():
     first_seed, out_name = 101, "g10_hier_posteriors.json"
     if a.all_remaining:
         return all_remaining(a, dr, locs)
+    if a.follow_up:
+        return all_remaining(a, dr, locs, pairs=list(FOLLOW_UP), seeds=FOLLOW_UP_SEEDS, tag="g10d", fixture="g10d_hier_posteriors_follow_up.json",
+                             keep_quantiles=True)
     if a.per_drug:
         drugs, channels = list(dr.drugs), list(dr.channels)
         chosen = []
@@ -164,32 +182,33 @@ def _pool_entry(d, c, start, mine, iterations, thinning):
             "pooled": pooled, "runs": mine}
 
 
-def all_remaining(a, dr, locs):
-    """G10c: see the module docstring"""
+def all_remaining(a, dr, locs, pairs=None, seeds=(301, 302), tag="g10c", fixture="g10c_hier_posteriors_all_remaining.json", keep_quantiles=False):
+    """G10c (and, with a pair list, G10d): see the module docstring"""
     import make_golden as G
     from pyhillfit_amd import bestfit
-    done = set()
-    for name in ("g10_hier_posteriors.json", "g10b_hier_posteriors_per_drug.json"):
-        with open(os.path.join(HERE, name)) as f:
-            done |= {(e["drug"], e["channel"]) for e in json.load(f)}
-    pairs = [(d, c) for d in dr.drugs for c in dr.channels if (d, c) not in done]
+    if pairs is None:
+        done = set()
+        for name in ("g10_hier_posteriors.json", "g10b_hier_posteriors_per_drug.json"):
+            with open(os.path.join(HERE, name)) as f:
+                done |= {(e["drug"], e["channel"]) for e in json.load(f)}
+        pairs = [(d, c) for d in dr.drugs for c in dr.channels if (d, c) not in done]
     starts = {}
     for d, c in pairs:
         starts[(d, c)] = np.asarray(bestfit.hierarchical_first_iteration(G.concat_pair(dr, d, c)["experiments"], locs), dtype=float)
-    log_path = os.path.join(HERE, "g10c_runs.jsonl")
+    log_path = os.path.join(HERE, tag + "_runs.jsonl")
     runs = []
     if os.path.exists(log_path):                              # the scratch log of an interrupted generation (git-ignored) ...
         with open(log_path) as f:
             runs = [json.loads(l) for l in f if l.strip()]
-    fixture_path = os.path.join(HERE, "g10c_hier_posteriors_all_remaining.json")
+    fixture_path = os.path.join(HERE, fixture)
     if os.path.exists(fixture_path):                          # ... and the runs the committed fixture already holds
         with open(fixture_path) as f:
             known = {(r["drug"], r["channel"], r["seed"]) for r in runs}
             runs += [r for e in json.load(f) for r in e["runs"] if (r["drug"], r["channel"], r["seed"]) not in known]
     have = {(r["drug"], r["channel"], r["seed"]) for r in runs}
-    seeds = (301, 302)
+    seeds = tuple(seeds)
     jobs = [(d, c, s, a.iterations, a.thinning, starts[(d, c)].tolist()) for d, c in pairs for s in seeds if (d, c, s) not in have]   # pair-major
-    print("G10c: %d pairs, %d runs to do (%d already in %s)" % (len(pairs), len(jobs), len(runs), os.path.basename(log_path)), flush=True)
+    print("%s: %d pairs, %d runs to do (%d already in %s)" % (tag, len(pairs), len(jobs), len(runs), os.path.basename(log_path)), flush=True)
     t0 = time.time()
 
     def write_fixture():
@@ -198,21 +217,21 @@ def all_remaining(a, dr, locs):
             mine = sorted([r for r in runs if (r["drug"], r["channel"]) == (d, c)], key=lambda r: r["seed"])
             if [r["seed"] for r in mine] == list(seeds):
                 out.append(_pool_entry(d, c, starts[(d, c)].tolist(), mine, a.iterations, a.thinning))
-        with open(os.path.join(HERE, "g10c_hier_posteriors_all_remaining.json"), "w") as f:
+        with open(fixture_path, "w") as f:
             json.dump(out, f, separators=(",", ":"))
         return len(out)
     with mp.get_context("fork").Pool(a.workers) as pool, open(log_path, "a") as log:
         for k, r in enumerate(pool.imap_unordered(_run, jobs)):
-            for key in ("q05", "q50", "q95"):                 # the quantiles are not used by any test: keep the fixture small
+            for key in (() if keep_quantiles else ("q05", "q50", "q95")):   # G10c: the quantiles are not used by any test: keep the fixture small
                 r.pop(key, None)
             runs.append(r)
             log.write(json.dumps(r) + "\n"); log.flush()
-            print("  G10c %-14s %-12s seed %d: acceptance %.3f, %.0f s (%.0f s elapsed, %d of %d)"
-                  % (r["drug"], r["channel"], r["seed"], r["acceptance"], r["seconds"], time.time() - t0, k + 1, len(jobs)), flush=True)
+            print("  %s %-14s %-12s seed %d: acceptance %.3f, %.0f s (%.0f s elapsed, %d of %d)"
+                  % (tag, r["drug"], r["channel"], r["seed"], r["acceptance"], r["seconds"], time.time() - t0, k + 1, len(jobs)), flush=True)
             if (k + 1) % 28 == 0:
                 write_fixture()
     n = write_fixture()
-    print("g10c_hier_posteriors_all_remaining.json written: %d pairs complete of %d in %.0f s" % (n, len(pairs), time.time() - t0))
+    print("%s written: %d pairs complete of %d in %.0f s" % (fixture, n, len(pairs), time.time() - t0))
 
 
 if __name__ == "__main__":
