@@ -18,14 +18,11 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def visible_gpu_count():
-    """GPUs this process (and the ranks it starts) can use, WITHOUT touching the HIP runtime: the topology the kernel driver
-    publishes (/sys/class/kfd: a node with SIMDs is a GPU), cut down by the visibility variables the runtime honours
-    (ROCR_VISIBLE_DEVICES, then HIP_/CUDA_VISIBLE_DEVICES select from what ROCR left).  Only if the driver's topology is not
-    readable: torch.cuda.device_count(), which MAY initialise the runtime in this process when amdsmi is absent — tolerable only
-    because the ranks are then started as a child process, never by an exec."""
+def _gpu_count_from_driver_topology():
+    """GPUs by the topology the kernel driver publishes (/sys/class/kfd: a node with SIMDs is a GPU), cut down by the visibility
+    variables the runtime honours (ROCR_VISIBLE_DEVICES, then HIP_/CUDA_VISIBLE_DEVICES select from what ROCR left); None if the
+    topology is not readable.  No HIP call — but also blind to visibility restricted by other means (device-node permissions)."""
     import glob
-    n = None
     try:
         gpus = 0
         for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
@@ -34,17 +31,36 @@ def visible_gpu_count():
                     if line.startswith("simd_count"):
                         gpus += int(line.split()[1]) > 0
                         break
-        n = gpus if gpus > 0 else None
     except (OSError, ValueError):
-        n = None
-    if n is None:
-        import torch
-        return torch.cuda.device_count()
+        return None
+    if gpus == 0:
+        return None
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
-            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
-    return n
+            gpus = min(gpus, len([x for x in v.split(",") if x.strip() != ""]))
+    return gpus
+
+
+def visible_gpu_count():
+    """GPUs this process (and the ranks it starts) can use, WITHOUT touching the HIP runtime in THIS process (ADVICE r03:
+    torch.cuda.device_count() may initialise it when amdsmi is absent, and the process then holds it while its ranks run).  The
+    runtime's own answer is asked of a short-lived CHILD interpreter — exact whatever restricts visibility —; if that fails, the
+    driver's topology files are read; torch in this process is the last resort (tolerable only because ranks are started as a child
+    process, never by an exec)."""
+    import subprocess
+    import sys
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=180)
+        if out.returncode == 0:
+            return int(out.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+        pass
+    n = _gpu_count_from_driver_topology()
+    if n is not None:
+        return n
+    import torch
+    return torch.cuda.device_count()
 
 
 def torchrun_command(n, tail):

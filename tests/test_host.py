@@ -275,19 +275,27 @@ def test_bench_gpus_n_starts_n_ranks_as_a_child(monkeypatch):
     assert bench.spawn_ranks(a) == 7 and seen
 
 
-def test_visible_gpu_count_reads_the_driver_topology_not_the_runtime(monkeypatch, tmp_path):
-    """distributed.visible_gpu_count: GPUs = nodes with SIMDs in /sys/class/kfd, cut by ROCR_/HIP_/CUDA_VISIBLE_DEVICES; torch's
-    device_count (which may initialise the HIP runtime) only when the topology cannot be read"""
+def test_visible_gpu_count_asks_a_child_then_the_driver_topology_never_this_process_first(monkeypatch, tmp_path):
+    """distributed.visible_gpu_count: the runtime's answer from a short-lived CHILD interpreter; if that fails, GPUs = nodes with SIMDs
+    in /sys/class/kfd cut by ROCR_/HIP_/CUDA_VISIBLE_DEVICES; torch in this process (which may initialise the HIP runtime) only last"""
     import glob as _glob
+    import subprocess
     import torch
     from pyhillfit_amd import distributed as D
+
+    class Done(object):
+        def __init__(self, rc, out):
+            self.returncode, self.stdout = rc, out
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: pytest.fail("this process's runtime must not be asked"))
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: Done(0, "some warning\n6\n"))
+    assert D.visible_gpu_count() == 6                                # the child's answer (last line of its output)
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: Done(1, ""))   # the child fails: the driver's topology
     nodes = []
     for k, simds in enumerate([0, 0, 1024, 1024, 1024]):            # two CPU nodes, three GPUs
         d = tmp_path / str(k); d.mkdir()
         (d / "properties").write_text("cpu_cores_count 64\nsimd_count %d\nmem_banks_count 1\n" % simds)
         nodes.append(str(d / "properties"))
     monkeypatch.setattr(_glob, "glob", lambda pattern: nodes if "kfd" in pattern else [])
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: pytest.fail("the runtime must not be asked"))
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         monkeypatch.delenv(var, raising=False)
     assert D.visible_gpu_count() == 3
@@ -297,7 +305,11 @@ def test_visible_gpu_count_reads_the_driver_topology_not_the_runtime(monkeypatch
     assert D.visible_gpu_count() == 1
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
     assert D.visible_gpu_count() == 0
-    monkeypatch.setattr(_glob, "glob", lambda pattern: [])          # no topology (not an AMD host): fall back to torch
+
+    def boom(*a, **k):
+        raise OSError("no interpreter")
+    monkeypatch.setattr(subprocess, "run", boom)
+    monkeypatch.setattr(_glob, "glob", lambda pattern: [])          # no child, no topology (not an AMD host): torch, last
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 5)
     assert D.visible_gpu_count() == 5
 
