@@ -168,6 +168,17 @@ def test_best_fit_start_points(dr):
     assert ss < 1e-9 and th[2] == 1.0                                   # not the reference's absorbing sigma0 = 0
 
 
+def test_chain_start_moves_only_a_hill_above_the_priors_bound():
+    """bestfit.chain_start: the fit is the start, except a model-2 Hill coefficient above hill_uniform_upper (doseresponse.py:18), which is
+    moved ONTO the bound (inside the support: doseresponse.py:181-182 rejects hill > 10 only); model 1 has no Hill column"""
+    from pyhillfit_amd import bestfit
+    th = np.array([[6.0, 0.7, 8.0], [5.0, 24.98, 3.0], [4.0, 10.0, 2.0], [3.0, 10.0000001, 1.0]])
+    out = bestfit.chain_start(th, 2)
+    assert np.array_equal(out, [[6.0, 0.7, 8.0], [5.0, 10.0, 3.0], [4.0, 10.0, 2.0], [3.0, 10.0, 1.0]]) and out is not th and th[1, 1] == 24.98
+    assert np.array_equal(bestfit.chain_start(th[1], 2), [5.0, 10.0, 3.0])             # one row
+    assert np.array_equal(bestfit.chain_start(np.array([[6.0, 25.0]]), 1), [[6.0, 25.0]])   # model 1: (pIC50, sigma)
+
+
 def test_batched_least_squares_against_the_reference_objective_grid(dr):
     """golden G8 (tests/golden/make_golden_bestfit.py): the reference's own sum_of_square_diffs (python/PyHillFit.py:93-97),
     lifted and evaluated on a dense (pIC50, Hill) grid for every Crumb pair and both models.  The product's batched fit
