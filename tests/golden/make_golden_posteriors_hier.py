@@ -167,7 +167,7 @@ def main():
                     "burn": "first quarter of the saved rows", "columns": "alpha, beta, mu, s, (pIC50_i, Hill_i) x Ne, sigma, log-target",
                     "pooled": pooled, "runs": mine})
     with open(os.path.join(HERE, out_name), "w") as f:
-        json.dump(out, f, indent=1)
+        json.dump(out, f, separators=(",", ":"))            # compact: the fixtures are data, not prose
     print(out_name + " written: %d pairs x %d seeds in %.0f s" % (len(PAIRS), a.seeds, time.time() - t0))
 
 

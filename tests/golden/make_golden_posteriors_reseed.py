@@ -112,7 +112,7 @@ def main():
                     "se_single_chain_batch_means": np.array([r["batch_means_se"] for r in mine]).mean(axis=0).tolist(),
                     "runs": mine})
     with open(out_path, "w") as f:
-        json.dump(out, f, indent=1)
+        json.dump(out, f, separators=(",", ":"))            # compact: the fixtures are data, not prose
     print("%s written: %d cases x %d seeds in %.0f s" % (os.path.basename(out_path), len(CASES), a.seeds, time.time() - t0))
 
 
