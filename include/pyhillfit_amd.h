@@ -253,6 +253,15 @@ int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior
  * from one hardware estimate (ABI 5; python/PyHillFit.py:831 draws through numpy's factorisation of the same covariance). */
 int phf_debug_math(int fn, int64_t n, const double* in, double* out, void* stream);
 
+/* The same for the hand-allocated gfx950 code object (ABI 6; tools/gen_hier_isa.py, tools/isa/phf_isa_math.py): every elementary
+ * function of the assembly build of the hierarchical Ne = 3 iteration, evaluated on an array by a unit kernel of the same code object —
+ * each must reproduce its C namesake in pyhillfit_amd/csrc/phf_math.h bit for bit (tests/test_gpu_isa.py).
+ * fn: 0 phf_exp_fast_k, 1 phf_exp_capped_k, 2 phf_log_pos_k, 3 phf_log_fast_k, 4 phf_erfc_tab, 5 phf_rcp, 6 phf_sqrt_nonneg (in, out:
+ * device double [n]); 7 phf_normal_u32, 8 phf_log_pos_k(phf_unit_open32(w)) (in: device uint32 [n], out: device double [n]);
+ * 9 Philox4x32-7 (in: device uint32 [n][6] = counter words 0..3, key words 0..1 — the KEY OF ELEMENT 0 is used for the whole call,
+ * as the kernels advance the key schedule on the scalar unit; out: device uint32 [n][4]). */
+int phf_debug_isa(int fn, int64_t n, const void* in, void* out, void* stream);
+
 /* The four Philox4x32-R words of n (counter, key) tuples: in device uint32 [n][6], out device uint32 [n][4].
  * phf_debug_philox: R = the rounds the samplers draw with, phf_philox_rounds() (7 since ABI 5; rounds 1-3 of this build: 10);
  * phf_debug_philox_rounds: R = 7 or 10 (both are held to the Random123 known-answer vectors).  Plays the role of the reference's

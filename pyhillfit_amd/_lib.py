@@ -11,7 +11,7 @@ ABI_VERSION = 5
 # every symbol include/pyhillfit_amd.h declares
 EXPORTS = ["phf_version", "phf_last_error", "phf_simd_count", "phf_single_level_state_size", "phf_single_level_init",
            "phf_single_level_advance", "phf_single_level_advance_queued", "phf_single_level_queue_status", "phf_single_level_log_target",
-           "phf_debug_math", "phf_philox_rounds", "phf_debug_philox", "phf_debug_philox_rounds", "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance",
+           "phf_debug_math", "phf_debug_isa", "phf_philox_rounds", "phf_debug_philox", "phf_debug_philox_rounds", "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance",
            "phf_hierarchical_set_kernel_policy", "phf_hierarchical_log_target", "phf_predictive_scratch_bytes", "phf_predictive_accumulate"]
 
 
@@ -70,6 +70,7 @@ def load():
     lib.phf_simd_count.restype = C.c_int
     lib.phf_single_level_log_target.argtypes = [C.POINTER(Points), i32, i64, vp, vp, vp, vp, vp, vp]
     lib.phf_debug_math.argtypes = [i32, i64, vp, vp, vp]
+    lib.phf_debug_isa.argtypes = [i32, i64, vp, vp, vp]
     lib.phf_debug_philox.argtypes = [i64, vp, vp, vp]
     lib.phf_debug_philox_rounds.argtypes = [i32, i64, vp, vp, vp]
     lib.phf_philox_rounds.restype = C.c_int

@@ -15,7 +15,11 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpyhillfit_amd.so")
 TEXTIO_SRC = os.path.join(CSRC, "phf_textio.cpp")                 # host-only C++ (chain-file text), built with g++
 TEXTIO_LIB = os.path.join(LIB_DIR, "libphf_textio.so")
-SOURCES = ["phf_capi.hip", "phf_single_level.hip", "phf_hierarchical.hip", "phf_predictive.hip"]
+SOURCES = ["phf_capi.hip", "phf_single_level.hip", "phf_hierarchical.hip", "phf_predictive.hip", "phf_hier3_isa.hip"]
+# the hand-allocated gfx950 code object: generated assembly (tools/gen_hier_isa.py; committed) -> .o -> .co, embedded by phf_hier3_isa.hip
+ISA_SRC = os.path.join(CSRC, "generated", "phf_hier3_gfx950.s")
+ISA_CO = os.path.join(LIB_DIR, "obj", "phf_hier3_gfx950.co")
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
@@ -56,17 +60,36 @@ def _write_stamp(artefact, digest):
 
 
 def _headers():
-    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "pyhillfit_amd.h")]
+    return (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "generated", "*.h"))
+            + [os.path.join(HERE, "..", "include", "pyhillfit_amd.h")])
+
+
+def build_isa(verbose=False):
+    """assemble and link the generated gfx950 assembly into a code object (clang as the assembler, ld.lld; no compiler involved)"""
+    os.makedirs(os.path.dirname(ISA_CO), exist_ok=True)
+    digest = _digest([ISA_SRC], ["isa-1"])
+    if _is_current(ISA_CO, digest):
+        return ISA_CO
+    obj = ISA_CO[:-3] + ".o"
+    for cmd in ([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", ISA_SRC, "-o", obj],
+                [os.path.join(LLVM_BIN, "ld.lld"), "-shared", obj, "-o", ISA_CO]):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    _write_stamp(ISA_CO, digest)
+    return ISA_CO
 
 
 def _object_digest(src, extra_flags=()):
     # every header of csrc/ (globbed, not a hand-kept list: the oracle's Makefile wildcards the same headers, and a stale library
     # next to a rebuilt twin would make the two silently diverge) + the public header + the flags
-    return _digest([src] + _headers(), [f for f in FLAGS if f] + list(extra_flags))
+    # (the generated assembly counts as a source of the object that embeds its code object)
+    isa = [ISA_SRC] if os.path.basename(src) == "phf_hier3_isa.hip" else []
+    return _digest([src] + isa + _headers(), [f for f in FLAGS if f] + list(extra_flags))
 
 
 def _library_digest(extra_flags=()):
-    return _digest([os.path.join(CSRC, s) for s in SOURCES] + _headers(), [f for f in FLAGS if f] + list(extra_flags))
+    return _digest([os.path.join(CSRC, s) for s in SOURCES] + [ISA_SRC] + _headers(), [f for f in FLAGS if f] + list(extra_flags))
 
 
 def build_textio(force=False, verbose=False):
@@ -92,6 +115,8 @@ def needs_build():
 
 def _compile_one(src, obj, extra_flags, verbose):
     cmd = [_hipcc()] + [f for f in FLAGS if f and f != "-shared"] + list(extra_flags) + ["-c", "-o", obj, src]
+    if os.path.basename(src) == "phf_hier3_isa.hip":
+        cmd.insert(1, '-DPHF_ISA_CO_PATH="%s"' % os.path.abspath(ISA_CO))
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -101,6 +126,7 @@ def _compile_one(src, obj, extra_flags, verbose):
 def build(force=False, verbose=False, extra_flags=()):
     """one object per source (compiled side by side: the sampler kernels take a minute each), then one link"""
     build_textio(force, verbose)
+    build_isa(verbose)
     digest = _library_digest(extra_flags)
     if not force and _is_current(LIB_PATH, digest):
         return LIB_PATH

@@ -307,6 +307,29 @@ def debug_math(fn, x, device="cuda"):
     return out.cpu().numpy()
 
 
+def debug_isa(fn, x, device="cuda"):
+    """phf_debug_isa: the unit kernels of the hand-allocated gfx950 code object (include/pyhillfit_amd.h lists fn).  x: float64 array
+    (fn 0..6), uint32 array (fn 7, 8) or uint32 [n][6] (fn 9: Philox4x32-7 with the key of element 0; returns uint32 [n][4])."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    if fn <= 6:
+        xin = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
+        out = torch.empty_like(xin)
+        n = xin.numel()
+    elif fn <= 8:
+        xin = torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint32).view(np.int32)).to(dev)
+        out = torch.empty(xin.numel(), dtype=torch.float64, device=dev)
+        n = xin.numel()
+    else:
+        ck = np.ascontiguousarray(x, dtype=np.uint32).reshape(-1, 6)
+        xin = torch.from_numpy(ck.view(np.int32)).to(dev)
+        out = torch.empty((ck.shape[0], 4), dtype=torch.int32, device=dev)
+        n = ck.shape[0]
+    _lib.check(lib.phf_debug_isa(int(fn), n, _ptr(xin), _ptr(out), _stream_ptr(dev)), "phf_debug_isa")
+    res = out.cpu().numpy()
+    return res.view(np.uint32) if fn == 9 else res
+
+
 def debug_philox(counter_key, device="cuda", rounds=0):
     """Philox4x32-R blocks on the device; rounds 7 or 10, 0 = the samplers' own (phf_philox_rounds)"""
     lib = _lib.load()
