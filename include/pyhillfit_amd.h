@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PHF_ABI_VERSION 5
+#define PHF_ABI_VERSION 6
 
 enum {
   PHF_OK = 0,
@@ -78,7 +78,8 @@ typedef struct phf_problems {
   uint32_t chain_id_base;        /* global number of local chain 0 (Philox counter word 0) */
   uint32_t kernel_hint;          /* hierarchical launches (ABI 5; was `reserved`, must be 0 for single-level): which kernel THIS launch
                                     should get — bits 0-1 lanes per chain (1 | 2), bits 2-3 register build of the two-lane kernel (1 | 2
-                                    wavefronts per SIMD); 0 = the library decides from the launch size.  A host that runs several
+                                    wavefronts per SIMD), bit 4 (ABI 6) = 1: not the gfx950 assembly build of the Ne = 3 iteration (A/B timing,
+                                    bit-identity tests); 0 = the library decides from the launch size.  A host that runs several
                                     groups side by side sets it per launch (the groups together fill the chip although each alone
                                     would not); a process-wide policy (phf_hierarchical_set_kernel_policy, PHF_HIER_LANES / _WPS) overrides it.
                                     Every choice gives the same numbers bit for bit. */
@@ -192,7 +193,10 @@ typedef struct phf_hier_points {
   int32_t num_pairs;          /* P */
   int32_t stride;             /* doubles per pair row in ln_conc/response */
   int32_t n_expts;            /* Ne, the same for every pair of this set */
-  int32_t reserved;
+  int32_t points_per_expt;    /* ABI 6 (was `reserved`): n > 0 = EVERY experiment of EVERY pair of this set has exactly n points (the caller's
+                                 statement about its data, like n_expts; expt_start must say the same); 0 = experiments differ, or unknown.
+                                 With n_expts == 3 and points_per_expt == 4 (147 of the Crumb set's 210 pairs) launches that get one lane
+                                 per chain run the hand-allocated gfx950 build of the iteration (two wavefronts per SIMD): same numbers. */
   const double* ln_conc;      /* device [P][stride] */
   const double* response;     /* device [P][stride] */
   const int32_t* expt_start;  /* device [P][Ne+1]  first point of each experiment; [Ne] = number of points */
@@ -234,6 +238,14 @@ int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* pro
  * phf_problems.kernel_hint, else the launch size, decides.  The environment variables PHF_HIER_LANES / PHF_HIER_WPS give the initial
  * values and are read ONCE, here in the library, at the first use; the two words are plain atomics (any thread may set them). */
 int phf_hierarchical_set_kernel_policy(int lanes, int wps);
+
+/* Which kernel the calling thread's last phf_hierarchical_advance launched (ABI 6; 0 = none yet): the tests that compare kernels
+ * against each other assert through it that the kernel they mean is the one that ran. */
+#define PHF_HIER_KERNEL_ONE_LANE 1     /* hier_advance_kernel<Ne>: one lane per chain, hipcc */
+#define PHF_HIER_KERNEL_TWO_LANES 2    /* hier_advance2_kernel<Ne, wps> */
+#define PHF_HIER_KERNEL_WAVE 3         /* hier_wave_advance_kernel: one wavefront per chain (Ne > 8) */
+#define PHF_HIER_KERNEL_GFX950_ISA 4   /* phf_hier3_advance: the hand-allocated gfx950 build (Ne = 3, four points per experiment) */
+int phf_hierarchical_last_kernel(void);
 
 /* log_target_distribution (python/PyHillFit.py:173-193) at M parameter vectors: theta device [dim][M]. */
 int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior* prior, int64_t m,

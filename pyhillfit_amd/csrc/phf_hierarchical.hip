@@ -15,6 +15,7 @@
 #define PHF_FMA_K_AS_BUILTIN 1   // one wavefront per SIMD: every s_nop is a lost issue slot (phf_math.h)
 #include "../../include/pyhillfit_amd.h"
 #include "phf_common.h"
+#include "phf_hier3_isa.h"
 #include "phf_hier_model.h"
 
 namespace {
@@ -917,11 +918,16 @@ int check(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_p
     const int64_t bpp = (pts->n_expts > PHF_HIER_FAST_EXPTS) ? prob->chains_per_problem : (prob->chains_per_problem + kBlock - 1) / kBlock;
     if (bpp * prob->num_problems > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
     if ((int64_t)prob->num_problems * prob->chains_per_problem > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains");
+    if ((prob->kernel_hint & 3u) == 3u || ((prob->kernel_hint >> 2) & 3u) == 3u || (prob->kernel_hint & ~31u))
+      return phf_fail(PHF_ERR_INVALID_ARGUMENT, "kernel_hint: bits 0-1 and 2-3 hold 0, 1 or 2; bit 4 = not the gfx950 assembly build; the other bits must be 0");
   }
+  if (pts->points_per_expt < 0 || (pts->points_per_expt > 0 && pts->points_per_expt * pts->n_expts > pts->stride))
+    return phf_fail(PHF_ERR_INVALID_ARGUMENT, "phf_hier_points.points_per_expt: 0 (experiments differ / unknown) or the number of points of EVERY experiment");
   return PHF_OK;
 }
 
 constexpr int kMaxDevices = 64;
+thread_local int g_last_kernel = 0;               // phf_hierarchical_last_kernel(): what this thread's last advance launched
 
 int current_device() {
   int dev = 0;
@@ -956,6 +962,43 @@ int hier_lanes_override(const HierArgs& a) {
   const int hint = (int)(a.prob.kernel_hint & 3u);
   return forced ? forced : (hint <= 2 ? hint : 0);
 }
+// The hand-allocated gfx950 build of the Ne = 3 iteration (phf_hier3_isa.hip, tools/gen_hier_isa.py): 256 registers, two wavefronts
+// per SIMD, 256-thread workgroups sharing one copy of the function tables.  Used for a launch that (a) holds pairs with exactly four
+// points in each of three experiments (phf_hier_points.points_per_expt == 4: the caller's statement about its data, like n_expts),
+// (b) would get the one-lane kernel, (c) is not told otherwise: kernel_hint bit 4 or PHF_HIER_ISA=0 in the environment (read once)
+// select the hipcc kernels — same numbers bit for bit, kept for A/B timing and for the bit-identity tests.
+bool hier_isa_enabled() {
+  static const bool on = [] { const char* e = getenv("PHF_HIER_ISA"); return !(e && e[0] == '0' && e[1] == 0); }();
+  return on;
+}
+
+int launch_isa3(const HierArgs& a, hipStream_t stream, bool* launched) {
+  *launched = false;
+  const int64_t bpp = a.blocks_per_problem;
+  const int64_t total = bpp * a.prob.num_problems;
+  if (a.cfg.adapt_start < 0 || a.t_end >= 0xffffffffLL || total * bpp >= (1LL << 32) || total > 0x7fffffffLL) return PHF_OK;   // hipcc kernels
+  if (!phf_hier3_isa_available()) return PHF_OK;
+  phf_hier3_isa_args g{};
+  g.state = a.state; g.rows = a.rows; g.moments = a.moments; g.gamma = a.cfg.gamma;
+  g.ln_conc = a.pts.ln_conc; g.response = a.pts.response; g.pair_index = a.prob.pair_index; g.problem_id = a.prob.problem_id;
+  g.launch_order = a.prob.launch_order; g.chain_offset = a.prob.chain_offset;
+  g.t_begin = (uint32_t)a.t_begin; g.t_end = (uint32_t)a.t_end;
+  g.adapt_start = (uint32_t)(a.cfg.adapt_start > 0xffffffffLL ? 0xffffffffLL : a.cfg.adapt_start);
+  g.thinning = a.cfg.thinning;
+  g.moments_after = (uint32_t)(a.moments_after < 0 ? 0 : (a.moments_after > 0xffffffffLL ? 0xffffffffLL : a.moments_after));
+  g.chains = a.prob.chains_per_problem; g.num_problems = a.prob.num_problems; g.bpp = (int32_t)bpp;
+  g.bpp_magic = bpp == 1 ? 0u : (uint32_t)((1ULL << 32) / (uint64_t)bpp + 1ULL);
+  g.total_waves = (int32_t)total;
+  g.seed_lo = (uint32_t)a.cfg.seed; g.seed_hi = (uint32_t)(a.cfg.seed >> 32);
+  g.chain_id_base = a.prob.chain_id_base; g.pts_stride = a.pts.stride;
+  g.until_save0 = a.cfg.thinning - (int32_t)(a.t_begin % a.cfg.thinning);
+  for (int i = 0; i < 5; ++i) { g.prior_loc[i] = a.prior.loc[i]; g.prior_inv_scale[i] = a.prior.inv_scale[i]; g.prior_shape_m1[i] = a.prior.shape_m1[i]; }
+  g.three_twelve[0] = 3.0; g.three_twelve[1] = 12.0;
+  *launched = true;
+  g_last_kernel = PHF_HIER_KERNEL_GFX950_ISA;
+  return phf_hier3_isa_advance(&g, stream);
+}
+
 int hier_wps_override(const HierArgs& a) {
   const int forced = hier_policy().wps.load(std::memory_order_relaxed);
   const int hint = (int)((a.prob.kernel_hint >> 2) & 3u);
@@ -984,6 +1027,7 @@ int launch_advance1(const HierArgs& a, hipStream_t stream) {
   static bool configured[kMaxDevices] = {};
   if (int rc = allow_big_lds(&hier_advance_kernel<NE>, configured)) return rc;
   hipLaunchKernelGGL((hier_advance_kernel<NE>), grid, block, lds, stream, a);
+  g_last_kernel = PHF_HIER_KERNEL_ONE_LANE;
   return phf_check_launch("phf_hierarchical_advance");
 }
 
@@ -993,6 +1037,7 @@ int launch_advance2_wps(const HierArgs& a, size_t lds, hipStream_t stream) {
   if (int rc = allow_big_lds(&hier_advance2_kernel<NE, WPS>, configured)) return rc;
   const dim3 grid((unsigned)(a.blocks_per_problem * a.prob.num_problems)), block(kBlock);
   hipLaunchKernelGGL((hier_advance2_kernel<NE, WPS>), grid, block, lds, stream, a);
+  g_last_kernel = PHF_HIER_KERNEL_TWO_LANES;
   return phf_check_launch("phf_hierarchical_advance (two lanes per chain)");
 }
 
@@ -1018,6 +1063,13 @@ int launch_advance(const HierArgs& a, hipStream_t stream) {
     if (two) return launch_advance2<NE>(a, stream);
   }
 #endif
+  if constexpr (NE == 3) {
+    if (a.pts.points_per_expt == 4 && !(a.prob.kernel_hint & 16u) && hier_isa_enabled()) {
+      bool launched = false;
+      const int rc = launch_isa3(a, stream, &launched);
+      if (rc != PHF_OK || launched) return rc;
+    }
+  }
   return launch_advance1<NE>(a, stream);
 }
 
@@ -1030,7 +1082,9 @@ int launch_init(const HierArgs& a, hipStream_t stream) {
 
 // PHF_EXP_ONLY_NE (timing experiments, tools/build_exp.sh): compile the kernels of ONE Ne only — a minute less per build
 #ifdef PHF_EXP_ONLY_NE
-#define PHF_DISPATCH_NE(ne, FN, ...) return FN<PHF_EXP_ONLY_NE>(__VA_ARGS__);
+#define PHF_DISPATCH_NE(ne, FN, ...)                                                                            \
+  if ((ne) != PHF_EXP_ONLY_NE) return phf_fail(PHF_ERR_UNSUPPORTED, "experiment build: kernels of one Ne only");  \
+  return FN<PHF_EXP_ONLY_NE>(__VA_ARGS__);
 #else
 #define PHF_DISPATCH_NE(ne, FN, ...)                                \
   switch (ne) {                                                     \
@@ -1056,6 +1110,7 @@ int launch_wave_advance(const HierArgs& a, hipStream_t stream, bool* launched) {
   if (int rc = allow_big_lds(&hier_wave_advance_kernel, configured)) return rc;
   hipLaunchKernelGGL(hier_wave_advance_kernel, dim3((unsigned)blocks), dim3(kBlock), w.bytes(), stream, a);
   *launched = true;
+  g_last_kernel = PHF_HIER_KERNEL_WAVE;
   return phf_check_launch("phf_hierarchical_advance (wave per chain)");
 }
 
@@ -1098,6 +1153,8 @@ int phf_hierarchical_state_size(int n_expts) {
   const int d = 5 + 2 * n_expts;
   return 2 * d + d * (d + 1) / 2 + 3;
 }
+
+int phf_hierarchical_last_kernel(void) { return g_last_kernel; }
 
 int phf_hierarchical_set_kernel_policy(int lanes, int wps) {
   if (lanes < 0 || lanes > 2 || wps < 0 || wps > 2) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "kernel policy: lanes and wps must be 0 (automatic), 1 or 2");

@@ -43,7 +43,7 @@ class HierPrior(C.Structure):
 
 
 class HierPoints(C.Structure):
-    _fields_ = [("num_pairs", C.c_int32), ("stride", C.c_int32), ("n_expts", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("num_pairs", C.c_int32), ("stride", C.c_int32), ("n_expts", C.c_int32), ("points_per_expt", C.c_int32),
                 ("ln_conc", C.c_void_p), ("response", C.c_void_p), ("expt_start", C.c_void_p)]
 
 
@@ -76,6 +76,9 @@ class PackedHierPoints(object):
                 self.ln_conc[p, :len(conc)] = np.log(conc)
             self.response[p, :len(y)] = y
             self.expt_start[p] = np.concatenate([[0], np.cumsum([len(x) for x in expts])])
+        # phf_hier_points.points_per_expt (ABI 6): n if EVERY experiment of EVERY pair has n points, else 0
+        sizes = {len(x) for e in experiments_per_pair for x in e}
+        self.points_per_expt = sizes.pop() if len(sizes) == 1 else 0
 
 
 class DeviceHierPoints(object):
@@ -85,7 +88,7 @@ class DeviceHierPoints(object):
         self.ln_conc = torch.from_numpy(packed.ln_conc).to(self.device)
         self.response = torch.from_numpy(packed.response).to(self.device)
         self.expt_start = torch.from_numpy(packed.expt_start).to(self.device)
-        self.struct = HierPoints(packed.num_pairs, packed.stride, packed.n_expts, 0, self.ln_conc.data_ptr(),
+        self.struct = HierPoints(packed.num_pairs, packed.stride, packed.n_expts, packed.points_per_expt, self.ln_conc.data_ptr(),
                                  self.response.data_ptr(), self.expt_start.data_ptr())
 
 
@@ -108,6 +111,12 @@ def set_kernel_policy(lanes=0, wps=0):
     environment set the process's initial values; they are read by the library, once.)"""
     lib = _lib.load(); _bind(lib)
     _lib.check(lib.phf_hierarchical_set_kernel_policy(int(lanes), int(wps)), "phf_hierarchical_set_kernel_policy")
+
+
+def last_kernel():
+    """which kernel this thread's last advance launched (phf_hierarchical_last_kernel): 1 one lane per chain (hipcc), 2 two lanes,
+    3 one wavefront per chain, 4 the hand-allocated gfx950 build of the Ne = 3 iteration"""
+    return int(_lib.load().phf_hierarchical_last_kernel())
 
 
 def simd_count():
@@ -183,12 +192,14 @@ class HierarchicalSampler(object):
         self.state = torch.zeros((self.S, self.Q * self.C), dtype=torch.float64, device=dev)
         self.moments, self.moments_after, self.t, self.row0, self._gamma = None, 0, 0, None, None
 
-    def set_kernel_hint(self, lanes=0, wps=0):
+    def set_kernel_hint(self, lanes=0, wps=0, isa=None):
         """which kernel THIS sampler's launches should get (phf_problems.kernel_hint: lanes per chain 1 | 2, register build of the two-lane
-        kernel 1 | 2; 0 = the library decides from the launch size).  Same numbers either way; a process-wide policy overrides it."""
+        kernel 1 | 2; 0 = the library decides from the launch size; isa=False: not the hand-allocated gfx950 build of the Ne = 3
+        iteration).  Same numbers either way; a process-wide policy overrides lanes / wps."""
         if lanes not in (0, 1, 2) or wps not in (0, 1, 2):
             raise ValueError("kernel hint: lanes and wps must be 0 (automatic), 1 or 2")
-        self.prob.kernel_hint = int(lanes) | (int(wps) << 2)
+        keep = (self.prob.kernel_hint & 16) if isa is None else (0 if isa else 16)      # isa=None: leave that bit as it is
+        self.prob.kernel_hint = int(lanes) | (int(wps) << 2) | keep
 
     def init(self, theta0, cov_scale=0.01):
         """theta0: [dim], [Q][dim] or [Q][C][dim]"""

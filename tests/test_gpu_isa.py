@@ -59,3 +59,69 @@ def test_isa_philox_known_answers(gpu):
                       [5, 0, 77, 2], [0, 7, 0, 1], [9, 9, 9, 0], [64, 209, 24000, 2]]
         ck[:, 4], ck[:, 5] = key
         assert np.array_equal(debug_isa(9, ck, gpu), debug_philox(ck, gpu, rounds=7)), key
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# phf_hier3_advance: the hand-allocated Ne = 3 / 4 + 4 + 4 iteration against the hipcc one-lane kernel and the scalar twin
+def _setup(gpu, names, oracle_pair, C, thin, adapt, seed, isa, chain_offsets=None, launch_order=None):
+    from pyhillfit_amd import hierarchical as H
+    pairs = [oracle_pair(d, c) for d, c in names]
+    packed = H.PackedHierPoints([p.experiments for p in pairs])
+    assert packed.n_expts == 3 and packed.points_per_expt == 4
+    Q = len(names)
+    s = H.HierarchicalSampler(packed, list(range(Q)), C, thinning=thin, seed=seed, adapt_start=adapt, problem_ids=[7 + 3 * q for q in range(Q)],
+                              chain_id_base=9, chain_offsets=chain_offsets, device=gpu)
+    if launch_order is not None:
+        import torch
+        s.launch_order = torch.tensor(np.asarray(launch_order, dtype=np.int32), device=gpu)
+        s.prob.launch_order = s.launch_order.data_ptr()
+    s.set_kernel_hint(lanes=1, isa=isa)
+    return s, pairs
+
+
+THETA0 = [np.concatenate([[1., 5., 6., .3], np.tile([6.0, 0.8], 3), [8.0]]), np.concatenate([[1.2, 4., 5., .4], np.tile([4.5, 1.1], 3), [5.0]]),
+          np.concatenate([[0.9, 3., 5.5, .25], np.tile([5.2, 1.4], 3), [6.5]])]
+UNIFORM4 = [("Amiodarone", "hERG"), ("Amitriptyline", "Cav1.2"), ("Azithromycin", "Nav1.5-late")]
+
+
+@pytest.mark.parametrize("C,thin,cuts", [(256, 5, (137, 9, 454)), (70, 1, (100, 201)), (1024, 5, (600,))])
+def test_isa_advance_bit_identical_to_the_hipcc_kernel(C, thin, cuts, gpu, oracle_pair):
+    """same launches through kernel_hint bit 4 (hipcc one-lane kernel) and without it (phf_hier3_advance): rows, final state and
+    moments must agree bit for bit — launches cut before, at and after the start of the adaptation, a ragged last wavefront
+    (70 chains), thinning 1 and 5, a permuted launch order, per-problem chain offsets"""
+    adapt = 140
+    got = {}
+    for isa in (False, True):
+        s, _ = _setup(gpu, UNIFORM4, oracle_pair, C, thin, adapt, 424242, isa, chain_offsets=[0, 64, 640], launch_order=[2, 0, 1])
+        s.init(np.array(THETA0), cov_scale=0.01)
+        s.enable_moments(after_iteration=adapt + 10)
+        chain = np.concatenate([s.advance(k).cpu().numpy() for k in cuts])
+        from pyhillfit_amd.hierarchical import last_kernel
+        assert last_kernel() == (4 if isa else 1), last_kernel()          # the kernel meant is the kernel that ran
+        got[isa] = (chain, s.state.cpu().numpy(), s.moments.cpu().numpy())
+    for name, a, b in zip(("rows", "state", "moments"), got[False], got[True]):
+        same = a.view(np.uint64) == b.view(np.uint64)
+        assert same.all(), (name, int((~same).sum()), np.argwhere(~same)[:5].tolist())
+    acc = got[True][1][-1].mean() / sum(cuts)
+    assert 0.01 < acc < 0.95, acc
+
+
+def test_isa_advance_bit_identical_to_the_twin(gpu, oracle_pair):
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import gamma_table
+    shapes, scales, locs = H.prior_params()
+    C, T, thin, adapt = 130, 500, 5, 150
+    s, pairs = _setup(gpu, UNIFORM4[:2], oracle_pair, C, thin, adapt, 987654321, True)
+    s.init(np.array(THETA0[:2]), cov_scale=0.01)
+    chain = np.concatenate([s.advance(k).cpu().numpy() for k in (adapt - 3, 4, T - adapt - 1)])
+    assert H.last_kernel() == 4
+    state = s.state.cpu().numpy().reshape(s.S, 2, C)
+    gam = gamma_table(T)
+    for q in range(2):
+        pk = co.PackedHierPair(pairs[q].experiments, shapes, scales, locs)
+        for c in (0, 63, 64, C - 1):
+            st = pk.init_state(THETA0[q], 0.01)
+            rows = pk.advance(st, 0, T, thin, adapt, gam, seed=987654321, chain_id=9 + c, problem_id=7 + 3 * q)
+            assert np.array_equal(chain[:, q, :, c], rows), (q, c)
+            assert np.array_equal(state[:, q, c], st), (q, c)

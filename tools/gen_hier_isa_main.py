@@ -1,0 +1,811 @@
+"""phf_hier3_advance: the hierarchical sampler's iteration for Ne = 3, four points per experiment, one lane per chain, in gfx950
+assembly with every register placed by hand (see tools/gen_hier_isa.py for the why and the overall layout).
+
+Each phase below names the C it restates (pyhillfit_amd/csrc/phf_hierarchical.hip: hier_advance_body, PHF_LDL_COLUMN;
+pyhillfit_amd/csrc/phf_hier_model.h: phf_hier_log_target_n / phf_hier_target_half / phf_hier_draws_k) — same fp64 operations, same
+order per value, so that chains, states and moments are bit-identical to the hipcc kernels and to the twin (oracle/phf_oracle.c).
+"""
+import gfx950_asm as A
+import phf_isa_math as M
+from gfx950_asm import EXEC, VCC, Lit, Neg, Reg
+from gen_hier_isa import ARG_BYTES, ARG_OFF, D, NE, S_LOGA, S_LT, S_MEAN, S_NACC, S_TH, S_TRI, TRI, Gen
+
+# ---- what lives where ---------------------------------------------------------------------------------------------------------
+# LDS, per wavefront: [slot][64 lanes] doubles.  slots 0..10 the running mean, 11..21 the diagonal d, then the elements of L listed here
+# (row i, column k < i); every other element of L stays in VGPRs.
+LDS_L = [(i, 0) for i in range(1, D)] + [(i, 1) for i in range(2, 6)]
+SLOT_MEAN, SLOT_D, SLOT_L = 0, D, 2 * D
+NSLOTS = 2 * D + len(LDS_L)
+WAVE_LDS = NSLOTS * 512
+WAVE_BASE = 8064                                    # behind the workgroup's tables (M.TABLE_BYTES, padded)
+LDS_BYTES = WAVE_BASE + 4 * WAVE_LDS
+
+RESIDENT = ["L2E64", "NLN2HI64", "NLN2LO64", "KE0", "KE1", "K100", "KL0", "KL1", "KL2", "LN2HI", "LN2LO", "LN10", "ISQRT2",
+            "M746", "P710", "P40", "P6", "QUARTER", "LOGADD", "MBITS"]
+
+
+def tri_index(i, k):
+    return i * (i + 1) // 2 + k
+
+
+class Main(object):
+    def __init__(self):
+        self.g = Gen("phf_hier3_advance", NSLOTS)
+        self.k = self.g.k
+        self.m = self.g.m
+        self.c = self.g.c
+        self.info = {}
+
+    # ------------------------------------------------------------------------------------------------------------ small helpers
+    def arg(self, dst, name, extra=0):
+        self.k.s_load(dst, self.g.kernarg, ARG_OFF[name] + extra)
+        return dst
+
+    def add64(self, dst, a, b):
+        """dst (SGPR pair) = a + b, 64 bits; b a pair or a single (zero-extended)"""
+        k = self.k
+        k.sop("s_add_u32", dst.lo(), a.lo(), b.lo() if b.n == 2 else b)
+        k.sop("s_addc_u32", dst.hi(), a.hi(), b.hi() if b.n == 2 else 0)
+
+    def lds_addr(self, slot):
+        return self.v_lds, slot * 512
+
+    def lds_load(self, dst, slot):
+        self.k.ds_read(dst, self.v_lds, slot * 512)
+
+    def lds_store(self, slot, src):
+        self.k.ds_write(self.v_lds, src, slot * 512)
+
+    def l_slot(self, i, kcol):
+        return SLOT_L + LDS_L.index((i, kcol))
+
+    # ------------------------------------------------------------------------------------------------------------ prologue
+    def prologue(self):
+        k, g = self.k, self.g
+        k.comment("---- prologue: arguments, tables -> LDS, constants, which (problem, 64-chain block) this wavefront owns ----")
+        assert ARG_OFF["total_waves"] == ARG_OFF["num_problems"] + 12 and ARG_OFF["chains"] == ARG_OFF["adapt_start"] + 12
+
+        def ptr(name):
+            r = k.sd()
+            k.s_load(r, g.kernarg, ARG_OFF[name])
+            return r
+
+        s_consts = ptr("consts")
+        g.load_constants(s_consts, RESIDENT)
+        # every scalar that lives as long as the loop, allocated in one block (temporaries come and go behind it: no holes)
+        self.s_pid, self.s_g0, self.s_flags, self.s_c8 = k.s1(), k.s1(), k.s1(), k.s1()
+        self.s_t, self.s_tend, self.s_first, self.s_adapt = k.s1(), k.s1(), k.s1(), k.s1()
+        self.s_until, self.s_thin, self.s_mafter = k.s1(), k.s1(), k.s1()
+        self.s_seedlo, self.s_seedhi = k.s1(), k.s1()
+        self.s_nch8, self.s_rows, self.s_rstride, self.s_mom = k.sd(), k.sd(), k.sd(), k.sd()
+        self.s_lc, self.s_yp, self.s_gamma, self.s_acc = k.sd(), k.sd(), k.sd(), k.sd()
+        g.stage_tables(s_consts)
+        k.free(s_consts)
+        w4 = k.sx(4)
+        k.s_load(w4, g.kernarg, ARG_OFF["num_problems"])          # num_problems bpp bpp_magic total_waves
+        a_np, a_bpp, a_magic, a_total = (w4.sub(i, 1) for i in range(4))
+        c4 = k.sx(4)
+        k.s_load(c4, g.kernarg, ARG_OFF["adapt_start"])           # adapt_start thinning moments_after chains
+        a_adapt, a_thin, a_mafter, a_C = (c4.sub(i, 1) for i in range(4))
+        # wave number inside the workgroup, global wave number
+        vt = k.v1()
+        k.vop("v_lshrrev_b32_e32", vt, 6, g.tid)
+        s_wave = k.s1()
+        k.readfirstlane(s_wave, vt)
+        gw = k.s1()
+        k.sop("s_lshl_b32", gw, g.wg_id, 2)
+        k.sop("s_add_u32", gw, gw, s_wave)
+        self.l_end = k.new_label("end")
+        k.sop("s_cmp_ge_u32", None, gw, a_total)
+        k.branch("s_cbranch_scc1", self.l_end)
+        # slot = gw / bpp (host-checked magic), chunk = gw - slot * bpp
+        slot, chunk, tmp = k.s1(), k.s1(), k.s1()
+        k.sop("s_mul_hi_u32", slot, gw, a_magic)
+        k.sop("s_cmp_eq_u32", None, a_magic, 0)                   # bpp == 1: the magic does not fit 32 bits; slot = gw
+        k.sop("s_cselect_b32", slot, gw, slot)
+        k.sop("s_mul_i32", tmp, slot, a_bpp)
+        k.sop("s_sub_u32", chunk, gw, tmp)
+        # q = launch_order ? launch_order[slot] : slot
+        q = k.s1()
+        a_order = ptr("launch_order")
+        k.sop("s_mov_b32", q, slot)
+        l_noorder = k.new_label("noorder")
+        k.sop("s_cmp_eq_u64", None, a_order, 0)
+        k.branch("s_cbranch_scc1", l_noorder)
+        k.sop("s_lshl_b32", tmp, slot, 2)
+        k.s_load(q, a_order, tmp)
+        k.label(l_noorder)
+        k.free(a_order, slot, gw)
+        # pair, problem id, chain offset
+        s_pair = k.s1()
+        s_coff = k.s1()
+        a_pi, a_pid, a_coff = ptr("pair_index"), ptr("problem_id"), ptr("chain_offset")
+        k.sop("s_lshl_b32", tmp, q, 2)
+        k.s_load(s_pair, a_pi, tmp)
+        k.s_load(self.s_pid, a_pid, tmp)
+        k.sop("s_mov_b32", s_coff, 0)
+        l_nocoff = k.new_label("nocoff")
+        k.sop("s_cmp_eq_u64", None, a_coff, 0)
+        k.branch("s_cbranch_scc1", l_nocoff)
+        k.s_load(s_coff, a_coff, tmp)
+        k.label(l_nocoff)
+        k.free(a_pi, a_pid, a_coff)
+        more = k.sx(4)
+        k.s_load(more, g.kernarg, ARG_OFF["seed_lo"])             # seed_lo seed_hi chain_id_base pts_stride
+        # lanes: c = chunk * 64 + lane < C
+        self.v_lane8 = k.v1()
+        self.v_lds = k.v1()
+        self.v_cid = k.v1()
+        lane = k.v1()
+        c0 = k.s1()
+        k.sop("s_lshl_b32", c0, chunk, 6)
+        k.vop("v_and_b32_e32", lane, 63, g.tid)
+        k.sop("s_sub_u32", tmp, a_C, c0)
+        k.cmp_u32("gt", VCC, tmp, lane)
+        k.sop("s_and_b64", EXEC, EXEC, VCC)
+        k.vop("v_lshlrev_b32_e32", self.v_lane8, 3, lane)
+        k.sop("s_add_u32", tmp, more.sub(2, 1), s_coff)           # chain_id_base + chain_offset[q] + chunk * 64 + lane
+        k.sop("s_add_u32", tmp, tmp, c0)
+        k.vop("v_add_u32_e32", self.v_cid, tmp, lane)
+        k.sop("s_mul_i32", tmp, s_wave, Lit(WAVE_LDS))
+        k.sop("s_add_u32", tmp, tmp, Lit(WAVE_BASE))
+        k.vop("v_add_u32_e32", self.v_lds, tmp, self.v_lane8)
+        k.free(lane, vt, s_wave, s_coff, chunk)
+        # g0 = q * C + chunk * 64: first chain of this wavefront in the [.][Q * C] arrays
+        k.sop("s_mul_i32", self.s_g0, q, a_C)
+        k.sop("s_add_u32", self.s_g0, self.s_g0, c0)
+        # nch8 = Q * C * 8 (64 bits)
+        k.sop("s_mul_i32", self.s_nch8.lo(), a_np, a_C)
+        k.sop("s_mul_hi_u32", self.s_nch8.hi(), a_np, a_C)
+        k.sop("s_lshl_b64", self.s_nch8, self.s_nch8, 3)
+        # rows: cursor = rows + ((q * 12) * C + chunk * 64) * 8; stride per saved row = 12 * nch8; flags: bit 0 rows, bit 1 moments
+        t2 = k.sd()
+        a_rows, a_mom = ptr("rows"), ptr("moments")
+        k.sop("s_cmp_lg_u64", None, a_rows, 0)
+        k.sop("s_cselect_b32", self.s_flags, 1, 0)
+        k.sop("s_cmp_lg_u64", None, a_mom, 0)
+        k.sop("s_cselect_b32", tmp, 2, 0)
+        k.sop("s_or_b32", self.s_flags, self.s_flags, tmp)
+        k.sop("s_mul_i32", tmp, q, a_C)                           # q C  (< 2^31)
+        k.sop("s_mul_hi_u32", t2.hi(), tmp, D + 1)
+        k.sop("s_mul_i32", t2.lo(), tmp, D + 1)
+        self.add64(t2, t2, c0)
+        k.sop("s_lshl_b64", t2, t2, 3)
+        self.add64(self.s_rows, a_rows, t2)
+        k.sop("s_mul_hi_u32", tmp, self.s_nch8.lo(), D + 1)
+        k.sop("s_mul_i32", self.s_rstride.lo(), self.s_nch8.lo(), D + 1)
+        k.sop("s_mul_i32", self.s_rstride.hi(), self.s_nch8.hi(), D + 1)
+        k.sop("s_add_u32", self.s_rstride.hi(), self.s_rstride.hi(), tmp)
+        k.sop("s_lshl_b32", self.s_c8, a_C, 3)
+        # moments base = moments + g0 * 8; gamma; points of the pair
+        k.sop("s_mov_b32", t2.lo(), self.s_g0)
+        k.sop("s_mov_b32", t2.hi(), 0)
+        k.sop("s_lshl_b64", t2, t2, 3)
+        self.add64(self.s_mom, a_mom, t2)
+        k.free(a_rows, a_mom)
+        a_state = ptr("state")
+        s_state = k.sd()
+        self.add64(s_state, a_state, t2)
+        k.free(a_state)
+        k.s_load(self.s_gamma, g.kernarg, ARG_OFF["gamma"])
+        a_lc, a_y = ptr("ln_conc"), ptr("response")
+        k.sop("s_mul_i32", t2.lo(), s_pair, more.sub(3, 1))
+        k.sop("s_mul_hi_u32", t2.hi(), s_pair, more.sub(3, 1))
+        k.sop("s_lshl_b64", t2, t2, 3)
+        self.add64(self.s_lc, a_lc, t2)
+        self.add64(self.s_yp, a_y, t2)
+        k.free(a_lc, a_y, s_pair, t2, q, c0)
+        # loop scalars
+        tb = k.sd()
+        k.s_load(tb, g.kernarg, ARG_OFF["t_begin"])               # t_begin t_end
+        until0 = k.s1()
+        k.s_load(until0, g.kernarg, ARG_OFF["until_save0"])
+        k.sop("s_add_u32", self.s_first, tb.lo(), 1)
+        k.sop("s_mov_b32", self.s_t, self.s_first)
+        k.sop("s_mov_b32", self.s_tend, tb.hi())
+        k.sop("s_mov_b32", self.s_adapt, a_adapt)
+        k.sop("s_mov_b32", self.s_thin, a_thin)
+        k.sop("s_mov_b32", self.s_mafter, a_mafter)
+        k.sop("s_mov_b32", self.s_until, until0)
+        k.sop("s_mov_b32", self.s_seedlo, more.sub(0, 1))
+        k.sop("s_mov_b32", self.s_seedhi, more.sub(1, 1))
+        k.sop("s_mov_b64", self.s_acc, 0)
+        k.s_waitcnt_all()
+        k.free(w4, c4, more, until0, tmp, tb)
+        # ---- the chain state: HBM -> registers / LDS ----
+        k.comment("---- state: HBM -> registers and this wavefront's LDS slots ----")
+        self.th = [k.vd() for _ in range(D)]
+        self.lt = k.vd()
+        self.y = [k.vd() for _ in range(D)]
+        self.Lreg = {}
+        for i in range(1, D):
+            for kc in range(i):
+                if (i, kc) not in LDS_L:
+                    self.Lreg[(i, kc)] = k.vd()
+        self.loga, self.nacc, self.sc, self.logu = k.vd(), k.vd(), k.vd(), k.vd()
+        self.walk_state(s_state, load=True)
+        k.free(s_state)
+
+    def state_rows(self):
+        """(state row, kind, key) in ascending row order"""
+        rows = [(S_TH + i, "th", i) for i in range(D)] + [(S_LT, "lt", None)] + [(S_MEAN + i, "mean", i) for i in range(D)]
+        for i in range(D):
+            for kc in range(i + 1):
+                rows.append((S_TRI + tri_index(i, kc), "d" if kc == i else "L", i if kc == i else (i, kc)))
+        rows += [(S_LOGA, "loga", None), (S_NACC, "nacc", None)]
+        assert [r for r, _, _ in rows] == list(range(2 * D + TRI + 3))
+        return rows
+
+    def walk_state(self, cur, load):
+        """one pass over the rows of the state with a 64-bit cursor (row r of this wavefront: cur + r * nch8)"""
+        k = self.k
+        temps = []
+        for r, kind, key in self.state_rows():
+            reg, slot = None, None
+            if kind == "th":
+                reg = self.th[key]
+            elif kind == "lt":
+                reg = self.lt
+            elif kind == "loga":
+                reg = self.loga
+            elif kind == "nacc":
+                reg = self.nacc
+            elif kind == "mean":
+                slot = SLOT_MEAN + key
+            elif kind == "d":
+                slot = SLOT_D + key
+            elif key in self.Lreg:
+                reg = self.Lreg[key]
+            else:
+                slot = self.l_slot(*key)
+            if load:
+                if reg is not None:
+                    k.gload(reg, self.v_lane8, cur)
+                else:
+                    t = k.vd()
+                    k.gload(t, self.v_lane8, cur)
+                    temps.append((t, slot))
+            else:
+                if reg is not None:
+                    k.gstore(self.v_lane8, reg, cur)
+                else:
+                    t = k.vd()
+                    self.lds_load(t, slot)
+                    k.gstore(self.v_lane8, t, cur)
+                    k.free(t)
+            self.add64(cur, cur, self.s_nch8)
+            if load and len(temps) == 12:
+                for t, s in temps:
+                    self.lds_store(s, t)
+                    k.free(t)
+                temps = []
+        for t, s in temps:
+            self.lds_store(s, t)
+            k.free(t)
+
+    # ------------------------------------------------------------------------------------------------------------ draws
+    def draws(self):
+        """phf_hier_draws_k(D, cid, pid, t, seed): three Philox4x32-7 blocks (counter (cid, pid, t, b), key = seed) -> normals z[0..10]
+        (word j of block b is normal 4 b + j) and log u (the last word of the last block).  The parts of the first rounds that do
+        not depend on the lane run on the scalar unit; the three blocks advance round by round side by side."""
+        k, c = self.k, self.c
+        k.comment("---- draws of iteration t: 3 Philox4x32-7 blocks -> 11 normals and log u ----")
+        NB, R = 3, 7
+        s = [k.s1() for _ in range(8)]
+        p1lo, p1hi, n0u, p0ulo, p0uhi, ka, kb, tx = s
+
+        def key(r):
+            """ka, kb <- round r's key words (seed + r * Weyl constants, mod 2^32)"""
+            k.sop("s_add_u32", ka, self.s_seedlo, Lit((r * M.PHILOX_W0) & 0xffffffff))
+            k.sop("s_add_u32", kb, self.s_seedhi, Lit((r * M.PHILOX_W1) & 0xffffffff))
+
+        # round 0, uniform half: p1 = M1 * t; n0 = hi(p1) ^ pid ^ k0; c1' = lo(p1)
+        key(0)
+        k.sop("s_mul_i32", p1lo, self.s_t, c["PM1"])
+        k.sop("s_mul_hi_u32", p1hi, self.s_t, c["PM1"])
+        k.sop("s_xor_b32", n0u, p1hi, self.s_pid)
+        k.sop("s_xor_b32", n0u, n0u, ka)
+        # round 0, lane half: p0 = M0 * cid (the same for the three blocks); n2_b = hi(p0) ^ b ^ k1; c3' = lo(p0)
+        P0 = k.vd()
+        k.mad_u64_u32(P0, self.v_cid, c["PM0"])
+        sets = [[(k.vd(), k.vd()), (k.vd(), k.vd())] for _ in range(NB)]        # per block: two (p0, p1) register pairs, used in turn
+        n2 = [sets[b][0][0].hi() for b in range(NB)]
+        for b in range(NB):
+            k.xor3(n2[b], P0.hi(), b, kb)
+        # round 1: p0' = M0 * n0 (uniform); p1'_b = M1 * n2_b; n0'_b = hi(p1'_b) ^ c1' ^ k0; n2' = hi(p0') ^ c3' ^ k1 (the same for all b)
+        key(1)
+        k.sop("s_mul_i32", p0ulo, n0u, c["PM0"])
+        k.sop("s_mul_hi_u32", p0uhi, n0u, c["PM0"])
+        k.sop("s_xor_b32", tx, p1lo, ka)
+        for b in range(NB):
+            k.mad_u64_u32(sets[b][1][1], n2[b], c["PM1"])
+        for b in range(NB):
+            k.vop("v_xor_b32_e32", sets[b][1][1].hi(), tx, sets[b][1][1].hi())       # n0'_b
+        k.sop("s_xor_b32", tx, p0uhi, kb)
+        n2s = P0.hi()
+        k.vop("v_xor_b32_e32", n2s, tx, P0.lo())                                       # n2' (shared); c3'' = lo(p0') uniform
+        # round 2: p0''_b = M0 * n0'_b; p1'' = M1 * n2' (shared); n0''_b = hi(p1'') ^ c1''_b ^ k0; n2''_b = hi(p0''_b) ^ c3'' ^ k1
+        key(2)
+        P1s = k.vd()
+        k.mad_u64_u32(P1s, n2s, c["PM1"])
+        for b in range(NB):
+            k.mad_u64_u32(sets[b][0][0], sets[b][1][1].hi(), c["PM0"])
+        k.sop("s_xor_b32", tx, p0ulo, kb)
+        for b in range(NB):
+            k.xor3(sets[b][0][1].hi(), P1s.hi(), sets[b][1][1].lo(), ka)               # n0''_b  (c1''_b = lo(p1'_b))
+        for b in range(NB):
+            k.vop("v_xor_b32_e32", sets[b][0][0].hi(), tx, sets[b][0][0].hi())       # n2''_b
+        # from here on every word is per lane: block b's state = (n0, c1, n2, c3)
+        st = [[sets[b][0][1].hi(), P1s.lo(), sets[b][0][0].hi(), sets[b][0][0].lo()] for b in range(NB)]
+        for r in range(3, R):
+            key(r)
+            cur = r % 2
+            for b in range(NB):
+                k.mad_u64_u32(sets[b][cur][0], st[b][0], c["PM0"])
+                k.mad_u64_u32(sets[b][cur][1], st[b][2], c["PM1"])
+            for b in range(NB):
+                p0, p1 = sets[b][cur]
+                k.xor3(p1.hi(), p1.hi(), st[b][1], ka)
+                k.xor3(p0.hi(), p0.hi(), st[b][3], kb)
+                st[b] = [p1.hi(), p1.lo(), p0.hi(), p0.lo()]
+        k.free(s)
+        # normals: word j of block b -> z[4 b + j]; the accept uniform: word 3 of block 2
+        self.zn = [k.vd() for _ in range(D)]
+        for b in range(NB):
+            idx = [4 * b + j for j in range(4) if 4 * b + j < D]
+            for grp in (idx[:2], idx[2:]):                                         # two at a time: 15 registers each while it runs
+                M.normal_u32(self.m, [self.zn[i] for i in grp], [st[b][i - 4 * b] for i in grp])
+        M.unit_open32(self.m, self.logu, st[NB - 1][3])
+        M.log_pos(self.m, [self.logu], [self.logu])
+        k.free(P0, P1s, [list(p) for blk in sets for p in blk])
+
+    # ------------------------------------------------------------------------------------------------------------ sweep
+    def sweep(self):
+        """the adaptation of iteration t - 1 (hier_advance_body: mean, loga, PHF_LDL_COLUMN column by column) fused with
+        y = L sqrt(d) z of iteration t's proposal; s_gs = gamma (0.0 where the C code does not adapt: an exact no-op)"""
+        k, c, m = self.k, self.c, self.m
+        k.comment("---- adaptation of t - 1 (rank-one update of L D L') + y = L sqrt(d) z for t ----")
+        # gamma: (t - 1 > adapt_start and t > first) ? gamma[t - 1 - adapt_start] : 0
+        self.s_gs = k.sd()
+        tmp = k.s1()
+        l_g0, l_gdone = k.new_label("g0"), k.new_label("gdone")
+        k.sop("s_mov_b64", self.s_gs, 0)
+        k.sop("s_cmp_eq_u32", None, self.s_t, self.s_first)
+        k.branch("s_cbranch_scc1", l_gdone)
+        k.sop("s_sub_u32", tmp, self.s_t, 1)
+        k.sop("s_cmp_le_u32", None, tmp, self.s_adapt)
+        k.branch("s_cbranch_scc1", l_gdone)
+        k.sop("s_sub_u32", tmp, tmp, self.s_adapt)
+        k.sop("s_lshl_b32", tmp, tmp, 3)
+        k.s_load(self.s_gs, self.s_gamma, tmp)
+        k.label(l_gdone)
+        k.free(tmp)
+        gs = self.s_gs
+        omg, alpha = k.vd(), k.vd()
+        k.add(omg, 1.0, Neg(gs))
+        # w = theta - mean; mean <- g theta + (1 - g) mean
+        w = [k.vd() for _ in range(D)]
+        mt = [k.vd() for _ in range(D)]
+        for i in range(D):
+            self.lds_load(mt[i], SLOT_MEAN + i)
+        dq = {}
+        for kc in range(2):                                  # the first diagonals: in flight while the mean is updated
+            dq[kc] = k.vd()
+            self.lds_load(dq[kc], SLOT_D + kc)
+        for i in range(D):
+            k.sub(w[i], self.th[i], mt[i])
+            k.mul(mt[i], omg, mt[i])
+            k.fma(mt[i], gs, self.th[i], mt[i])
+            self.lds_store(SLOT_MEAN + i, mt[i])
+        k.free(mt)
+        # loga <- loga + g ((accepted ? 1 : 0) - 1/4)
+        a01 = k.vd()
+        k.mov32(a01.lo(), 0)
+        k.cnd32(a01.hi(), 0, c["ONEHI"], self.s_acc)
+        k.sub(a01, a01, c["QUARTER"])
+        k.fma(self.loga, gs, a01, self.loga)
+        k.free(a01)
+        k.mov32(alpha.lo(), gs.lo())
+        k.mov32(alpha.hi(), gs.hi())
+        y = self.y
+        lq = {}
+
+        def fetch_column(kc):
+            for i in range(kc + 1, D):
+                if (i, kc) in LDS_L:
+                    lq[(i, kc)] = k.vd()
+                    self.lds_load(lq[(i, kc)], self.l_slot(i, kc))
+
+        fetch_column(0)
+        pos = k.sd()
+        for kc in range(D):
+            if kc + 2 < D:
+                dq[kc + 2] = k.vd()
+                self.lds_load(dq[kc + 2], SLOT_D + kc + 2)
+            if kc + 1 < D:
+                fetch_column(kc + 1)
+            dk, ap, dn, inv, beta, sq = k.vd(), k.vd(), k.vd(), k.vd(), k.vd(), k.vd()
+            k.mul(dk, omg, dq[kc])
+            k.mul(ap, alpha, w[kc])
+            k.fma(dn, ap, w[kc], dk)
+            self.lds_store(SLOT_D + kc, dn)
+            k.free(dq.pop(kc))
+            # 1 / dn (or 0) and sqrt(dn) (or 0): two dependency chains side by side
+            with k.parallel() as par:
+                par.stream()
+                M.rcp(m, [inv], [dn])
+                par.stream()
+                M.sqrt_nonneg(m, [sq], [dn], [pos])
+            k.cnd64(inv, 0.0, inv, pos)
+            k.mul(beta, ap, inv)
+            k.mul(dk, alpha, dk)
+            k.mul(dk, dk, inv)
+            k.cnd64(alpha, alpha, dk, pos)
+            k.mul(self.zn[kc], sq, self.zn[kc])
+            for i in range(kc + 1, D):
+                lik = lq[(i, kc)] if (i, kc) in LDS_L else self.Lreg[(i, kc)]
+                k.fma(w[i], Neg(w[kc]), lik, w[i])
+                k.fma(lik, beta, w[i], lik)
+                if (i, kc) in LDS_L:
+                    self.lds_store(self.l_slot(i, kc), lik)
+                k.fma(y[i], lik, self.zn[kc], 0.0 if kc == 0 else y[i])
+                if (i, kc) in LDS_L:
+                    k.free(lq.pop((i, kc)))
+            k.add(y[kc], 0.0 if kc == 0 else y[kc], self.zn[kc])
+            k.free(dk, ap, dn, inv, beta, sq)
+        k.free(pos, omg, alpha, w, self.zn, self.s_gs)
+        # the scale of the next proposal: e^(loga / 2)
+        h = k.vd()
+        k.mul(h, self.loga, 0.5)
+        M.exp_fast(m, [self.sc], [h])
+        k.free(h)
+
+    # ------------------------------------------------------------------------------------------------------------ save
+    def save(self):
+        """thinning + sample store + moments of iteration t - 1 (hier_advance_body, :502-503 of the reference)"""
+        k = self.k
+        k.comment("---- save iteration t - 1: thinned sample, moments ----")
+        l_skip = k.new_label("nosave")
+        k.sop("s_cmp_eq_u32", None, self.s_t, self.s_first)
+        k.branch("s_cbranch_scc1", l_skip)
+        k.sop("s_sub_u32", self.s_until, self.s_until, 1)
+        k.sop("s_cmp_lg_u32", None, self.s_until, 0)
+        k.branch("s_cbranch_scc1", l_skip)
+        k.sop("s_mov_b32", self.s_until, self.s_thin)
+        l_norows = k.new_label("norows")
+        k.sop("s_bitcmp0_b32", None, self.s_flags, 0)
+        k.branch("s_cbranch_scc1", l_norows)
+        cur = k.sd()
+        k.sop("s_mov_b64", cur, self.s_rows)
+        for i in range(D + 1):
+            k.gstore(self.v_lane8, self.th[i] if i < D else self.lt, cur)
+            if i < D:
+                self.add64(cur, cur, self.s_c8)
+        self.add64(self.s_rows, self.s_rows, self.s_rstride)
+        k.label(l_norows)
+        k.sop("s_bitcmp0_b32", None, self.s_flags, 1)
+        k.branch("s_cbranch_scc1", l_skip)
+        tmp = k.s1()
+        k.sop("s_sub_u32", tmp, self.s_t, 1)
+        k.sop("s_cmp_le_u32", None, tmp, self.s_mafter)
+        k.branch("s_cbranch_scc1", l_skip)
+        k.free(tmp)
+        k.sop("s_mov_b64", cur, self.s_mom)
+        sq = [k.vd() for _ in range(4)]
+        for r in range(2 * (D + 1)):
+            i = r % (D + 1)
+            src = self.th[i] if i < D else self.lt
+            if r >= D + 1:
+                t = sq[r % 4]
+                k.mul(t, src, src)
+                src = t
+            k.gatomic_add_f64(self.v_lane8, src, cur)
+            self.add64(cur, cur, self.s_nch8)
+        k.free(sq, cur)
+        k.label(l_skip)
+
+    # ------------------------------------------------------------------------------------------------------------ target
+    def target(self, lt_star):
+        """phf_hier_log_target_n(3, PHF_HIER_SHAPE(4, 0), ...) of the proposal in self.y (= star): both halves, experiment by experiment"""
+        k, c, m = self.k, self.c, self.m
+        st = self.y
+        alpha, beta, mu, s_, sigma = st[0], st[1], st[2], st[3], st[D - 1]
+        pic = [st[4 + 2 * i] for i in range(NE)]
+        hill = [st[5 + 2 * i] for i in range(NE)]
+        k.comment("---- target of the proposal: support, the 12 + 4 logarithms, the 12 points ----")
+        # support (phf_hier_out_of_support) and xl = hv - loc
+        s_bad = k.sd()
+        pa, pb = k.sx(8), k.sd()
+
+        def prior(name):
+            k.s_load(pa, self.g.kernarg, ARG_OFF[name])
+            k.s_load(pb, self.g.kernarg, ARG_OFF[name] + 32)
+            return [pa.sub(2 * j) for j in range(4)] + [pb]
+
+        loc = prior("prior_loc")
+        hv = [alpha, beta, mu, s_, sigma]
+        for j in range(5):
+            k.cmp("le", VCC, hv[j], loc[j])
+            k.sop("s_mov_b64" if j == 0 else "s_or_b64", s_bad, *( [VCC] if j == 0 else [s_bad, VCC]))
+        for i in range(NE):
+            k.cmp("lt", VCC, hill[i], 0.0)
+            k.sop("s_or_b64", s_bad, s_bad, VCC)
+            k.cmp("lt", VCC, pic[i], -2.0)
+            k.sop("s_or_b64", s_bad, s_bad, VCC)
+        xl = [k.vd() for _ in range(5)]
+        for j in range(5):
+            k.sub(xl[j], hv[j], loc[j])
+        # 1 / sigma and 1 / s behind one reciprocal (phf_batch_recip of {sigma, s})
+        inv_s, inv_sc, pre, inv = k.vd(), k.vd(), k.vd(), k.vd()
+        k.mul(pre, sigma, s_)
+        M.rcp(m, [inv], [pre])
+        k.mul(inv_sc, inv, sigma)
+        k.mul(inv_s, inv, s_)
+        k.free(pre, inv)
+        # lin0 = sum_k -xl_k / scale_k  (half 0);  z_i, lin1 (half 1)
+        isc = prior("prior_inv_scale")
+        lin0, lin1 = k.vd(), k.vd()
+        for j in range(5):
+            k.fma(lin0, Neg(xl[j]), isc[j], 0.0 if j == 0 else lin0)
+        z = [k.vd() for _ in range(NE)]
+        for i in range(NE):
+            k.sub(z[i], pic[i], mu)
+            k.mul(z[i], z[i], inv_sc)
+        for i in range(NE):
+            k.sub(lin1, 0.0 if i == 0 else lin1, z[i])
+        k.free(inv_sc)
+        # weights that are computed: -Ne beta, beta - 1
+        sm1 = prior("prior_shape_m1")
+        three, twelve = k.sd(), k.sd()                       # (double)Ne and (double)n_pts: literals (their low words are zero)
+        for r, hi in ((three, 0x40080000), (twelve, 0x40280000)):
+            k.sop("s_mov_b32", r.lo(), 0)
+            k.sop("s_mov_b32", r.hi(), Lit(hi))
+        wnb, wb1 = k.vd(), k.vd()
+        k.mul(wnb, Neg(three), beta)
+        k.add(wb1, beta, -1.0)
+        # half 0: ln alpha, ln Hill_1..3, ln beta, ln(alpha - loc0)
+        part0, part1 = k.vd(), k.vd()
+        lg0 = [k.vd() for _ in range(4)]
+        M.log_fast(m, lg0, [alpha] + hill)
+        k.fma(part0, wnb, lg0[0], 0.0)
+        for i in range(NE):
+            k.fma(part0, wb1, lg0[1 + i], part0)
+        k.free(wnb, wb1)
+        t2 = [k.vd(), k.vd()]
+        M.log_fast(m, t2, [beta, xl[0]])
+        k.fma(part0, three, t2[0], part0)
+        k.fma(part0, sm1[0], t2[1], part0)
+        # half 1: ln(beta - loc1), ln(mu - loc2), ln(s - loc3), ln(sigma - loc4), ln s, ln sigma
+        t4 = [k.vd() for _ in range(2)]
+        M.log_fast(m, t2 + t4, [xl[1], xl[2], xl[3], xl[4]])
+        for j, r in enumerate(t2 + t4):
+            k.fma(part1, sm1[1 + j], r, 0.0 if j == 0 else part1)
+        M.log_fast(m, t2, [s_, sigma])
+        k.fma(part1, Neg(three), t2[0], part1)
+        k.fma(part1, Neg(twelve), t2[1], part1)
+        k.free(t4, xl, pa, pb, three, twelve)
+        # la0_i = 1 + (Hill_i / alpha)^beta = 1 + exp(beta (ln Hill_i - ln alpha));  la1_i = 1 + exp(-z_i)
+        la0, la1 = [k.vd() for _ in range(NE)], [k.vd() for _ in range(NE)]
+        ea = [k.vd() for _ in range(NE)]
+        for i in range(NE):
+            k.sub(ea[i], lg0[1 + i], lg0[0])
+            k.mul(ea[i], beta, ea[i])
+        k.free(lg0)
+        for i in range(NE):
+            k.fmax(z[i], Neg(z[i]), c["M746"])                   # phf_exp_fast_k(-z): the clamp's first half takes the negation
+            k.fmin(z[i], z[i], c["P710"])
+        M.exp_fast(m, la0, ea)
+        M.exp_core(m, la1, z)
+        k.free(ea, z)
+        for i in range(NE):
+            k.add(la0[i], la0[i], 1.0)
+            k.add(la1[i], la1[i], 1.0)
+        k.add(part0, part0, lin0)
+        k.add(part1, part1, lin1)
+        k.free(lin0, lin1)
+        # -2 ln prod_i la_i, term by term where the product is not below 2^1000 (rare: a uniform branch)
+        prod = t2
+        k.mul(prod[0], la0[0], la0[1])
+        k.mul(prod[0], prod[0], la0[2])
+        k.mul(prod[1], la1[0], la1[1])
+        k.mul(prod[1], prod[1], la1[2])
+        vlog = [k.vd(), k.vd()]
+        big = [k.sd(), k.sd()]
+        for h in range(2):
+            k.cmp_lit("ngt", 0x7e700000, prod[h])                # !(prod < 2^1000)  ==  !(2^1000 > prod)
+            k.sop("s_mov_b64", big[h], VCC)
+        M.log_pos(m, vlog, prod)
+        anyb = k.sd()
+        l_nobig = k.new_label("nobig")
+        k.sop("s_or_b64", anyb, big[0], big[1])
+        k.sop("s_cmp_eq_u64", None, anyb, 0)
+        k.branch("s_cbranch_scc1", l_nobig)
+        for h, la in ((0, la0), (1, la1)):
+            vs, vi = k.vd(), k.vd()
+            for i in range(NE):
+                M.log_pos(m, [vi], [la[i]])
+                k.cmp_lit("lt", 0x7e700000, la[i])                 # la > 2^1000
+                k.cnd32_vcc(vi.lo(), vi.lo(), self.v_zero)
+                k.cnd32_vcc(vi.hi(), vi.hi(), self.v_infhi)
+                k.add(vs, 0.0 if i == 0 else vs, vi)
+            k.cnd64(vlog[h], vlog[h], vs, big[h])
+            k.free(vs, vi)
+        k.label(l_nobig)
+        k.free(anyb, big, la0, la1)
+        k.fma(part0, -2.0, vlog[0], part0)
+        k.fma(part1, -2.0, vlog[1], part1)
+        k.free(vlog, prod)
+        # the points: experiment i's four points, two for each half (:117-125)
+        sse, mass = [k.vd(), k.vd()], [k.vd(), k.vd()]
+        pts = k.sx(8)
+        for i in range(NE):
+            k.s_load(pts, self.s_lc, 32 * i)                      # ln conc of points 4 i .. 4 i + 3
+            lcs = [pts.sub(2 * j) for j in range(4)]
+            ys = lcs                                              # ... then, in the same registers, their responses
+            lnic = k.vd()
+            k.sub(lnic, c["P6"], pic[i])
+            k.mul(lnic, c["LN10"], lnic)
+            x = [k.vd() for _ in range(4)]
+            d = [k.vd() for _ in range(4)]
+            for j in range(4):
+                k.sub(x[j], lcs[j], lnic)
+                k.mul(x[j], hill[i], x[j])
+                k.fmin(x[j], x[j], c["P40"])
+            k.free(lnic)
+            k.s_load(pts, self.s_yp, 32 * i)
+            M.exp_capped(m, d, x)
+            for j in range(4):
+                k.add(d[j], d[j], 1.0)
+            inv = [x[0], x[1]]
+            pred = [x[2], x[3], k.vd(), k.vd()]
+            k.mul(pred[0], d[0], d[1])
+            k.mul(pred[1], d[2], d[3])
+            M.rcp(m, inv, [pred[0], pred[1]])
+            # pred0 = fma(-100, inv * d1, 100), pred1 = fma(-100, inv * d0, 100)
+            tt = [k.vd() for _ in range(4)]
+            for h in range(2):
+                k.mul(tt[2 * h], inv[h], d[2 * h + 1])
+                k.mul(tt[2 * h + 1], inv[h], d[2 * h])
+            k.free(d)
+            for j in range(4):
+                k.fma(pred[j], Neg(c["K100"]), tt[j], c["K100"])
+            for j in range(4):
+                k.sub(tt[j], ys[j], pred[j])
+            for h in range(2):
+                k.fma(sse[h], tt[2 * h], tt[2 * h], 0.0 if i == 0 else sse[h])
+                k.fma(sse[h], tt[2 * h + 1], tt[2 * h + 1], sse[h])
+            k.free(tt, inv)
+            # truncation masses (phf_trunc_mass_x2, upper tails skipped unless some lane needs one), a pair of points at a time
+            for h in range(2):
+                p0, p1 = pred[2 * h], pred[2 * h + 1]
+                ya = [k.vd(), k.vd()]
+                yb = [k.vd(), k.vd()]
+                for j, p in enumerate((p0, p1)):
+                    k.mul(ya[j], p, inv_s)
+                    k.mul(ya[j], ya[j], c["ISQRT2"])
+                    k.sub(yb[j], c["K100"], p)
+                    k.mul(yb[j], yb[j], inv_s)
+                    k.mul(yb[j], yb[j], c["ISQRT2"])
+                tl = [p0, p1]                                        # the predictions are spent: their registers take the tails
+                M.erfc_tab(m, tl, ya)
+                k.free(ya)
+                need = k.sd()
+                l_skip = k.new_label("noupper")
+                k.cmp("lt", need, yb[0], c["P6"])
+                k.cmp("lt", VCC, yb[1], c["P6"])
+                k.sop("s_or_b64", need, need, VCC)
+                k.sop("s_cmp_eq_u64", None, need, 0)
+                k.branch("s_cbranch_scc1", l_skip)
+                tu = [k.vd(), k.vd()]
+                M.erfc_tab(m, tu, yb)
+                k.add(tl[0], tl[0], tu[0])
+                k.add(tl[1], tl[1], tu[1])
+                k.free(tu)
+                k.label(l_skip)
+                k.free(need, yb)
+                k.fma(tl[0], -0.5, tl[0], 1.0)
+                k.fma(tl[1], -0.5, tl[1], 1.0)
+                k.mul(tl[0], tl[0], tl[1])
+                if i == 0:
+                    k.mul(mass[h], 1.0, tl[0])
+                else:
+                    k.mul(mass[h], mass[h], tl[0])
+            k.free(pred)
+        k.free(pts)
+        # halves: part_h - fma(sse_h, (0.5 inv_s) inv_s, ln mass_h), -inf if the mass underflowed; sum; -inf outside the support
+        hs = k.vd()
+        k.mul(hs, inv_s, 0.5)
+        k.mul(hs, hs, inv_s)
+        tr = [k.vd(), k.vd()]
+        M.log_pos(m, tr, mass)
+        for h, part in ((0, part0), (1, part1)):
+            k.fma(tr[h], sse[h], hs, tr[h])
+            k.sub(part, part, tr[h])
+            k.cmp_lit("ngt", 0x00100000, mass[h])               # !(mass < 2^-1022)
+            k.cnd32_vcc(part.lo(), 0, part.lo())
+            k.cnd32_vcc(part.hi(), c["NINFHI"], part.hi())
+        k.add(lt_star, part0, part1)
+        k.sop("s_not_b64", VCC, s_bad)
+        k.cnd32_vcc(lt_star.lo(), 0, lt_star.lo())
+        k.cnd32_vcc(lt_star.hi(), c["NINFHI"], lt_star.hi())
+        k.free(hs, tr, sse, mass, part0, part1, inv_s, s_bad)
+
+    # ------------------------------------------------------------------------------------------------------------ the kernel
+    def build(self):
+        k, c = self.k, self.c
+        self.prologue()
+        self.v_zero, self.v_infhi = k.v1(), k.v1()
+        k.mov32(self.v_zero, 0)
+        k.mov32(self.v_infhi, Lit(0x7ff00000))
+        k.count_marker("prologue")
+        l_loop, l_exit = k.new_label("loop"), k.new_label("exit")
+        k.label(l_loop)
+        self.draws()
+        k.count_marker("draws")
+        self.sweep()
+        k.count_marker("sweep")
+        self.save()
+        k.count_marker("save")
+        k.sop("s_cmp_gt_u32", None, self.s_t, self.s_tend)
+        k.branch("s_cbranch_scc1", l_exit)
+        k.comment("---- proposal theta* = theta + e^(loga/2) y (in y's registers), target, accept ----")
+        for i in range(D):
+            k.fma(self.y[i], self.sc, self.y[i], self.th[i])
+        lt_star = k.vd()
+        self.target(lt_star)
+        k.count_marker("target")
+        diff = k.vd()
+        k.sub(diff, lt_star, self.lt)
+        k.cmp("lt", self.s_acc, self.logu, diff)
+        k.free(diff)
+        for i in range(D):
+            k.cnd64(self.th[i], self.th[i], self.y[i], self.s_acc)
+        k.cnd64(self.lt, self.lt, lt_star, self.s_acc)
+        k.free(lt_star)
+        one = k.vd()
+        k.mov32(one.lo(), 0)
+        k.cnd32(one.hi(), 0, c["ONEHI"], self.s_acc)
+        k.add(self.nacc, self.nacc, one)
+        k.free(one)
+        k.sop("s_add_u32", self.s_t, self.s_t, 1)
+        k.count_marker("accept")
+        k.branch("s_branch", l_loop)
+        k.label(l_exit)
+        # ---- epilogue: state back to HBM ----
+        k.comment("---- epilogue: registers and LDS slots -> state ----")
+        st = k.sd()
+        t2 = k.sd()
+        k.s_load(st, self.g.kernarg, ARG_OFF["state"])
+        k.sop("s_mov_b32", t2.lo(), self.s_g0)
+        k.sop("s_mov_b32", t2.hi(), 0)
+        k.sop("s_lshl_b64", t2, t2, 3)
+        self.add64(st, st, t2)
+        self.walk_state(st, load=False)
+        k.label(self.l_end)
+        k.endpgm()
+        lines_meta = k.finish(LDS_BYTES, ARG_BYTES)
+        snaps = k.snapshots
+        order = ["prologue", "draws", "sweep", "save", "target", "accept"]
+        prev = snaps["prologue"]
+        for name in order[1:]:
+            cur = snaps[name]
+            self.info["count_" + name] = {key: cur.get(key, 0) - prev.get(key, 0) for key in sorted(cur) if cur.get(key, 0) - prev.get(key, 0)}
+            prev = cur
+        tot = {}
+        for name in order[1:]:
+            for key, v in self.info["count_" + name].items():
+                tot[key] = tot.get(key, 0) + v
+        self.info["count_iteration"] = tot
+        self.info["vgpr_high_water"] = k.v.high
+        self.info["sgpr_high_water"] = k.s.high
+        self.info["lds_bytes_per_workgroup"] = LDS_BYTES
+        self.info["lds_slots_per_wavefront"] = NSLOTS
+        return lines_meta, self.info
+
+
+def main_kernel():
+    return Main().build()
+
+
+def header_extra(info):
+    return ("#define PHF_ISA_HIER3_LDS_BYTES %d\n#define PHF_ISA_HIER3_VGPRS %d\n\n" % (info["lds_bytes_per_workgroup"], info["vgpr_high_water"]))

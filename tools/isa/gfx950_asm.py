@@ -379,6 +379,11 @@ class Kernel(object):
         self._bus_check([a, b])
         return self.emit("v_cmp_%s_f64_e64" % rel, [mask], [a, b], "valu", count="valu_f64")
 
+    def cmp_lit(self, rel, hi_word, v):
+        """VCC <- C rel v per lane, C the fp64 constant whose HIGH word is hi_word and whose low word is zero (VOPC e32: a 32-bit
+        literal stands for the high half of a 64-bit operand)"""
+        return self.emit("v_cmp_%s_f64_e32" % rel, [VCC], [Lit(hi_word), v], "valu", count="valu_f64")
+
     def cmp_u32(self, rel, mask, a, b):
         self._bus_check([a, b])
         return self.emit("v_cmp_%s_u32_e64" % rel, [mask], [a, b], "valu", count="valu_int")

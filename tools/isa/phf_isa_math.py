@@ -167,7 +167,7 @@ def log_fast(m, dsts, xs):
     k, c = m.k, m.c
     log_pos(m, dsts, xs)
     for i in range(len(xs)):
-        k.cmp("ngt", VCC, c["DBLMIN"], xs[i])                              # !(MIN > x): keep r (also for a NaN, as the C select does)
+        k.cmp_lit("ngt", 0x00100000, xs[i])                                # !(2^-1022 > x): keep r (also for a NaN, as the C select does)
         k.cnd32_vcc(dsts[i].lo(), 0, dsts[i].lo())
         k.cnd32_vcc(dsts[i].hi(), c["NINFHI"], dsts[i].hi())                # high word of -inf in a VGPR (VCC is the constant-bus read)
 
@@ -194,7 +194,7 @@ def erfc_tab(m, dsts, ys):
     for j in range(9, -1, -1):
         _each(n, lambda i, j=j: k.fma(p[i], p[i], s[i], cf(i, j)))
     for i in range(n):
-        k.cmp("lt", VCC, ys[i], c["P6"])
+        k.cmp_lit("gt", 0x40180000, ys[i])                                 # y < 6
         k.cnd32_vcc(dsts[i].lo(), 0, p[i].lo())
         k.cnd32_vcc(dsts[i].hi(), 0, p[i].hi())
     k.free(t, s, ad, tab)
