@@ -177,10 +177,10 @@ class HierarchicalBatch(object):
         groups = {}
         for p, (d_, c_) in enumerate(names):
             ne, _, ex = dr.load_crumb_data(d_, c_)
-            groups.setdefault(len(ex), []).append((p, ex))
+            groups.setdefault(H.group_key(ex), []).append((p, ex))
         shapes, scales, locs = H.prior_params()
         self.samplers = []
-        for ne, members in sorted(groups.items(), reverse=True):
+        for (ne, _), members in sorted(groups.items(), reverse=True):
             exs = [ex for _, ex in members]
             start = np.array([H.first_iteration(e, locs) for e in exs])
             if units is None:

@@ -233,6 +233,20 @@ int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* pro
                              const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
                              double* moments, int64_t moments_after, void* stream);
 
+/* The same advance as a WORK QUEUE inside one launch (ABI 6), as phf_single_level_advance_queued: where the launch runs the gfx950
+ * assembly build (n_expts == 3, points_per_expt == 4, one lane per chain) AND has more 64-chain blocks than the chip holds wavefronts
+ * (2 x phf_simd_count()) AND at least two quanta, it is cut into quanta of `quantum` iterations (0 = the library's choice, 125; rounded
+ * down to a multiple of the thinning) and a grid as large as the chip pulls (quantum, block) tasks from a counter, a block's quanta
+ * chaining through its state in HBM with agent-scope release / acquire — the ragged last round of a launch becomes a round of short
+ * tasks (147 pairs x 1 024 chains: 2 352 wavefronts on 2 048 slots).  Every other launch runs exactly as phf_hierarchical_advance.
+ * Results are identical either way (same chains, rows, state, moments).
+ *   queue   device int32 [2 + Q * ceil(C / 64)], owned by the caller, zeroed by the caller when allocated; words 0 .. Q ceil(C/64) are
+ *           zeroed here, on the stream, before a queued launch; the LAST word is the sticky fault flag of
+ *           phf_single_level_queue_status (same layout, same meaning: check it there wherever the host synchronises anyway). */
+int phf_hierarchical_advance_queued(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
+                                    const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
+                                    double* moments, int64_t moments_after, int32_t quantum, int32_t* queue, void* stream);
+
 /* Which kernel runs groups with Ne = 3..6, PROCESS-WIDE (ABI 4; A/B timing and the bit-identity tests): lanes 1 | 2 = one | two lanes
  * per chain, wps 1 | 2 = the register build of the two-lane kernel (512 | 256 registers); 0 = not forced: the launch's own
  * phf_problems.kernel_hint, else the launch size, decides.  The environment variables PHF_HIER_LANES / PHF_HIER_WPS give the initial
@@ -245,6 +259,7 @@ int phf_hierarchical_set_kernel_policy(int lanes, int wps);
 #define PHF_HIER_KERNEL_TWO_LANES 2    /* hier_advance2_kernel<Ne, wps> */
 #define PHF_HIER_KERNEL_WAVE 3         /* hier_wave_advance_kernel: one wavefront per chain (Ne > 8) */
 #define PHF_HIER_KERNEL_GFX950_ISA 4   /* phf_hier3_advance: the hand-allocated gfx950 build (Ne = 3, four points per experiment) */
+#define PHF_HIER_KERNEL_GFX950_ISA_QUEUED 5   /* ... as a work queue (phf_hierarchical_advance_queued) */
 int phf_hierarchical_last_kernel(void);
 
 /* log_target_distribution (python/PyHillFit.py:173-193) at M parameter vectors: theta device [dim][M]. */

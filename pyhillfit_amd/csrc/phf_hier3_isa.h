@@ -9,7 +9,8 @@
 
 // true once the embedded code object is loaded on the current device and holds the advance kernel
 bool phf_hier3_isa_available();
-// launch phf_hier3_advance: `a` complete except `consts` (filled here); (total_waves + 3) / 4 workgroups of 256 threads
-int phf_hier3_isa_advance(phf_hier3_isa_args* a, hipStream_t stream);
+// launch phf_hier3_advance: `a` complete except `consts` (filled here); (grid_waves + 3) / 4 workgroups of 256 threads — grid_waves =
+// a->total_waves for a plain launch (a->queue == NULL), the chip's wavefront slots for a queued one
+int phf_hier3_isa_advance(phf_hier3_isa_args* a, int grid_waves, hipStream_t stream);
 
 #endif

@@ -135,12 +135,12 @@ bool phf_hier3_isa_available() {
   return m->advance != nullptr;
 }
 
-int phf_hier3_isa_advance(phf_hier3_isa_args* a, hipStream_t stream) {
+int phf_hier3_isa_advance(phf_hier3_isa_args* a, int grid_waves, hipStream_t stream) {
   DeviceModule* m = nullptr;
   if (int rc = get_module(&m)) return rc;
   if (!m->advance) return phf_fail(PHF_ERR_UNSUPPORTED, "gfx950 code object holds no phf_hier3_advance");
   a->consts = m->consts;
-  const unsigned blocks = (unsigned)((a->total_waves + 3) / 4);
+  const unsigned blocks = (unsigned)((grid_waves + 3) / 4);
   return launch(m->advance, blocks, a, sizeof(*a), stream, "phf_hierarchical_advance (gfx950 assembly, Ne = 3)");
 }
 

@@ -58,6 +58,8 @@ struct HierArgs {
   double* moments;
   int64_t moments_after;
   int32_t blocks_per_problem;
+  int32_t* queue;          // phf_hierarchical_advance_queued: the work-queue workspace (gfx950 assembly build only) and the quantum asked for
+  int32_t quantum;
   // init only
   double cov_scale;
   const double* theta0;
@@ -994,9 +996,28 @@ int launch_isa3(const HierArgs& a, hipStream_t stream, bool* launched) {
   g.until_save0 = a.cfg.thinning - (int32_t)(a.t_begin % a.cfg.thinning);
   for (int i = 0; i < 5; ++i) { g.prior_loc[i] = a.prior.loc[i]; g.prior_inv_scale[i] = a.prior.inv_scale[i]; g.prior_shape_m1[i] = a.prior.shape_m1[i]; }
   g.three_twelve[0] = 3.0; g.three_twelve[1] = 12.0;
+  // Work queue (phf_hierarchical_advance_queued): the launch is cut into quanta, the grid is only as large as the chip holds (two
+  // wavefronts per SIMD) and its wavefronts pull (quantum, block) tasks, so that the last round of a launch is a round of short tasks:
+  // 147 pairs x 1 024 chains are 2 352 wavefronts on 2 048 slots — 1.15 rounds that cost two without the queue.  Worth it only when
+  // the blocks do not fit the chip at once and the launch has at least two quanta; the quantum is a multiple of the thinning, so that
+  // every quantum saves the same number of rows.
+  const int64_t slots = 2LL * phf_simd_count();
+  int64_t quantum = a.quantum > 0 ? a.quantum : 125;
+  quantum -= quantum % a.cfg.thinning;
+  if (quantum < a.cfg.thinning) quantum = a.cfg.thinning;
+  const int64_t nquanta = (a.t_end - a.t_begin + quantum - 1) / quantum;
+  int64_t grid_waves = total;
+  if (a.queue && total > slots && nquanta >= 2 && nquanta * total * total < (1LL << 32) && a.t_begin % a.cfg.thinning == 0) {
+    if (hipMemsetAsync(a.queue, 0, (size_t)(1 + total) * sizeof(int32_t), stream) != hipSuccess)
+      return phf_check_launch("phf_hierarchical_advance_queued (memset)");
+    g.queue = a.queue; g.quantum = (uint32_t)quantum; g.num_tasks = (int32_t)(nquanta * total);
+    g.blocks_magic = total == 1 ? 0u : (uint32_t)((1ULL << 32) / (uint64_t)total + 1ULL);
+    g.rows_per_quantum = (uint32_t)(quantum / a.cfg.thinning);
+    grid_waves = slots;
+  }
   *launched = true;
-  g_last_kernel = PHF_HIER_KERNEL_GFX950_ISA;
-  return phf_hier3_isa_advance(&g, stream);
+  g_last_kernel = g.queue ? PHF_HIER_KERNEL_GFX950_ISA_QUEUED : PHF_HIER_KERNEL_GFX950_ISA;
+  return phf_hier3_isa_advance(&g, (int)grid_waves, stream);
 }
 
 int hier_wps_override(const HierArgs& a) {
@@ -1174,9 +1195,9 @@ int phf_hierarchical_init(const phf_hier_points* pts, const phf_problems* prob, 
   return dispatch_init(a, (hipStream_t)stream);
 }
 
-int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
+static int hier_advance_impl(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
                              const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
-                             double* moments, int64_t moments_after, void* stream) {
+                             double* moments, int64_t moments_after, int32_t quantum, int32_t* queue, void* stream) {
   if (!prob || !cfg) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null problems/config");
   if (int rc = check(pts, prob, prior)) return rc;
   if (!state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null state");
@@ -1190,7 +1211,22 @@ int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* pro
   a.pts = *pts; a.prob = *prob; a.prior = *prior; a.cfg = *cfg; a.t_begin = t_begin; a.t_end = t_end; a.state = state; a.rows = rows;
   a.moments = moments; a.moments_after = moments_after;
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
+  a.queue = queue; a.quantum = quantum;
+  if (int rc = phf_require_device_memory(queue, "queue workspace")) return rc;
   return dispatch_advance(a, (hipStream_t)stream);
+}
+
+int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
+                             const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
+                             double* moments, int64_t moments_after, void* stream) {
+  return hier_advance_impl(pts, prob, prior, cfg, t_begin, t_end, state, rows, moments, moments_after, 0, nullptr, stream);
+}
+
+int phf_hierarchical_advance_queued(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
+                                    const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
+                                    double* moments, int64_t moments_after, int32_t quantum, int32_t* queue, void* stream) {
+  if (quantum < 0 || !queue) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "queued advance needs a queue workspace and a quantum >= 0 (0 = the library's)");
+  return hier_advance_impl(pts, prob, prior, cfg, t_begin, t_end, state, rows, moments, moments_after, quantum, queue, stream);
 }
 
 int phf_hierarchical_log_target(const phf_hier_points* pts, const phf_hier_prior* prior, int64_t m,

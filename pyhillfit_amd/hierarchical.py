@@ -56,6 +56,16 @@ def make_prior(shapes=None, scales=None, locs=None):
     return pr
 
 
+def group_key(experiments):
+    """Which launch group a pair belongs to: pairs of one group share a kernel instantiation.  (Ne, 0) in general; (3, 4) for the pairs
+    with three experiments of exactly four points (147 of the Crumb set's 210), which run the hand-allocated gfx950 build of the
+    iteration (phf_hier_points.points_per_expt)."""
+    ne = len(experiments)
+    if ne == 3 and all(len(x) == 4 for x in experiments):
+        return (ne, 4)
+    return (ne, 0)
+
+
 class PackedHierPoints(object):
     """numpy image of `phf_hier_points`: pairs that all have Ne experiments, points experiment by experiment."""
 
@@ -100,6 +110,8 @@ def _bind(lib):
     lib.phf_hierarchical_init.argtypes = [C.POINTER(HierPoints), C.POINTER(_lib.Problems), C.POINTER(HierPrior), f64, vp, vp, vp, vp]
     lib.phf_hierarchical_advance.argtypes = [C.POINTER(HierPoints), C.POINTER(_lib.Problems), C.POINTER(HierPrior),
                                              C.POINTER(_lib.MhConfig), i64, i64, vp, vp, vp, i64, vp]
+    lib.phf_hierarchical_advance_queued.argtypes = [C.POINTER(HierPoints), C.POINTER(_lib.Problems), C.POINTER(HierPrior),
+                                                    C.POINTER(_lib.MhConfig), i64, i64, vp, vp, vp, i64, C.c_int32, vp, vp]
     lib.phf_hierarchical_log_target.argtypes = [C.POINTER(HierPoints), C.POINTER(HierPrior), i64, vp, vp, vp, vp]
     lib._phf_hier_bound = True
 
@@ -191,6 +203,10 @@ class HierarchicalSampler(object):
             raise _lib.PhfError(self.lib.phf_last_error().decode())
         self.state = torch.zeros((self.S, self.Q * self.C), dtype=torch.float64, device=dev)
         self.moments, self.moments_after, self.t, self.row0, self._gamma = None, 0, 0, None, None
+        # work-queue workspace of phf_hierarchical_advance_queued (used by launches that run the gfx950 assembly build on more blocks
+        # than the chip holds wavefronts; ignored by every other launch); quantum 0 = the library's choice
+        self.queue = torch.zeros(2 + self.Q * (-(-self.C // 64)), dtype=torch.int32, device=dev)
+        self.quantum = 0
 
     def set_kernel_hint(self, lanes=0, wps=0, isa=None):
         """which kernel THIS sampler's launches should get (phf_problems.kernel_hint: lanes per chain 1 | 2, register build of the two-lane
@@ -241,10 +257,11 @@ class HierarchicalSampler(object):
             rows = torch.empty(shape, dtype=torch.float64, device=self.device) if out is None else out
             if tuple(rows.shape) != shape or not rows.is_contiguous():
                 raise ValueError("out must be contiguous with shape %s" % (shape,))
-        _lib.check(self.lib.phf_hierarchical_advance(C.byref(self.points.struct), C.byref(self.prob), C.byref(self.prior),
-                                                     C.byref(cfg), self.t, t_end, _ptr(self.state), _ptr(rows),
-                                                     _ptr(self.moments), self.moments_after, _stream_ptr(self.device)),
-                   "phf_hierarchical_advance")
+        _lib.check(self.lib.phf_hierarchical_advance_queued(C.byref(self.points.struct), C.byref(self.prob), C.byref(self.prior),
+                                                            C.byref(cfg), self.t, t_end, _ptr(self.state), _ptr(rows),
+                                                            _ptr(self.moments), self.moments_after, int(self.quantum), _ptr(self.queue),
+                                                            _stream_ptr(self.device)),
+                   "phf_hierarchical_advance_queued")
         self.t = t_end
         return rows
 
@@ -291,7 +308,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         if ne > MAX_EXPTS:
             print("{} + {}: {} experiments exceed the {} supported by the hierarchical kernels --- skipping".format(drug, channel, ne, MAX_EXPTS))
             continue
-        groups.setdefault(ne, []).append((drug, channel, experiments, all_pairs.index((drug, channel)), fitted_all))
+        groups.setdefault(group_key(experiments), []).append((drug, channel, experiments, all_pairs.index((drug, channel)), fitted_all))
     summaries = []
     total_iterations, thinning = args.iterations, args.thinning
     saved_iterations = total_iterations // thinning + 1                # :469
@@ -307,7 +324,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     # (the least-squares fits of every experiment of every pair as ONE batch in this process, the two small distribution fits
     # per pair over the pool)
     fits = bestfit.hierarchical_first_iteration_batch([m[2] for _, members in ordered for m in members], locs)
-    for ne, members in ordered:
+    for (ne, _), members in ordered:
         packed = PackedHierPoints([m[2] for m in members])
         theta0 = np.array(fits[:len(members)]); fits = fits[len(members):]
         Q, C, d = len(members), args.num_chains, 5 + 2 * ne

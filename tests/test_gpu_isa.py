@@ -125,3 +125,39 @@ def test_isa_advance_bit_identical_to_the_twin(gpu, oracle_pair):
             rows = pk.advance(st, 0, T, thin, adapt, gam, seed=987654321, chain_id=9 + c, problem_id=7 + 3 * q)
             assert np.array_equal(chain[:, q, :, c], rows), (q, c)
             assert np.array_equal(state[:, q, c], st), (q, c)
+
+
+def test_isa_work_queue_bit_identical_at_full_width(gpu):
+    """all 147 Crumb pairs with 3 x 4 points x 1 024 chains = 2 352 blocks on 2 048 wavefront slots: the launch runs as a work queue
+    (quanta of 125 iterations, blocks chaining through their state in HBM) — rows, state and moments against the hipcc kernel's plain
+    launch, bit for bit; launches of 300 (125 + 125 + 50) and 500 iterations, moments from iteration 1 200 on"""
+    import os
+    import torch
+    from conftest import REPO
+    from pyhillfit_amd import bestfit, doseresponse as dr, hierarchical as H
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    shapes, scales, locs = H.prior_params()
+    exs = []
+    for d in dr.drugs:
+        for c in dr.channels:
+            ne, _, ex = dr.load_crumb_data(d, c)
+            if H.group_key(ex) == (3, 4):
+                exs.append(ex)
+    assert len(exs) == 147
+    packed = H.PackedHierPoints(exs)
+    theta0 = np.array([bestfit.hierarchical_first_iteration(e, locs) for e in exs])
+    got = {}
+    for isa in (False, True):
+        s = H.HierarchicalSampler(packed, list(range(len(exs))), 1024, thinning=5, seed=77, adapt_start=1100, device=gpu)
+        s.set_kernel_hint(lanes=1, isa=isa)
+        s.init(theta0, cov_scale=0.01)
+        s.enable_moments(after_iteration=1200)
+        s.advance(1000, save=False)
+        assert H.last_kernel() == (5 if isa else 1), H.last_kernel()
+        rows = torch.cat([s.advance(k) for k in (300, 500)])
+        torch.cuda.synchronize()
+        assert int(s.queue[-1]) == 0                                  # the queue's sticky fault word
+        got[isa] = (rows, s.state.clone(), s.moments.clone())
+    for name, a, b in zip(("rows", "state", "moments"), got[False], got[True]):
+        same = a.view(torch.int64) == b.view(torch.int64)
+        assert bool(same.all()), (name, int((~same).sum()))

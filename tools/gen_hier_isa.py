@@ -42,11 +42,12 @@ S_TH, S_LT, S_MEAN, S_TRI, S_LOGA, S_NACC = 0, D, D + 1, 2 * D + 1, 2 * D + 1 + 
 # kernel arguments of phf_hier3_advance (bytes); the C struct is generated from this list (phf_hier3_isa_layout.h)
 ARGS = [("consts", "const void*"), ("state", "double*"), ("rows", "double*"), ("moments", "double*"), ("gamma", "const double*"),
         ("ln_conc", "const double*"), ("response", "const double*"), ("pair_index", "const int32_t*"), ("problem_id", "const uint32_t*"),
-        ("launch_order", "const int32_t*"), ("chain_offset", "const uint32_t*"),
+        ("launch_order", "const int32_t*"), ("chain_offset", "const uint32_t*"), ("queue", "int32_t*"),
         ("t_begin", "uint32_t"), ("t_end", "uint32_t"), ("adapt_start", "uint32_t"), ("thinning", "int32_t"),
         ("moments_after", "uint32_t"), ("chains", "int32_t"), ("num_problems", "int32_t"), ("bpp", "int32_t"),
         ("bpp_magic", "uint32_t"), ("total_waves", "int32_t"), ("seed_lo", "uint32_t"), ("seed_hi", "uint32_t"),
-        ("chain_id_base", "uint32_t"), ("pts_stride", "int32_t"), ("until_save0", "int32_t"), ("pad0", "int32_t"),
+        ("chain_id_base", "uint32_t"), ("pts_stride", "int32_t"), ("until_save0", "int32_t"), ("quantum", "uint32_t"),
+        ("num_tasks", "int32_t"), ("blocks_magic", "uint32_t"), ("rows_per_quantum", "uint32_t"), ("pad0", "int32_t"),
         ("prior_loc", "double[5]"), ("prior_inv_scale", "double[5]"), ("prior_shape_m1", "double[5]"), ("three_twelve", "double[2]")]
 
 

@@ -13,10 +13,15 @@ from gen_hier_isa import ARG_BYTES, ARG_OFF, D, NE, S_LOGA, S_LT, S_MEAN, S_NACC
 # ---- what lives where ---------------------------------------------------------------------------------------------------------
 # LDS, per wavefront: [slot][64 lanes] doubles.  slots 0..10 the running mean, 11..21 the diagonal d, then the elements of L listed here
 # (row i, column k < i); every other element of L stays in VGPRs.
-LDS_L = [(i, 0) for i in range(1, D)] + [(i, 1) for i in range(2, 6)]
+LDS_L = [(i, 0) for i in range(1, D)] + [(i, 1) for i in range(2, 5)]
 SLOT_MEAN, SLOT_D, SLOT_L = 0, D, 2 * D
 NSLOTS = 2 * D + len(LDS_L)
-WAVE_LDS = NSLOTS * 512
+# ... and the wavefront's UNIFORM values, read with one address for all lanes (a broadcast): the pair's points, experiment by experiment
+# [ln c (4)][y (4)], then the prior's loc[5], 1/scale[5], shape-1[5].  (Scalar loads would do — but they share lgkmcnt with the LDS and
+# return out of order, so every table look-up behind one waits for it: ~11 exposed scalar-memory latencies per iteration, measured as
+# 20 % of the wavefront's cycles in s_waitcnt.)
+U_POINTS, U_LOC, U_ISC, U_SM1, U_BYTES = 0, 192, 232, 272, 320
+WAVE_LDS = NSLOTS * 512 + U_BYTES
 WAVE_BASE = 8064                                    # behind the workgroup's tables (M.TABLE_BYTES, padded)
 LDS_BYTES = WAVE_BASE + 4 * WAVE_LDS
 
@@ -56,58 +61,175 @@ class Main(object):
     def lds_store(self, slot, src):
         self.k.ds_write(self.v_lds, src, slot * 512)
 
+    def uload(self, dst, off):
+        """dst (a pair, or a quad for two consecutive doubles) <- the wavefront's uniform area at byte offset `off` (same address in every lane)"""
+        self.k.ds_read(dst, self.v_ulds, off)
+        return dst
+
     def l_slot(self, i, kcol):
         return SLOT_L + LDS_L.index((i, kcol))
 
     # ------------------------------------------------------------------------------------------------------------ prologue
-    def prologue(self):
+    def ptr(self, name):
+        r = self.k.sd()
+        self.k.s_load(r, self.g.kernarg, ARG_OFF[name])
+        return r
+
+    def prologue_once(self):
+        """what a wavefront does once: constants, the workgroup's tables, its own LDS areas, the registers that live as long as it does"""
         k, g = self.k, self.g
-        k.comment("---- prologue: arguments, tables -> LDS, constants, which (problem, 64-chain block) this wavefront owns ----")
+        k.comment("---- once per wavefront: constants, tables -> LDS, LDS bases ----")
         assert ARG_OFF["total_waves"] == ARG_OFF["num_problems"] + 12 and ARG_OFF["chains"] == ARG_OFF["adapt_start"] + 12
-
-        def ptr(name):
-            r = k.sd()
-            k.s_load(r, g.kernarg, ARG_OFF[name])
-            return r
-
-        s_consts = ptr("consts")
+        s_consts = self.ptr("consts")
         g.load_constants(s_consts, RESIDENT)
-        # every scalar that lives as long as the loop, allocated in one block (temporaries come and go behind it: no holes)
+        # every scalar that lives as long as the wavefront, allocated in one block (temporaries come and go behind it: no holes)
         self.s_pid, self.s_g0, self.s_flags, self.s_c8 = k.s1(), k.s1(), k.s1(), k.s1()
         self.s_t, self.s_tend, self.s_first, self.s_adapt = k.s1(), k.s1(), k.s1(), k.s1()
         self.s_until, self.s_thin, self.s_mafter = k.s1(), k.s1(), k.s1()
         self.s_seedlo, self.s_seedhi = k.s1(), k.s1()
+        self.s_wave, self.s_block, self.s_quant = k.s1(), k.s1(), k.s1()      # wave in the workgroup; the task: block, quantum
         self.s_nch8, self.s_rows, self.s_rstride, self.s_mom = k.sd(), k.sd(), k.sd(), k.sd()
-        self.s_lc, self.s_yp, self.s_gamma, self.s_acc = k.sd(), k.sd(), k.sd(), k.sd()
+        self.s_gamma, self.s_acc, self.s_queue = k.sd(), k.sd(), k.sd()
         g.stage_tables(s_consts)
         k.free(s_consts)
+        self.v_lane, self.v_lane8, self.v_lds, self.v_ulds, self.v_cid = k.v1(), k.v1(), k.v1(), k.v1(), k.v1()
+        self.v_zero, self.v_infhi = k.v1(), k.v1()
+        k.mov32(self.v_zero, 0)
+        k.mov32(self.v_infhi, Lit(0x7ff00000))
+        vt, tmp = k.v1(), k.s1()
+        k.vop("v_lshrrev_b32_e32", vt, 6, g.tid)
+        k.readfirstlane(self.s_wave, vt)
+        k.vop("v_and_b32_e32", self.v_lane, 63, g.tid)
+        k.vop("v_lshlrev_b32_e32", self.v_lane8, 3, self.v_lane)
+        k.sop("s_mul_i32", tmp, self.s_wave, Lit(WAVE_LDS))
+        k.sop("s_add_u32", tmp, tmp, Lit(WAVE_BASE))
+        k.vop("v_add_u32_e32", self.v_lds, tmp, self.v_lane8)
+        k.sop("s_add_u32", tmp, tmp, Lit(NSLOTS * 512))
+        k.mov32(self.v_ulds, tmp)
+        k.s_load(self.s_queue, g.kernarg, ARG_OFF["queue"])
+        k.free(vt, tmp)
+        # the chain state's registers
+        self.th = [k.vd() for _ in range(D)]
+        self.lt = k.vd()
+        self.y = [k.vd() for _ in range(D)]
+        self.Lreg = {}
+        for i in range(1, D):
+            for kc in range(i):
+                if (i, kc) not in LDS_L:
+                    self.Lreg[(i, kc)] = k.vd()
+        self.loga, self.nacc, self.sc, self.logu = k.vd(), k.vd(), k.vd(), k.vd()
+        k.s_waitcnt_all()
+
+    def next_task(self):
+        """which (block, quantum) this wavefront runs next.  Plain launch (queue == NULL): block = its global number, the whole launch,
+        once.  Queued launch: the grid is as large as the chip holds and its wavefronts PULL tasks from a counter (queue[0]); task n is
+        quantum n / blocks of block n % blocks (quantum-major: a block's quanta are pulled a whole round of tasks apart), and a block's
+        quanta chain through its state in HBM: whoever finishes quantum j of block b publishes queue[1 + b] = j + 1 behind an agent-scope
+        release; whoever pulled quantum j + 1 polls that word, then acquires.  As phf_single_level.hip's queue, instruction for instruction
+        what hipcc emits there (global_atomic_add sc0, global_load sc1 + s_sleep, buffer_inv sc1 / buffer_wbl2 sc1, global_store sc1)."""
+        k, g = self.k, self.g
+        k.comment("---- next task ----")
+        self.l_task = k.new_label("task")
+        self.l_end = k.new_label("end")
+        l_plain, l_have = k.new_label("plain"), k.new_label("have")
+        k.label(self.l_task)
+        k.sop("s_mov_b64", EXEC, -1)
         w4 = k.sx(4)
         k.s_load(w4, g.kernarg, ARG_OFF["num_problems"])          # num_problems bpp bpp_magic total_waves
         a_np, a_bpp, a_magic, a_total = (w4.sub(i, 1) for i in range(4))
-        c4 = k.sx(4)
-        k.s_load(c4, g.kernarg, ARG_OFF["adapt_start"])           # adapt_start thinning moments_after chains
-        a_adapt, a_thin, a_mafter, a_C = (c4.sub(i, 1) for i in range(4))
-        # wave number inside the workgroup, global wave number
+        q4 = k.sx(4)
+        k.s_load(q4, g.kernarg, ARG_OFF["quantum"])               # quantum num_tasks blocks_magic rows_per_quantum
+        a_quant, a_ntasks, a_bmagic, a_rpq = (q4.sub(i, 1) for i in range(4))
+        assert ARG_OFF["rows_per_quantum"] == ARG_OFF["quantum"] + 12
+        tb = k.sd()
+        k.s_load(tb, g.kernarg, ARG_OFF["t_begin"])               # t_begin t_end
+        tmp, task = k.s1(), k.s1()
+        k.sop("s_cmp_eq_u64", None, self.s_queue, 0)
+        k.branch("s_cbranch_scc1", l_plain)
+        # -- queued: pull a task
         vt = k.v1()
-        k.vop("v_lshrrev_b32_e32", vt, 6, g.tid)
-        s_wave = k.s1()
-        k.readfirstlane(s_wave, vt)
-        gw = k.s1()
-        k.sop("s_lshl_b32", gw, g.wg_id, 2)
-        k.sop("s_add_u32", gw, gw, s_wave)
-        self.l_end = k.new_label("end")
-        k.sop("s_cmp_ge_u32", None, gw, a_total)
+        one = k.v1()
+        save = k.sd()
+        k.mov32(one, 1)
+        k.emit("v_cmp_eq_u32_e32", [VCC], [0, self.v_lane], "valu", count="valu_int")
+        k.sop("s_and_saveexec_b64", save, VCC)
+        k.emit("global_atomic_add", [vt], [self.v_zero, one, self.s_queue], "vmem", suffix="sc0", mem="vm")
+        k.sop("s_mov_b64", EXEC, save)
+        k.readfirstlane(task, vt)
+        k.sop("s_cmp_ge_u32", None, task, a_ntasks)
         k.branch("s_cbranch_scc1", self.l_end)
-        # slot = gw / bpp (host-checked magic), chunk = gw - slot * bpp
-        slot, chunk, tmp = k.s1(), k.s1(), k.s1()
-        k.sop("s_mul_hi_u32", slot, gw, a_magic)
-        k.sop("s_cmp_eq_u32", None, a_magic, 0)                   # bpp == 1: the magic does not fit 32 bits; slot = gw
-        k.sop("s_cselect_b32", slot, gw, slot)
+        k.sop("s_mul_hi_u32", self.s_quant, task, a_bmagic)      # quantum = task / blocks (host-checked magic; 0 = one block)
+        k.sop("s_cmp_eq_u32", None, a_bmagic, 0)
+        k.sop("s_cselect_b32", self.s_quant, task, self.s_quant)
+        k.sop("s_mul_i32", tmp, self.s_quant, a_total)
+        k.sop("s_sub_u32", self.s_block, task, tmp)
+        # wait for this block's previous quantum: queue[1 + block] >= quantum
+        cur = k.sd()
+        polls = k.s1()
+        l_poll, l_ready, l_giveup = k.new_label("poll"), k.new_label("ready"), k.new_label("giveup")
+        k.sop("s_lshl_b32", cur.lo(), self.s_block, 2)
+        k.sop("s_mov_b32", cur.hi(), 0)
+        self.add64(cur, cur, self.s_queue)
+        k.sop("s_mov_b32", polls, 0)
+        k.sop("s_cmp_eq_u32", None, self.s_quant, 0)
+        k.branch("s_cbranch_scc1", l_ready)
+        k.label(l_poll)
+        k.emit("global_load_dword", [vt], [self.v_zero, cur], "vmem", suffix="offset:4 sc1", mem="vm")
+        k.readfirstlane(tmp, vt)
+        k.sop("s_cmp_ge_i32", None, tmp, self.s_quant)
+        k.branch("s_cbranch_scc1", l_ready)
+        k.raw_rec("s_sleep 16")
+        k.sop("s_add_u32", polls, polls, 1)
+        k.sop("s_cmp_lt_u32", None, polls, Lit(1 << 22))
+        k.branch("s_cbranch_scc1", l_poll)
+        # cannot happen in a correct run: give up, poison the counter so that every wavefront drains, raise the sticky fault word
+        k.label(l_giveup)
+        k.sop("s_lshl_b32", cur.lo(), a_total, 2)
+        k.sop("s_mov_b32", cur.hi(), 0)
+        self.add64(cur, cur, self.s_queue)
+        k.mov32(one, 1)
+        k.emit("global_store_dword", [], [self.v_zero, one, cur], "vmem", suffix="offset:4 sc1", mem="vm")
+        k.mov32(one, Lit(0x40000000))
+        k.emit("global_store_dword", [], [self.v_zero, one, self.s_queue], "vmem", suffix="sc1", mem="vm")
+        k.branch("s_branch", self.l_end)
+        k.label(l_ready)
+        k.raw_rec("buffer_inv sc1")
+        k.free(cur, polls, vt, one, save)
+        # this quantum's iterations: (t_begin + quantum * Q, min(that + Q, t_end)]
+        k.sop("s_mul_i32", tmp, self.s_quant, a_quant)
+        k.sop("s_add_u32", self.s_first, tb.lo(), tmp)
+        k.sop("s_add_u32", self.s_tend, self.s_first, a_quant)
+        k.sop("s_min_u32", self.s_tend, self.s_tend, tb.hi())
+        k.sop("s_add_u32", self.s_first, self.s_first, 1)
+        k.sop("s_mul_i32", task, self.s_quant, a_rpq)             # rows saved by this block's earlier quanta (< 2^32)
+        k.branch("s_branch", l_have)
+        # -- plain: one task per wavefront
+        k.label(l_plain)
+        k.sop("s_lshl_b32", self.s_block, g.wg_id, 2)
+        k.sop("s_add_u32", self.s_block, self.s_block, self.s_wave)
+        k.sop("s_cmp_ge_u32", None, self.s_block, a_total)
+        k.branch("s_cbranch_scc1", self.l_end)
+        k.sop("s_mov_b32", self.s_quant, 0)
+        k.sop("s_mov_b32", task, 0)
+        k.sop("s_add_u32", self.s_first, tb.lo(), 1)
+        k.sop("s_mov_b32", self.s_tend, tb.hi())
+        k.label(l_have)
+        k.free(q4, tb)
+        k.sop("s_mov_b32", self.s_t, self.s_first)
+        k.comment("---- the block: which problem, which chains; uniform area; addresses; state -> registers / LDS ----")
+        a_C = k.s1()
+        k.s_load(a_C, g.kernarg, ARG_OFF["chains"])
+        # slot = block / bpp (host-checked magic), chunk = block - slot * bpp
+        slot, chunk = k.s1(), k.s1()
+        k.sop("s_mul_hi_u32", slot, self.s_block, a_magic)
+        k.sop("s_cmp_eq_u32", None, a_magic, 0)                   # bpp == 1: the magic does not fit 32 bits; slot = block
+        k.sop("s_cselect_b32", slot, self.s_block, slot)
         k.sop("s_mul_i32", tmp, slot, a_bpp)
-        k.sop("s_sub_u32", chunk, gw, tmp)
+        k.sop("s_sub_u32", chunk, self.s_block, tmp)
+        k.free(w4)
         # q = launch_order ? launch_order[slot] : slot
         q = k.s1()
-        a_order = ptr("launch_order")
+        a_order = self.ptr("launch_order")
         k.sop("s_mov_b32", q, slot)
         l_noorder = k.new_label("noorder")
         k.sop("s_cmp_eq_u64", None, a_order, 0)
@@ -115,11 +237,11 @@ class Main(object):
         k.sop("s_lshl_b32", tmp, slot, 2)
         k.s_load(q, a_order, tmp)
         k.label(l_noorder)
-        k.free(a_order, slot, gw)
+        k.free(a_order, slot)
         # pair, problem id, chain offset
         s_pair = k.s1()
         s_coff = k.s1()
-        a_pi, a_pid, a_coff = ptr("pair_index"), ptr("problem_id"), ptr("chain_offset")
+        a_pi, a_pid, a_coff = self.ptr("pair_index"), self.ptr("problem_id"), self.ptr("chain_offset")
         k.sop("s_lshl_b32", tmp, q, 2)
         k.s_load(s_pair, a_pi, tmp)
         k.s_load(self.s_pid, a_pid, tmp)
@@ -130,37 +252,63 @@ class Main(object):
         k.s_load(s_coff, a_coff, tmp)
         k.label(l_nocoff)
         k.free(a_pi, a_pid, a_coff)
-        more = k.sx(4)
-        k.s_load(more, g.kernarg, ARG_OFF["seed_lo"])             # seed_lo seed_hi chain_id_base pts_stride
-        # lanes: c = chunk * 64 + lane < C
-        self.v_lane8 = k.v1()
-        self.v_lds = k.v1()
-        self.v_cid = k.v1()
-        lane = k.v1()
+        a_stride = k.s1()
+        k.s_load(a_stride, g.kernarg, ARG_OFF["pts_stride"])
+        lane = self.v_lane
         c0 = k.s1()
         k.sop("s_lshl_b32", c0, chunk, 6)
-        k.vop("v_and_b32_e32", lane, 63, g.tid)
+        # the wavefront's uniform area (before EXEC shrinks to the live chains): lanes 0..11 the points, lanes 0..14 the prior
+        a_lc, a_y = self.ptr("ln_conc"), self.ptr("response")
+        pp = k.sd()
+        k.sop("s_mul_i32", pp.lo(), s_pair, a_stride)
+        k.sop("s_mul_hi_u32", pp.hi(), s_pair, a_stride)
+        k.sop("s_lshl_b64", pp, pp, 3)
+        self.add64(a_lc, a_lc, pp)
+        self.add64(a_y, a_y, pp)
+        save = k.sd()
+        ua, u1, u2 = k.v1(), k.vd(), k.vd()
+        k.emit("v_cmp_gt_u32_e32", [VCC], [12, lane], "valu", count="valu_int")
+        k.sop("s_and_saveexec_b64", save, VCC)
+        k.gload(u1, self.v_lane8, a_lc)
+        k.gload(u2, self.v_lane8, a_y)
+        k.vop("v_and_b32_e32", ua, Lit(0xfffffffc), lane)            # point p of experiment p >> 2: doubles 8 (p >> 2) + (p & 3) [+ 4 for y]
+        k.vop("v_add_u32_e32", ua, ua, lane)
+        k.vop("v_lshl_add_u32", ua, ua, 3, self.v_ulds)
+        k.ds_write(ua, u1, U_POINTS)
+        k.ds_write(ua, u2, U_POINTS + 32)
+        k.sop("s_mov_b64", EXEC, save)
+        k.emit("v_cmp_gt_u32_e32", [VCC], [15, lane], "valu", count="valu_int")
+        k.sop("s_and_saveexec_b64", save, VCC)
+        k.gload(u1, self.v_lane8, g.kernarg, ARG_OFF["prior_loc"])
+        k.vop("v_add_u32_e32", ua, self.v_ulds, self.v_lane8)
+        k.ds_write(ua, u1, U_LOC)
+        k.sop("s_mov_b64", EXEC, save)
+        k.free(save, ua, u1, u2, a_lc, a_y, pp, s_pair, a_stride)
+        more = k.sx(4)
+        k.s_load(more, g.kernarg, ARG_OFF["seed_lo"])             # seed_lo seed_hi chain_id_base pts_stride
+        assert ARG_OFF["prior_inv_scale"] == ARG_OFF["prior_loc"] + 40 and ARG_OFF["prior_shape_m1"] == ARG_OFF["prior_loc"] + 80
+        # lanes: c = chunk * 64 + lane < C
         k.sop("s_sub_u32", tmp, a_C, c0)
         k.cmp_u32("gt", VCC, tmp, lane)
         k.sop("s_and_b64", EXEC, EXEC, VCC)
-        k.vop("v_lshlrev_b32_e32", self.v_lane8, 3, lane)
         k.sop("s_add_u32", tmp, more.sub(2, 1), s_coff)           # chain_id_base + chain_offset[q] + chunk * 64 + lane
         k.sop("s_add_u32", tmp, tmp, c0)
         k.vop("v_add_u32_e32", self.v_cid, tmp, lane)
-        k.sop("s_mul_i32", tmp, s_wave, Lit(WAVE_LDS))
-        k.sop("s_add_u32", tmp, tmp, Lit(WAVE_BASE))
-        k.vop("v_add_u32_e32", self.v_lds, tmp, self.v_lane8)
-        k.free(lane, vt, s_wave, s_coff, chunk)
+        k.free(s_coff, chunk)
         # g0 = q * C + chunk * 64: first chain of this wavefront in the [.][Q * C] arrays
         k.sop("s_mul_i32", self.s_g0, q, a_C)
         k.sop("s_add_u32", self.s_g0, self.s_g0, c0)
         # nch8 = Q * C * 8 (64 bits)
+        a_np = k.s1()
+        k.s_load(a_np, g.kernarg, ARG_OFF["num_problems"])
         k.sop("s_mul_i32", self.s_nch8.lo(), a_np, a_C)
         k.sop("s_mul_hi_u32", self.s_nch8.hi(), a_np, a_C)
+        k.free(a_np)
         k.sop("s_lshl_b64", self.s_nch8, self.s_nch8, 3)
-        # rows: cursor = rows + ((q * 12) * C + chunk * 64) * 8; stride per saved row = 12 * nch8; flags: bit 0 rows, bit 1 moments
+        # rows: cursor = rows + ((q * 12) * C + chunk * 64) * 8 + (quantum * rows_per_quantum) * stride; stride per saved row = 12 * nch8
+        # flags: bit 0 rows, bit 1 moments
         t2 = k.sd()
-        a_rows, a_mom = ptr("rows"), ptr("moments")
+        a_rows, a_mom = self.ptr("rows"), self.ptr("moments")
         k.sop("s_cmp_lg_u64", None, a_rows, 0)
         k.sop("s_cselect_b32", self.s_flags, 1, 0)
         k.sop("s_cmp_lg_u64", None, a_mom, 0)
@@ -176,33 +324,30 @@ class Main(object):
         k.sop("s_mul_i32", self.s_rstride.lo(), self.s_nch8.lo(), D + 1)
         k.sop("s_mul_i32", self.s_rstride.hi(), self.s_nch8.hi(), D + 1)
         k.sop("s_add_u32", self.s_rstride.hi(), self.s_rstride.hi(), tmp)
+        k.sop("s_mul_hi_u32", t2.hi(), task, self.s_rstride.lo())  # + (rows saved by this block's earlier quanta) * stride
+        k.sop("s_mul_i32", t2.lo(), task, self.s_rstride.lo())
+        k.sop("s_mul_i32", tmp, task, self.s_rstride.hi())
+        k.sop("s_add_u32", t2.hi(), t2.hi(), tmp)
+        self.add64(self.s_rows, self.s_rows, t2)
         k.sop("s_lshl_b32", self.s_c8, a_C, 3)
-        # moments base = moments + g0 * 8; gamma; points of the pair
+        # moments base = moments + g0 * 8; state; gamma
         k.sop("s_mov_b32", t2.lo(), self.s_g0)
         k.sop("s_mov_b32", t2.hi(), 0)
         k.sop("s_lshl_b64", t2, t2, 3)
         self.add64(self.s_mom, a_mom, t2)
         k.free(a_rows, a_mom)
-        a_state = ptr("state")
+        a_state = self.ptr("state")
         s_state = k.sd()
         self.add64(s_state, a_state, t2)
         k.free(a_state)
         k.s_load(self.s_gamma, g.kernarg, ARG_OFF["gamma"])
-        a_lc, a_y = ptr("ln_conc"), ptr("response")
-        k.sop("s_mul_i32", t2.lo(), s_pair, more.sub(3, 1))
-        k.sop("s_mul_hi_u32", t2.hi(), s_pair, more.sub(3, 1))
-        k.sop("s_lshl_b64", t2, t2, 3)
-        self.add64(self.s_lc, a_lc, t2)
-        self.add64(self.s_yp, a_y, t2)
-        k.free(a_lc, a_y, s_pair, t2, q, c0)
+        k.free(t2, q, c0)
         # loop scalars
-        tb = k.sd()
-        k.s_load(tb, g.kernarg, ARG_OFF["t_begin"])               # t_begin t_end
         until0 = k.s1()
         k.s_load(until0, g.kernarg, ARG_OFF["until_save0"])
-        k.sop("s_add_u32", self.s_first, tb.lo(), 1)
-        k.sop("s_mov_b32", self.s_t, self.s_first)
-        k.sop("s_mov_b32", self.s_tend, tb.hi())
+        c4 = k.sx(4)
+        k.s_load(c4, g.kernarg, ARG_OFF["adapt_start"])           # adapt_start thinning moments_after chains
+        a_adapt, a_thin, a_mafter = (c4.sub(i, 1) for i in range(3))
         k.sop("s_mov_b32", self.s_adapt, a_adapt)
         k.sop("s_mov_b32", self.s_thin, a_thin)
         k.sop("s_mov_b32", self.s_mafter, a_mafter)
@@ -211,20 +356,43 @@ class Main(object):
         k.sop("s_mov_b32", self.s_seedhi, more.sub(1, 1))
         k.sop("s_mov_b64", self.s_acc, 0)
         k.s_waitcnt_all()
-        k.free(w4, c4, more, until0, tmp, tb)
-        # ---- the chain state: HBM -> registers / LDS ----
-        k.comment("---- state: HBM -> registers and this wavefront's LDS slots ----")
-        self.th = [k.vd() for _ in range(D)]
-        self.lt = k.vd()
-        self.y = [k.vd() for _ in range(D)]
-        self.Lreg = {}
-        for i in range(1, D):
-            for kc in range(i):
-                if (i, kc) not in LDS_L:
-                    self.Lreg[(i, kc)] = k.vd()
-        self.loga, self.nacc, self.sc, self.logu = k.vd(), k.vd(), k.vd(), k.vd()
+        k.free(c4, more, until0, tmp, task, a_C)
         self.walk_state(s_state, load=True)
         k.free(s_state)
+
+    def task_done(self):
+        """state back to HBM; queued: release, publish queue[1 + block] = quantum + 1, next task"""
+        k = self.k
+        k.comment("---- the block's state: registers and LDS slots -> HBM; hand the block over ----")
+        st, t2 = k.sd(), k.sd()
+        k.s_load(st, self.g.kernarg, ARG_OFF["state"])
+        k.sop("s_mov_b32", t2.lo(), self.s_g0)
+        k.sop("s_mov_b32", t2.hi(), 0)
+        k.sop("s_lshl_b64", t2, t2, 3)
+        self.add64(st, st, t2)
+        self.walk_state(st, load=False)
+        k.sop("s_cmp_eq_u64", None, self.s_queue, 0)
+        k.branch("s_cbranch_scc1", self.l_end)
+        k.sop("s_mov_b64", EXEC, -1)
+        k.s_waitcnt_all()
+        k.raw_rec("buffer_wbl2 sc1")
+        k.raw_rec("s_waitcnt vmcnt(0)")
+        k.sop("s_lshl_b32", t2.lo(), self.s_block, 2)
+        k.sop("s_mov_b32", t2.hi(), 0)
+        self.add64(t2, t2, self.s_queue)
+        v = k.v1()
+        tmp = k.s1()
+        k.sop("s_add_u32", tmp, self.s_quant, 1)
+        k.mov32(v, tmp)
+        save = k.sd()
+        k.emit("v_cmp_eq_u32_e32", [VCC], [0, self.v_lane], "valu", count="valu_int")
+        k.sop("s_and_saveexec_b64", save, VCC)
+        k.emit("global_store_dword", [], [self.v_zero, v, t2], "vmem", suffix="offset:4 sc1", mem="vm")
+        k.sop("s_mov_b64", EXEC, save)
+        k.free(st, t2, v, tmp, save)
+        k.branch("s_branch", self.l_task)
+        k.label(self.l_end)
+        k.endpgm()
 
     def state_rows(self):
         """(state row, kind, key) in ascending row order"""
@@ -360,27 +528,36 @@ class Main(object):
         k.free(P0, P1s, [list(p) for blk in sets for p in blk])
 
     # ------------------------------------------------------------------------------------------------------------ sweep
-    def sweep(self):
-        """the adaptation of iteration t - 1 (hier_advance_body: mean, loga, PHF_LDL_COLUMN column by column) fused with
-        y = L sqrt(d) z of iteration t's proposal; s_gs = gamma (0.0 where the C code does not adapt: an exact no-op)"""
-        k, c, m = self.k, self.c, self.m
-        k.comment("---- adaptation of t - 1 (rank-one update of L D L') + y = L sqrt(d) z for t ----")
-        # gamma: (t - 1 > adapt_start and t > first) ? gamma[t - 1 - adapt_start] : 0
-        self.s_gs = k.sd()
+    def load_gamma(self):
+        """v_gs <- (t - 1 > adapt_start and t > first) ? gamma[t - 1 - adapt_start] : 0, issued at the top of the loop: a vector-memory
+        load (its own counter: nothing else waits for it) that the draws cover"""
+        k = self.k
+        self.v_gs = k.vd()
         tmp = k.s1()
-        l_g0, l_gdone = k.new_label("g0"), k.new_label("gdone")
-        k.sop("s_mov_b64", self.s_gs, 0)
+        cur = k.sd()
+        l_gdone = k.new_label("gdone")
+        k.mov32(self.v_gs.lo(), 0)
+        k.mov32(self.v_gs.hi(), 0)
         k.sop("s_cmp_eq_u32", None, self.s_t, self.s_first)
         k.branch("s_cbranch_scc1", l_gdone)
         k.sop("s_sub_u32", tmp, self.s_t, 1)
         k.sop("s_cmp_le_u32", None, tmp, self.s_adapt)
         k.branch("s_cbranch_scc1", l_gdone)
         k.sop("s_sub_u32", tmp, tmp, self.s_adapt)
-        k.sop("s_lshl_b32", tmp, tmp, 3)
-        k.s_load(self.s_gs, self.s_gamma, tmp)
-        k.label(l_gdone)
-        k.free(tmp)
-        gs = self.s_gs
+        k.sop("s_lshl_b32", cur.lo(), tmp, 3)
+        k.sop("s_lshr_b32", cur.hi(), tmp, 29)
+        self.add64(cur, cur, self.s_gamma)
+        k.gload(self.v_gs, self.v_zero, cur)
+        k.label(l_gdone, drain=False)
+        k.free(tmp, cur)
+
+    def sweep(self):
+        """the adaptation of iteration t - 1 (hier_advance_body: mean, loga, PHF_LDL_COLUMN column by column) fused with
+        y = L sqrt(d) z of iteration t's proposal; v_gs = gamma (0.0 where the C code does not adapt: an exact no-op).
+        Column k runs as: [1 / dn chain | sqrt(dn) chain | w_i -= w_k L_ik] side by side, then [L_ik, y_i updates | head of column k + 1]."""
+        k, c, m = self.k, self.c, self.m
+        k.comment("---- adaptation of t - 1 (rank-one update of L D L') + y = L sqrt(d) z for t ----")
+        gs = self.v_gs
         omg, alpha = k.vd(), k.vd()
         k.add(omg, 1.0, Neg(gs))
         # w = theta - mean; mean <- g theta + (1 - g) mean
@@ -392,6 +569,15 @@ class Main(object):
         for kc in range(2):                                  # the first diagonals: in flight while the mean is updated
             dq[kc] = k.vd()
             self.lds_load(dq[kc], SLOT_D + kc)
+        lq = {}
+
+        def fetch_column(kc):
+            for i in range(kc + 1, D):
+                if (i, kc) in LDS_L:
+                    lq[(i, kc)] = k.vd()
+                    self.lds_load(lq[(i, kc)], self.l_slot(i, kc))
+
+        fetch_column(0)
         for i in range(D):
             k.sub(w[i], self.th[i], mt[i])
             k.mul(mt[i], omg, mt[i])
@@ -405,55 +591,62 @@ class Main(object):
         k.sub(a01, a01, c["QUARTER"])
         k.fma(self.loga, gs, a01, self.loga)
         k.free(a01)
-        k.mov32(alpha.lo(), gs.lo())
-        k.mov32(alpha.hi(), gs.hi())
+        k.mov64(alpha, gs)
+        k.free(gs)
         y = self.y
-        lq = {}
-
-        def fetch_column(kc):
-            for i in range(kc + 1, D):
-                if (i, kc) in LDS_L:
-                    lq[(i, kc)] = k.vd()
-                    self.lds_load(lq[(i, kc)], self.l_slot(i, kc))
-
-        fetch_column(0)
         pos = k.sd()
+
+        def head(kc):
+            """dk = (1 - g) d_k; ap = alpha w_k; dn = fma(ap, w_k, dk): what column kc's chains start from"""
+            h = {"dk": k.vd(), "ap": k.vd(), "dn": k.vd()}
+            k.mul(h["dk"], omg, dq[kc])
+            k.mul(h["ap"], alpha, w[kc])
+            k.fma(h["dn"], h["ap"], w[kc], h["dk"])
+            self.lds_store(SLOT_D + kc, h["dn"])
+            k.free(dq.pop(kc))
+            return h
+
+        hd = head(0)
         for kc in range(D):
             if kc + 2 < D:
                 dq[kc + 2] = k.vd()
                 self.lds_load(dq[kc + 2], SLOT_D + kc + 2)
             if kc + 1 < D:
                 fetch_column(kc + 1)
-            dk, ap, dn, inv, beta, sq = k.vd(), k.vd(), k.vd(), k.vd(), k.vd(), k.vd()
-            k.mul(dk, omg, dq[kc])
-            k.mul(ap, alpha, w[kc])
-            k.fma(dn, ap, w[kc], dk)
-            self.lds_store(SLOT_D + kc, dn)
-            k.free(dq.pop(kc))
-            # 1 / dn (or 0) and sqrt(dn) (or 0): two dependency chains side by side
+            dk, ap, dn = hd["dk"], hd["ap"], hd["dn"]
+            inv, beta, sq = k.vd(), k.vd(), k.vd()
+            lik = {i: (lq[(i, kc)] if (i, kc) in LDS_L else self.Lreg[(i, kc)]) for i in range(kc + 1, D)}
             with k.parallel() as par:
-                par.stream()
+                par.stream()                                 # 1 / dn (or 0), beta, the next alpha
                 M.rcp(m, [inv], [dn])
-                par.stream()
+                par.stream()                                 # sqrt(dn) (or 0), u_k = sqrt(dn) z_k
                 M.sqrt_nonneg(m, [sq], [dn], [pos])
+                k.mul(self.zn[kc], sq, self.zn[kc])
+                par.stream()                                 # w_i <- w_i - w_k L_ik: needs w_k only
+                for i in range(kc + 1, D):
+                    k.fma(w[i], Neg(w[kc]), lik[i], w[i])
             k.cnd64(inv, 0.0, inv, pos)
             k.mul(beta, ap, inv)
             k.mul(dk, alpha, dk)
             k.mul(dk, dk, inv)
             k.cnd64(alpha, alpha, dk, pos)
-            k.mul(self.zn[kc], sq, self.zn[kc])
-            for i in range(kc + 1, D):
-                lik = lq[(i, kc)] if (i, kc) in LDS_L else self.Lreg[(i, kc)]
-                k.fma(w[i], Neg(w[kc]), lik, w[i])
-                k.fma(lik, beta, w[i], lik)
-                if (i, kc) in LDS_L:
-                    self.lds_store(self.l_slot(i, kc), lik)
-                k.fma(y[i], lik, self.zn[kc], 0.0 if kc == 0 else y[i])
-                if (i, kc) in LDS_L:
-                    k.free(lq.pop((i, kc)))
-            k.add(y[kc], 0.0 if kc == 0 else y[kc], self.zn[kc])
-            k.free(dk, ap, dn, inv, beta, sq)
-        k.free(pos, omg, alpha, w, self.zn, self.s_gs)
+            k.free(dk, ap, dn, inv, sq)
+            with k.parallel() as par:
+                par.stream()                                 # L_ik <- L_ik + beta w_i; y_i += L_ik u_k
+                for i in range(kc + 1, D):
+                    k.fma(lik[i], beta, w[i], lik[i])
+                for i in range(kc + 1, D):
+                    if (i, kc) in LDS_L:
+                        self.lds_store(self.l_slot(i, kc), lik[i])
+                    k.fma(y[i], lik[i], self.zn[kc], 0.0 if kc == 0 else y[i])
+                    if (i, kc) in LDS_L:
+                        k.free(lq.pop((i, kc)))
+                k.add(y[kc], 0.0 if kc == 0 else y[kc], self.zn[kc])
+                if kc + 1 < D:
+                    par.stream()                             # the head of the next column (alpha and w_{k+1} are final)
+                    hd = head(kc + 1)
+            k.free(beta)
+        k.free(pos, omg, alpha, w, self.zn)
         # the scale of the next proposal: e^(loga / 2)
         h = k.vd()
         k.mul(h, self.loga, 0.5)
@@ -515,14 +708,11 @@ class Main(object):
         k.comment("---- target of the proposal: support, the 12 + 4 logarithms, the 12 points ----")
         # support (phf_hier_out_of_support) and xl = hv - loc
         s_bad = k.sd()
-        pa, pb = k.sx(8), k.sd()
-
-        def prior(name):
-            k.s_load(pa, self.g.kernarg, ARG_OFF[name])
-            k.s_load(pb, self.g.kernarg, ARG_OFF[name] + 32)
-            return [pa.sub(2 * j) for j in range(4)] + [pb]
-
-        loc = prior("prior_loc")
+        # the prior's 15 doubles (loc, 1 / scale, shape - 1) -> registers, all in flight before the first use: seven 16-byte reads, one 8-byte
+        pq = [self.uload(k.vq(), U_LOC + 16 * n) for n in range(7)] + [self.uload(k.vd(), U_LOC + 112)]
+        pd = [pq[n // 2].sub(2 * (n % 2)) if n < 14 else pq[7] for n in range(15)]
+        loc, isc, sm1 = pd[0:5], pd[5:10], pd[10:15]
+        f_loc, f_isc, f_sm1 = pq[0:2], pq[2:5], pq[5:8]
         hv = [alpha, beta, mu, s_, sigma]
         for j in range(5):
             k.cmp("le", VCC, hv[j], loc[j])
@@ -543,7 +733,7 @@ class Main(object):
         k.mul(inv_s, inv, s_)
         k.free(pre, inv)
         # lin0 = sum_k -xl_k / scale_k  (half 0);  z_i, lin1 (half 1)
-        isc = prior("prior_inv_scale")
+        k.free(f_loc)
         lin0, lin1 = k.vd(), k.vd()
         for j in range(5):
             k.fma(lin0, Neg(xl[j]), isc[j], 0.0 if j == 0 else lin0)
@@ -555,7 +745,7 @@ class Main(object):
             k.sub(lin1, 0.0 if i == 0 else lin1, z[i])
         k.free(inv_sc)
         # weights that are computed: -Ne beta, beta - 1
-        sm1 = prior("prior_shape_m1")
+        k.free(f_isc)
         three, twelve = k.sd(), k.sd()                       # (double)Ne and (double)n_pts: literals (their low words are zero)
         for r, hi in ((three, 0x40080000), (twelve, 0x40280000)):
             k.sop("s_mov_b32", r.lo(), 0)
@@ -566,7 +756,8 @@ class Main(object):
         # half 0: ln alpha, ln Hill_1..3, ln beta, ln(alpha - loc0)
         part0, part1 = k.vd(), k.vd()
         lg0 = [k.vd() for _ in range(4)]
-        M.log_fast(m, lg0, [alpha] + hill)
+        M.log_fast(m, lg0[:2], [alpha, hill[0]])
+        M.log_fast(m, lg0[2:], hill[1:])
         k.fma(part0, wnb, lg0[0], 0.0)
         for i in range(NE):
             k.fma(part0, wb1, lg0[1 + i], part0)
@@ -577,13 +768,14 @@ class Main(object):
         k.fma(part0, sm1[0], t2[1], part0)
         # half 1: ln(beta - loc1), ln(mu - loc2), ln(s - loc3), ln(sigma - loc4), ln s, ln sigma
         t4 = [k.vd() for _ in range(2)]
-        M.log_fast(m, t2 + t4, [xl[1], xl[2], xl[3], xl[4]])
+        M.log_fast(m, t2, [xl[1], xl[2]])
+        M.log_fast(m, t4, [xl[3], xl[4]])
         for j, r in enumerate(t2 + t4):
             k.fma(part1, sm1[1 + j], r, 0.0 if j == 0 else part1)
         M.log_fast(m, t2, [s_, sigma])
         k.fma(part1, Neg(three), t2[0], part1)
         k.fma(part1, Neg(twelve), t2[1], part1)
-        k.free(t4, xl, pa, pb, three, twelve)
+        k.free(t4, xl, f_sm1, three, twelve)
         # la0_i = 1 + (Hill_i / alpha)^beta = 1 + exp(beta (ln Hill_i - ln alpha));  la1_i = 1 + exp(-z_i)
         la0, la1 = [k.vd() for _ in range(NE)], [k.vd() for _ in range(NE)]
         ea = [k.vd() for _ in range(NE)]
@@ -637,11 +829,15 @@ class Main(object):
         k.free(vlog, prod)
         # the points: experiment i's four points, two for each half (:117-125)
         sse, mass = [k.vd(), k.vd()], [k.vd(), k.vd()]
-        pts = k.sx(8)
         for i in range(NE):
-            k.s_load(pts, self.s_lc, 32 * i)                      # ln conc of points 4 i .. 4 i + 3
-            lcs = [pts.sub(2 * j) for j in range(4)]
-            ys = lcs                                              # ... then, in the same registers, their responses
+            pl = [k.vq(), k.vq()]                                 # ln conc of points 4 i .. 4 i + 3
+            py = [k.vq(), k.vq()]                                 # their responses (used some fifty instructions further down)
+            for j in range(2):
+                self.uload(pl[j], U_POINTS + 64 * i + 16 * j)
+            for j in range(2):
+                self.uload(py[j], U_POINTS + 64 * i + 32 + 16 * j)
+            lcs = [pl[j // 2].sub(2 * (j % 2)) for j in range(4)]
+            ys = [py[j // 2].sub(2 * (j % 2)) for j in range(4)]
             lnic = k.vd()
             k.sub(lnic, c["P6"], pic[i])
             k.mul(lnic, c["LN10"], lnic)
@@ -651,8 +847,7 @@ class Main(object):
                 k.sub(x[j], lcs[j], lnic)
                 k.mul(x[j], hill[i], x[j])
                 k.fmin(x[j], x[j], c["P40"])
-            k.free(lnic)
-            k.s_load(pts, self.s_yp, 32 * i)
+            k.free(lnic, pl)
             M.exp_capped(m, d, x)
             for j in range(4):
                 k.add(d[j], d[j], 1.0)
@@ -674,7 +869,7 @@ class Main(object):
             for h in range(2):
                 k.fma(sse[h], tt[2 * h], tt[2 * h], 0.0 if i == 0 else sse[h])
                 k.fma(sse[h], tt[2 * h + 1], tt[2 * h + 1], sse[h])
-            k.free(tt, inv)
+            k.free(tt, inv, py)
             # truncation masses (phf_trunc_mass_x2, upper tails skipped unless some lane needs one), a pair of points at a time
             for h in range(2):
                 p0, p1 = pred[2 * h], pred[2 * h + 1]
@@ -711,7 +906,6 @@ class Main(object):
                 else:
                     k.mul(mass[h], mass[h], tl[0])
             k.free(pred)
-        k.free(pts)
         # halves: part_h - fma(sse_h, (0.5 inv_s) inv_s, ln mass_h), -inf if the mass underflowed; sum; -inf outside the support
         hs = k.vd()
         k.mul(hs, inv_s, 0.5)
@@ -733,13 +927,12 @@ class Main(object):
     # ------------------------------------------------------------------------------------------------------------ the kernel
     def build(self):
         k, c = self.k, self.c
-        self.prologue()
-        self.v_zero, self.v_infhi = k.v1(), k.v1()
-        k.mov32(self.v_zero, 0)
-        k.mov32(self.v_infhi, Lit(0x7ff00000))
+        self.prologue_once()
+        self.next_task()
         k.count_marker("prologue")
         l_loop, l_exit = k.new_label("loop"), k.new_label("exit")
         k.label(l_loop)
+        self.load_gamma()
         self.draws()
         k.count_marker("draws")
         self.sweep()
@@ -771,18 +964,7 @@ class Main(object):
         k.count_marker("accept")
         k.branch("s_branch", l_loop)
         k.label(l_exit)
-        # ---- epilogue: state back to HBM ----
-        k.comment("---- epilogue: registers and LDS slots -> state ----")
-        st = k.sd()
-        t2 = k.sd()
-        k.s_load(st, self.g.kernarg, ARG_OFF["state"])
-        k.sop("s_mov_b32", t2.lo(), self.s_g0)
-        k.sop("s_mov_b32", t2.hi(), 0)
-        k.sop("s_lshl_b64", t2, t2, 3)
-        self.add64(st, st, t2)
-        self.walk_state(st, load=False)
-        k.label(self.l_end)
-        k.endpgm()
+        self.task_done()
         lines_meta = k.finish(LDS_BYTES, ARG_BYTES)
         snaps = k.snapshots
         order = ["prologue", "draws", "sweep", "save", "target", "accept"]

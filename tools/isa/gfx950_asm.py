@@ -489,13 +489,20 @@ class Kernel(object):
         self.emit(opc, [d], [sbase, off], "smem", mem="smem")
         return d
 
+    def raw_rec(self, text):
+        """an instruction the builder knows nothing about (no register operands: s_sleep, buffer_inv, buffer_wbl2, s_waitcnt ...)"""
+        self._rec({"kind": "rawinst", "text": text})
+
     def s_waitcnt_all(self):
         self._rec({"kind": "waitall"})
 
     # ---- control flow ----
-    def label(self, name):
+    def label(self, name, drain=True):
+        """drain=False: loads in flight stay in flight across the label — only where every path into the label has issued the same
+        loads or none that the code behind it touches without a wait of its own (the tracker keeps its queue: a load issued on one
+        path only is waited for on both, which is safe: s_waitcnt on a counter that is already low does not block)"""
         assert self._streams is None
-        self._rec({"kind": "label", "name": name})
+        self._rec({"kind": "label", "name": name, "drain": drain})
 
     def branch(self, opc, target):
         """s_branch / s_cbranch_scc0 / scc1 / vccz / vccnz / execz / execnz"""
@@ -521,7 +528,8 @@ class Kernel(object):
             if kd == "comment":
                 self.lines.append("\t; " + r["text"])
             elif kd == "label":
-                self.drain()
+                if r.get("drain", True):
+                    self.drain()
                 self.lines.append(r["name"] + ":")
                 self.hist = [{"kind": "unknown", "vw": set(), "sw": set()}]
             elif kd == "branch":
@@ -538,6 +546,9 @@ class Kernel(object):
                 self.lgkm, self.vm = [], []
             elif kd == "endpgm":
                 self.raw("s_endpgm")
+            elif kd == "rawinst":
+                self.raw(r["text"])
+                self._hist_push({"kind": "salu", "vw": set(), "sw": set()})
             elif kd == "marker":
                 self.snapshots[r["name"]] = dict(self.counts)
             else:

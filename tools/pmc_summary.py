@@ -10,7 +10,7 @@ for d in sys.argv[1:]:
                 k = "mh_advance_kernel" + k.split("mh_advance_kernel")[1][:3] if "mh_advance_kernel" in k else k[:60]
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in acc.items():
-    if "mh_advance" not in k and "hier" not in k and "pred_" not in k:
+    if "mh_advance" not in k and "hier" not in k and "pred_" not in k and "phf_" not in k:
         continue
     print(k)
     for c, v in sorted(cs.items()):
