@@ -41,13 +41,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROAR
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 64 fp64 FMA lanes x 2 x 2.4 GHz (vector, non-MFMA)
 FP64_VALU_MEASURED_TFLOPS = 58.3  # tools/microbench.hip: v_fma_f64 saturates at 2.25 ns per wave-instruction per SIMD
 
-DEFAULT_CHAINS = {"c2": 65536, "c3": 4096, "c4": 1024, "c5": 1024}
+DEFAULT_CHAINS = {"c2": 65536, "c3": 4096, "c4": 1024, "c5": 1024, "s3": 1024}
+# s3: SURVEY 8(d)'s synthetic scaling set (pyhillfit_amd/synthetic.py): P generated pairs, model 2; N > 1 splits ONE 1 680 x 4 096 batch
+S3_PAIRS, S3_STRONG_CHAINS = 1680, 4096
 # c3: 24 000 iterations per step = one queued launch of ~0.3 s (6 quanta of 4 000), so that the driver's 20 timed steps last > 6 s;
 # c4: 2 000 per step — the command line runs 20 000 per launch, and at 500 a third of the HBM traffic was the state going in and out
-DEFAULT_ITERS = {"c2": 2000, "c3": 24000, "c4": 2000, "c5": 500}
+DEFAULT_ITERS = {"c2": 2000, "c3": 24000, "c4": 2000, "c5": 500, "s3": 4000}
 # (timed steps, warm-up steps) of the short regions after the headline; each region lasts 0.1 .. 0.5 s
-OTHER_STEPS = {"c2": (40, 10), "c4": (8, 3), "c5": (8, 4), "c5_moments": (8, 4), "c3_model1": (3, 2)}
-OTHER_SPECS = {"c2": ("c2", 2, False), "c4": ("c4", 2, False), "c5": ("c5", 2, False),          # name -> (workload, model, moments)
+# (steps, warm-up) of the short regions: every one of them at least half a second of timed work (c2 2.3 ms, c4 ~48, c5 ~50, s3 ~100,
+# c3 model 1 ~270 ms per step)
+OTHER_STEPS = {"c2": (250, 10), "c4": (12, 3), "c5": (12, 4), "c5_moments": (12, 4), "c3_model1": (3, 2), "s3": (6, 2)}
+OTHER_SPECS = {"c2": ("c2", 2, False), "c4": ("c4", 2, False), "c5": ("c5", 2, False), "s3": ("s3", 2, False),          # name -> (workload, model, moments)
                "c5_moments": ("c5", 2, True), "c3_model1": ("c3", 1, False)}
 
 
@@ -133,7 +137,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10, help="untimed steps before the timed ones (the first launches of a process run ~10 %% slow while the clocks settle)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "s3"])
+    ap.add_argument("--pairs", type=int, default=None, help="s3: number of generated pairs (default %d; SURVEY 8(d): 210 or 1 680)" % S3_PAIRS)
     ap.add_argument("--iters-per-step", type=int, default=None, help="MH iterations per step (default: 8000 c3, 2000 c2, 500 c4/c5)")
     ap.add_argument("--chains", type=int, default=None, help="chains per problem (default: 65536 c2, 4096 c3, 1024 c4/c5)")
     ap.add_argument("--thinning", type=int, default=5)
@@ -305,6 +310,9 @@ def workload_label(workload, n_pairs, C, per, model=2):
         return "Amiodarone-hERG, non-hierarchical %s, %d chains %s (BASELINE configs[1])" % (m, C, per)
     if workload == "c3":
         return "all %d Crumb drug x channel pairs, non-hierarchical %s, %d chains each %s (BASELINE configs[2])" % (n_pairs, m, C, per)
+    if workload == "s3":
+        return ("synthetic scaling set S3 (SURVEY 8d; pyhillfit_amd/synthetic.py, seed 12345): %d generated pairs of 3 x 4 points, non-hierarchical %s, "
+                "%d chains each %s" % (n_pairs, m, C, per))
     if workload == "c5":
         return "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains %s, %s (BASELINE configs[4])" % (n_pairs, C, per, m)
     return ("hierarchical model, all %d Crumb pairs, %d chains each %s (BASELINE configs[3]); one stream per Ne group, "
@@ -318,6 +326,8 @@ def make_batch(workload, scaling, C, a, ctx):
     dr, D, torch, dev, rank, world = ctx["dr"], ctx["D"], ctx["torch"], ctx["dev"], ctx["rank"], ctx["world"]
     all_names = [(d, c) for d in dr.drugs for c in dr.channels]
     names = [("Amiodarone", "hERG")] if workload == "c2" else all_names
+    if workload == "s3":
+        names = [("synthetic", str(p)) for p in range(a.pairs or S3_PAIRS)]
     strong = scaling == "strong" and world > 1
     chain_id_base = 0 if scaling == "strong" else rank * C
     if workload == "c4":
@@ -329,7 +339,11 @@ def make_batch(workload, scaling, C, a, ctx):
             units = D.shard_blocks(costs, C // 64, world)[rank]
         b = HierarchicalBatch(dr, names, C, a.thinning, chain_id_base, dev, torch, units=units)
     else:
-        packed = dr.pack_single_level(names) if rank == 0 or ctx["backend_is_local"] else None
+        if workload == "s3":                                          # generated, deterministic: rank 0 makes it, the others get it by broadcast
+            from pyhillfit_amd import synthetic
+            packed = dr.PackedPoints(synthetic.single_level_pairs(synthetic.generate(len(names))[0])) if rank == 0 or ctx["backend_is_local"] else None
+        else:
+            packed = dr.pack_single_level(names) if rank == 0 or ctx["backend_is_local"] else None
         packed = D.broadcast_packed_points(packed, dev)               # RCCL: "scatter the dataset", a few tens of KB
         if workload == "c5":
             ladder = dr.temperature_ladder(31)                        # 32 rungs (BASELINE configs[4]); reference ladder has 41
@@ -482,7 +496,9 @@ def main():
         out = {
             "metric": "MCMC samples/sec (whole node)", "value": chains_total * I * a.steps / dt, "unit": "MH samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "real Crumb dose-response rows (data/crumb_dataset.json), synthetic chain batch",
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": ("synthetic dose-response rows (SURVEY 8d S3, pyhillfit_amd/synthetic.py), synthetic chain batch" if a.workload == "s3"
+                     else "real Crumb dose-response rows (data/crumb_dataset.json), synthetic chain batch"),
             "config": {"workload": b.label, "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": b.chains,
                        "chains_all_gpus": chains_total,
                        "adaptation": "on (steps start after iteration %d > adapt_start %d)" % (a.warmup * I, b.adapt_start),
@@ -497,12 +513,18 @@ def main():
     # (pair, 64-chain block) units.  (N = 1: the two coincide.) ----
     if world > 1 and not a.single_region:
         other = "strong" if a.scaling == "weak" else "weak"
-        b2 = make_batch(a.workload, other, C, a, ctx)
-        dt2, kms2, chains2 = timed_region(b2, I, a.steps, a.warmup, ctx)
+        w2, C2, I2 = a.workload, C, I
+        if other == "strong" and a.workload == "c3" and a.chains is None:
+            # the strong-scaling batch is SURVEY 8(d)'s S3: ONE batch of 1 680 generated pairs x 4 096 chains = 107 520 blocks of 64 chains,
+            # 13 440 per GPU at 8 — the Crumb batch's 13 440 blocks leave 1 680 per GPU there, one ragged round of the chip's 2 048 slots
+            w2, C2, I2 = "s3", S3_STRONG_CHAINS, DEFAULT_ITERS["s3"]
+        b2 = make_batch(w2, other, C2, a, ctx)
+        dt2, kms2, chains2 = timed_region(b2, I2, a.steps, a.warmup, ctx)
+        I_other = I2
         if rank == 0:
-            out[other + "_value"] = chains2 * I * a.steps / dt2
+            out[other + "_value"] = chains2 * I_other * a.steps / dt2
             out[other + "_region"] = {"scaling": other, "ms_per_step": dt2 / a.steps * 1e3, "kernel_ms_rank0": kms2, "chains_all_gpus": chains2,
-                                      "chains_rank0": b2.chains, "workload": b2.label}
+                                      "chains_rank0": b2.chains, "workload": b2.label, "iterations_per_step": I_other}
         del b2
         release(torch)
 
@@ -510,7 +532,7 @@ def main():
     if world == 1 and a.workload == "c3" and a.chains is None and a.iters_per_step is None and not a.no_other_workloads \
             and a.model == 2 and not a.moments:
         others = {}
-        for name in ("c2", "c4", "c5", "c5_moments", "c3_model1"):
+        for name in ("c2", "c4", "c5", "c5_moments", "c3_model1", "s3"):
             w, model_w, moments_w = OTHER_SPECS[name]
             aw = argparse.Namespace(**vars(a))
             aw.model, aw.moments = model_w, moments_w

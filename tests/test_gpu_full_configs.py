@@ -389,3 +389,34 @@ def test_c5_full_ladder_all_pairs(gpu, dr):
     assert bad.mean() <= 0.002, (bad.sum(), np.argwhere(bad)[:5])
     acc = s.acceptance().view(P, R, C).mean(dim=2).cpu().numpy()
     assert 0.1 < acc.min() and acc.max() < 0.6, (acc.min(), acc.max())
+
+
+def test_synthetic_s3_sampled_rows_recomputed_by_the_numpy_oracle(gpu):
+    """SURVEY 8(d)'s synthetic scaling set (pyhillfit_amd/synthetic.py; bench.py --workload s3): 1 680 generated pairs x 64 chains,
+    model 2: sampled rows' log-targets recomputed by the independent numpy oracle, the censoring rate of the generated responses, and
+    chains that move"""
+    from oracle import pyhillfit_oracle as orc
+    from pyhillfit_amd import doseresponse as d
+    from pyhillfit_amd import synthetic as S
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    ex, truth = S.generate(1680)
+    assert 0.21 < S.censoring_rate(ex) < 0.26
+    pairs = S.single_level_pairs(ex)
+    packed = d.PackedPoints(pairs)
+    s = SingleLevelSampler(packed, 2, list(range(1680)), [1.0] * 1680, 64, thinning=5, seed=12, adapt_start=300, device=gpu)
+    s.init([6.0, 0.8, 8.0], cov_identity=False, cov_scale=0.05)
+    rows = s.advance(1500).cpu().numpy()
+    assert np.isfinite(rows).all()
+    rng = np.random.default_rng(2)
+    worst = 0.0
+    for q in rng.choice(1680, 300, replace=False):
+        concs, y = pairs[q]
+        pair = orc.PairData(concs, y, ex[q])
+        for r, c in zip(rng.integers(0, rows.shape[0], 3), rng.integers(0, 64, 3)):
+            th, got = rows[r, q, :3, c], rows[r, q, 3, c]
+            worst = max(worst, abs(got - orc.log_target(2, pair, th, 1.0)) / (abs(orc.log_target(2, pair, th, 1.0)) + 1.0))
+    assert worst <= 1e-12, worst
+    assert (np.abs(np.diff(rows[:, :, 0, :], axis=0)) > 0).mean() > 0.1
+    # the chains find the generating parameters: pooled pIC50 of the last rows within a few posterior widths of the truth for most pairs
+    est = rows[-100:, :, 0, :].mean(axis=(0, 2))
+    assert np.median(np.abs(est - truth["pic50"])) < 0.15
