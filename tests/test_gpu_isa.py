@@ -84,7 +84,7 @@ THETA0 = [np.concatenate([[1., 5., 6., .3], np.tile([6.0, 0.8], 3), [8.0]]), np.
 UNIFORM4 = [("Amiodarone", "hERG"), ("Amitriptyline", "Cav1.2"), ("Azithromycin", "Nav1.5-late")]
 
 
-@pytest.mark.parametrize("C,thin,cuts", [(256, 5, (137, 9, 454)), (70, 1, (100, 201)), (1024, 5, (600,))])
+@pytest.mark.parametrize("C,thin,cuts", [(256, 5, (137, 9, 454)), (70, 1, (100, 201)), (1024, 5, (600,)), (64, 5, (150, 100))])
 def test_isa_advance_bit_identical_to_the_hipcc_kernel(C, thin, cuts, gpu, oracle_pair):
     """same launches through kernel_hint bit 4 (hipcc one-lane kernel) and without it (phf_hier3_advance): rows, final state and
     moments must agree bit for bit — launches cut before, at and after the start of the adaptation, a ragged last wavefront

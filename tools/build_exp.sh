@@ -10,6 +10,6 @@ sed -e "s#\"../../include/pyhillfit_amd.h\"#\"$R/include/pyhillfit_amd.h\"#" $sr
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-pass-failed \
   -I$R/pyhillfit_amd/csrc "$@" -c -o $out/exp_$name.o $out/tmp_$name.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libexp_$name.so $R/pyhillfit_amd/lib/obj/phf_capi.o \
-  $R/pyhillfit_amd/lib/obj/phf_single_level.o $out/exp_$name.o $R/pyhillfit_amd/lib/obj/phf_predictive.o
+  $R/pyhillfit_amd/lib/obj/phf_single_level.o $out/exp_$name.o $R/pyhillfit_amd/lib/obj/phf_predictive.o $R/pyhillfit_amd/lib/obj/phf_hier3_isa.o
 rm -f $out/tmp_$name.hip
 echo built $out/libexp_$name.so
