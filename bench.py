@@ -157,7 +157,9 @@ def spawn_ranks(a):
     process; it is a child process, not an exec) and hand back its exit code."""
     from pyhillfit_amd import distributed as D
     backend = os.environ.get("PHF_BENCH_BACKEND", "nccl")
-    have = D.visible_gpu_count()              # from the driver's topology files: the HIP runtime stays untouched in this process
+    # the count comes from the driver's topology files (a child interpreter only where they are unreadable): the HIP runtime stays
+    # untouched in this process; the gloo rehearsal (several ranks on one GPU) does not need it at all
+    have = D.visible_gpu_count() if backend == "nccl" else a.gpus
     if backend == "nccl" and have < a.gpus:
         sys.stderr.write("bench.py: --gpus %d asked for but %d GPU(s) visible (RCCL needs one GPU per rank; "
                          "PHF_BENCH_BACKEND=gloo rehearses several ranks on one GPU)\n" % (a.gpus, have))

@@ -19,8 +19,10 @@
  *     without return) and the queued launch hands a block's state over with agent-scope release/acquire — on fine-grained, managed
  *     or host-pinned memory neither is guaranteed to take effect.  The advance calls CHECK these three (hipPointerGetAttributes:
  *     host, managed and fine-grained allocations are refused with PHF_ERR_INVALID_ARGUMENT; an address the runtime cannot classify
- *     passes).  rows and sums are written with plain stores and read by nobody inside a launch: any device-accessible memory works,
- *     and they are not checked.
+ *     passes; the verdicts of the calling thread's last 8 (address, device) pairs are remembered and forgotten at every *_init, so a
+ *     buffer re-allocated as another kind at the same address must not be swapped in between two advances of ONE sampler).  rows
+ *     and sums are written with plain stores and read by nobody inside a launch: any device-accessible memory works, and they are
+ *     not checked.
  */
 #ifndef PYHILLFIT_AMD_H
 #define PYHILLFIT_AMD_H

@@ -30,16 +30,32 @@ inline int phf_check_launch(const char* what) {
 // silently wrong sums (include/pyhillfit_amd.h, "MEMORY KIND").  NULL passes: optional buffers are checked for NULL by their
 // callers.  What the runtime cannot classify at all (hipPointerGetAttributes fails: e.g. a range mapped through the
 // virtual-memory API) passes too — nothing is known against it, and the header says so.
-// The verdict of the last few distinct addresses is remembered (a steady-state launch loop passes the same three buffers every
-// time: one runtime query per buffer, not per launch); an address is forgotten when it falls out of that window, so a buffer freed
-// and re-allocated as another kind at the same address is re-examined unless it comes back within the next few calls.
+// The verdict of the last few distinct (address, device) pairs is remembered (a steady-state launch loop passes the same three buffers
+// every time: one runtime query per buffer, not per launch).  An entry is forgotten when it falls out of that window of 8, when
+// phf_forget_device_memory_verdicts() is called (the *_init entry points call it: a new sampler starts from a clean slate, so a
+// buffer freed and re-allocated as another kind at the same address between two samplers is always re-examined), and the cache is
+// per thread.  What remains: a caller that frees a state / moments buffer and re-allocates it as managed or fine-grained memory at
+// the same address WITHIN one sampler's launch loop, inside the next 8 checks — such a caller must call an *_init in between
+// (include/pyhillfit_amd.h, "MEMORY KIND").
+struct phf_memory_verdicts {
+  static constexpr int kRemembered = 8;
+  const void* ptr[kRemembered] = {};
+  int dev[kRemembered] = {};
+  int next = 0;
+};
+inline phf_memory_verdicts& phf_memory_verdict_cache() {
+  static thread_local phf_memory_verdicts c;
+  return c;
+}
+inline void phf_forget_device_memory_verdicts() { phf_memory_verdict_cache() = phf_memory_verdicts(); }
+
 inline int phf_require_device_memory(const void* p, const char* what) {
   if (!p) return PHF_OK;
-  constexpr int kRemembered = 8;
-  static thread_local const void* ok_ptr[kRemembered] = {};
-  static thread_local int next = 0;
-  for (int i = 0; i < kRemembered; ++i)
-    if (ok_ptr[i] == p) return PHF_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+  phf_memory_verdicts& c = phf_memory_verdict_cache();
+  for (int i = 0; i < phf_memory_verdicts::kRemembered; ++i)
+    if (c.ptr[i] == p && c.dev[i] == dev) return PHF_OK;
   hipPointerAttribute_t attr;
   if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
     (void)hipGetLastError();
@@ -52,8 +68,9 @@ inline int phf_require_device_memory(const void* p, const char* what) {
                   "fp64 atomics and release/acquire hand-overs are not guaranteed there", what);
     return PHF_ERR_INVALID_ARGUMENT;
   }
-  ok_ptr[next] = p;
-  next = (next + 1) % kRemembered;
+  c.ptr[c.next] = p;
+  c.dev[c.next] = dev;
+  c.next = (c.next + 1) % phf_memory_verdicts::kRemembered;
   return PHF_OK;
 }
 

@@ -1189,6 +1189,7 @@ int phf_hierarchical_init(const phf_hier_points* pts, const phf_problems* prob, 
   if (!prob) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null problems");
   if (int rc = check(pts, prob, prior)) return rc;
   if (!theta0 || !state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null theta0/state");
+  phf_forget_device_memory_verdicts();              // a new sampler: every buffer's kind is asked of the runtime again (phf_common.h)
   HierArgs a{};
   a.pts = *pts; a.prob = *prob; a.prior = *prior; a.state = state; a.cov_scale = cov_scale; a.theta0 = theta0; a.row0 = row0;
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;

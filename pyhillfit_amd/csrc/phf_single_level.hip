@@ -504,6 +504,7 @@ int phf_single_level_init(const phf_points* pts, const phf_problems* prob, int m
                           double cov_scale, const double* theta0, double* state, double* row0, void* stream) {
   if (int rc = check_common(pts, prob, model)) return rc;
   if (!theta0 || !state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null theta0/state");
+  phf_forget_device_memory_verdicts();              // a new sampler: every buffer's kind is asked of the runtime again (phf_common.h)
   InitArgs a{*pts, *prob, cov_identity, cov_scale, theta0, state, row0, 0};
   a.blocks_per_problem = (prob->chains_per_problem + kBlock - 1) / kBlock;
   const dim3 grid((unsigned)(a.blocks_per_problem * prob->num_problems)), block(kBlock);

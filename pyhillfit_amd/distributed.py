@@ -44,21 +44,23 @@ def _gpu_count_from_driver_topology():
 
 def visible_gpu_count():
     """GPUs this process (and the ranks it starts) can use, WITHOUT touching the HIP runtime in THIS process (ADVICE r03:
-    torch.cuda.device_count() may initialise it when amdsmi is absent, and the process then holds it while its ranks run).  The
-    runtime's own answer is asked of a short-lived CHILD interpreter — exact whatever restricts visibility —; if that fails, the
-    driver's topology files are read; torch in this process is the last resort (tolerable only because ranks are started as a child
-    process, never by an exec)."""
+    torch.cuda.device_count() may initialise it when amdsmi is absent, and the process then holds it while its ranks run).
+    First the driver's topology files (/sys/class/kfd: no HIP call, milliseconds — a `-c N` start costs 3 s in all); only where they
+    are unreadable is the runtime's own answer asked of a short-lived CHILD interpreter (seconds: it imports torch); torch in this
+    process is the last resort (tolerable only because ranks are started as a child process, never by an exec).  PHF_GPU_COUNT_FROM=
+    child forces the child's answer (exact whatever restricts visibility, e.g. device-node permissions the topology does not show)."""
     import subprocess
     import sys
+    if os.environ.get("PHF_GPU_COUNT_FROM") != "child":
+        n = _gpu_count_from_driver_topology()
+        if n is not None:
+            return n
     try:
         out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=180)
         if out.returncode == 0:
             return int(out.stdout.strip().splitlines()[-1])
     except (OSError, ValueError, IndexError, subprocess.SubprocessError):
         pass
-    n = _gpu_count_from_driver_topology()
-    if n is not None:
-        return n
     import torch
     return torch.cuda.device_count()
 

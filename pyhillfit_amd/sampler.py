@@ -290,9 +290,19 @@ class SingleLevelSampler(object):
         """checkpoint: everything needed to continue bit-identically"""
         self.check_queue()
         return {"state": self.state.clone(), "t": self.t, "moments": None if self.moments is None else self.moments.clone(),
-                "moments_after": self.moments_after, "seed": self.seed}
+                "moments_after": self.moments_after, "seed": self.seed,
+                # what "continue bit-identically" depends on besides the state: the generator's rounds (7 since ABI 5, 10 before or with
+                # -DPHF_PHILOX_ROUNDS=10) and the ABI the state's layout belongs to
+                "philox_rounds": int(self.lib.phf_philox_rounds()), "abi_version": int(self.lib.phf_version())}
 
     def load_state_dict(self, sd):
+        """refuses a checkpoint taken with another generator or ABI (it would continue on another random stream, silently);
+        checkpoints from before these fields existed (rounds 1-4) are refused too: their generator is not known"""
+        have = (int(self.lib.phf_philox_rounds()), int(self.lib.phf_version()))
+        got = (sd.get("philox_rounds"), sd.get("abi_version"))
+        if got != have:
+            raise _lib.PhfError("checkpoint was taken with Philox rounds / ABI %s, this library has %s: the chains would not continue "
+                                "bit-identically" % (got, have))
         self.state.copy_(sd["state"]); self.t = int(sd["t"]); self.seed = int(sd["seed"])
         if sd.get("moments") is not None:
             self.moments = sd["moments"].clone().to(self.device); self.moments_after = int(sd["moments_after"])

@@ -80,7 +80,9 @@ def reference_posteriors(model, temperature=1.0):
     reseeded = []
     # G5d: the closed list of cases with 96 reference seeds each; G5e (round 4): the posterior-width follow-up, 32 seeds for each of the
     # twelve (pair, model) cases whose sd ratio against G5c's single chain lay outside [0.8, 1.25] (make_golden_posteriors_reseed.py --widths)
-    for fixture in ("g5d_posteriors_reseeded.json", "g5e_posterior_widths_reseeded.json"):
+    # G5f (round 5): 256 fresh seeds for the two pairs G5e left outside the width band (--tails; rule written before the runs); read last,
+    # it stands in for those two pairs' G5e entries
+    for fixture in ("g5d_posteriors_reseeded.json", "g5e_posterior_widths_reseeded.json", "g5f_posterior_tails_reseeded.json"):
         path = os.path.join(GOLDEN, fixture)
         if not os.path.exists(path):
             continue
@@ -92,5 +94,6 @@ def reference_posteriors(model, temperature=1.0):
                     mean[:, q] = e["mean"]
                     se[:, q] = np.maximum(e["se_between_seeds"], np.array(e["se_single_chain_batch_means"]) / np.sqrt(n))
                     sd[:, q] = e["sd"]
-                    reseeded.append(names[q])
+                    if names[q] not in reseeded:
+                        reseeded.append(names[q])
     return names, mean, se, sd, reseeded

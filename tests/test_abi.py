@@ -33,7 +33,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_state_sizes(lib):
-    assert lib.phf_version() == 5
+    assert lib.phf_version() == 6
+    assert lib.phf_hierarchical_last_kernel() == 0       # nothing launched yet in this thread
     assert lib.phf_philox_rounds() == 7                  # phf_philox.h: PHF_PHILOX_ROUNDS
     assert lib.phf_debug_philox_rounds(8, 1, 1, 1, None) == -1 and b"rounds" in lib.phf_last_error()
     assert lib.phf_simd_count() >= 4                      # without a GPU: the MI355X figure (1 024)
@@ -68,6 +69,24 @@ def test_argument_validation_without_gpu(lib):
     assert lib.phf_single_level_queue_status(None, 10, None) == -1 and lib.phf_single_level_queue_status(1, 0, None) == -1
     assert lib.phf_hierarchical_set_kernel_policy(3, 0) == -1 and lib.phf_hierarchical_set_kernel_policy(0, -1) == -1
     assert lib.phf_hierarchical_set_kernel_policy(2, 1) == 0 and lib.phf_hierarchical_set_kernel_policy(0, 0) == 0
+    # ABI 6: the hierarchical launch's own checks — kernel_hint fields, points_per_expt, the queued entry's workspace
+    from pyhillfit_amd import hierarchical as H
+    H._bind(lib)
+    hp = H.HierPoints(1, 16, 3, 0, 1, 1, 1)
+    pr = H.make_prior()
+    prob.kernel_hint = 3
+    assert lib.phf_hierarchical_advance(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
+    assert b"kernel_hint" in lib.phf_last_error()
+    prob.kernel_hint = 32
+    assert lib.phf_hierarchical_advance(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
+    prob.kernel_hint = 16 | 1
+    hp.points_per_expt = 7                                 # 3 experiments x 7 points do not fit a stride of 16
+    assert lib.phf_hierarchical_advance(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
+    assert b"points_per_expt" in lib.phf_last_error()
+    hp.points_per_expt = 4
+    assert lib.phf_hierarchical_advance_queued(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, 0, None, None) == -1
+    assert b"queue" in lib.phf_last_error()
+    assert lib.phf_debug_isa(99, 1, 1, 1, None) == -1 and lib.phf_debug_isa(0, 0, None, None, None) == 0
 
 
 def test_drained_queue_raises_on_the_host():

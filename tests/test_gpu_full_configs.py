@@ -191,6 +191,41 @@ def test_state_and_moments_must_be_device_memory(gpu, dr):
         hs.advance(10, save=False)
 
 
+def test_fine_grained_moments_buffer_is_refused(gpu, dr):
+    """the memory-kind check also refuses FINE-GRAINED device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained)),
+    on which the hardware fp64 atomics of the hierarchical moments are not guaranteed — allocated here through the HIP runtime the
+    process already has loaded, handed to the C ABI as the moments buffer; and the verdict cache (the last 8 (address, device) pairs)
+    is emptied by an *_init, so that an address once accepted is asked about again for the next sampler"""
+    import ctypes as C
+    from pyhillfit_amd import _lib
+    from pyhillfit_amd import hierarchical as H
+    hip_path = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                hip_path = line.split()[-1]
+                break
+    assert hip_path, "the HIP runtime is not mapped?"
+    hip = C.CDLL(hip_path)
+    hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipFree.argtypes = [C.c_void_p]
+    ex = dr.load_crumb_data("Amiodarone", "hERG")[2]
+    hs = H.HierarchicalSampler(H.PackedHierPoints([ex]), [0], 64, device=gpu)
+    hs.init(np.concatenate([[1., 5., 6., .3], np.tile([6.0, 0.8], 3), [8.0]])[None])
+    hs.enable_moments(0)
+    ptr = C.c_void_p()
+    nbytes = hs.moments.numel() * 8
+    assert hip.hipExtMallocWithFlags(C.byref(ptr), nbytes, 1) == 0 and ptr.value           # hipDeviceMallocFinegrained = 0x1
+    try:
+        cfg = hs._config(10)
+        rc = hs.lib.phf_hierarchical_advance(C.byref(hs.points.struct), C.byref(hs.prob), C.byref(hs.prior), C.byref(cfg), 0, 10,
+                                             hs.state.data_ptr(), None, ptr.value, 0, None)
+        assert rc == -1 and b"moments" in hs.lib.phf_last_error() and b"fine-grained" in hs.lib.phf_last_error(), (rc, hs.lib.phf_last_error())
+    finally:
+        hip.hipFree(ptr)
+    assert hs.advance(10).shape == (2, 1, 12, 64)                  # the sampler is still usable with its own (coarse-grained) buffers
+
+
 def test_queued_launch_at_the_bench_shape(gpu, dr):
     """the C3 launch exactly as bench.py runs it — 210 pairs x 4 096 chains = 13 440 blocks over 2 048 persistent wavefronts, 2 000
     iterations in 4 quanta, three launches back to back — ends in the same state and moments as the plain launches"""

@@ -326,6 +326,7 @@ def _hier_posteriors_against_reference_loop(gpu, dr, fixture, C, seed, report_na
     have not sampled in proportion; the MEDIAN chain's width is the reference's) r reaches 0.1 .. 0.2 —, acceptance within 0.02.  Returns the per-pair report.  failures: None =
     assert pair by pair; a list = collect (pair, what) of everything outside instead, so that a big fixture reports ALL of it at once."""
     from pyhillfit_amd import hierarchical as H
+    beyond_plain_band, columns_seen = [], [0]
     groups = {}
     for e in fixture:
         groups.setdefault(e["Ne"], []).append(e)
@@ -348,6 +349,7 @@ def _hier_posteriors_against_reference_loop(gpu, dr, fixture, C, seed, report_na
         acc = s.acceptance().mean(dim=1).cpu().numpy()
         for q, e in enumerate(entries):
             p = e["pooled"]
+            columns_seen[0] += len(p["mean"])
             want, want_sd = np.array(p["mean"]), np.array(p["sd"])
             se = np.maximum(p["se_batch_means"], p["se_between_seeds"])
             ratio = np.abs(pooled[:, q] - want) / (0.01 * np.abs(want) + 4 * se)
@@ -355,7 +357,11 @@ def _hier_posteriors_against_reference_loop(gpu, dr, fixture, C, seed, report_na
             run_means = np.array([r["mean"] for r in e["runs"]]); run_sds = np.array([r["sd"] for r in e["runs"]])
             v_seed = run_sds ** 2 + (run_means - run_means.mean(axis=0)) ** 2                       # each seed's share of the pooled variance
             rel_se_sd = v_seed.std(axis=0, ddof=1) / np.sqrt(len(e["runs"])) / (2.0 * np.maximum(v_seed.mean(axis=0), 1e-300))
-            sd_lo, sd_hi = 0.8 - 4 * rel_se_sd, 1.2 + 4 * rel_se_sd
+            # the band widens with the reference's OWN uncertainty about its width, but never beyond the round-3 bounds [0.5, 3.0]: with two
+            # reference seeds r can reach 0.5, and an unclamped [0.8 - 4 r, 1.2 + 4 r] would make the check vacuous exactly where the
+            # reference's two chains disagree
+            sd_lo, sd_hi = np.maximum(0.5, 0.8 - 4 * rel_se_sd), np.minimum(3.0, 1.2 + 4 * rel_se_sd)
+            beyond_plain_band.append(int(np.sum((sd_ratio <= 0.8) | (sd_ratio >= 1.2))))
             ref_acc = float(np.mean([r["acceptance"] for r in e["runs"]]))
             report.append((e["drug"], e["channel"], ne, float(ratio.max()), int(ratio.argmax()), float(sd_ratio.min()), float(sd_ratio.max()), float(acc[q])))
             print("%s %s-%s Ne=%d: worst mean ratio %.2f (column %d), sd ratios %.3f..%.3f, acceptance %.3f (reference %.3f)"
@@ -375,6 +381,11 @@ def _hier_posteriors_against_reference_loop(gpu, dr, fixture, C, seed, report_na
             assert ratio.max() < 1.0, (e["drug"], e["channel"], int(ratio.argmax()), pooled[:, q], want, se)
             assert np.all(sd_ratio > sd_lo) and np.all(sd_ratio < sd_hi), (e["drug"], e["channel"], sd_ratio, sd_lo, sd_hi)
             assert abs(acc[q] - ref_acc) < 0.02
+    # a systematic width error cannot hide behind noisy two-seed bands: at most 3 % of the (pair, column) entries may lie outside the
+    # PLAIN [0.8, 1.2] band at all (round 4 observed: G10 0, G10b 2 of 396, G10c/d 7 of 2 300)
+    n_beyond = int(sum(beyond_plain_band))
+    print("%s: %d of %d (pair, column) widths outside the plain [0.8, 1.2] band" % (report_name, n_beyond, columns_seen[0]))
+    assert n_beyond <= 0.03 * columns_seen[0], (n_beyond, columns_seen[0])
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     with open(os.path.join(REPO, "gpurun_out", report_name + "_report.json"), "w") as f:
         json.dump(report, f)
