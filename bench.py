@@ -139,6 +139,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10, help="untimed steps before the timed ones (the first launches of a process run ~10 %% slow while the clocks settle)")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "s3"])
     ap.add_argument("--pairs", type=int, default=None, help="s3: number of generated pairs (default %d; SURVEY 8(d): 210 or 1 680)" % S3_PAIRS)
+    ap.add_argument("--strong-chains", type=int, default=None, help="N > 1, default c3 run: chains per pair of the S3 batch that the strong-scaling "
+                    "region splits (default %d)" % S3_STRONG_CHAINS)
     ap.add_argument("--iters-per-step", type=int, default=None, help="MH iterations per step (default: 8000 c3, 2000 c2, 500 c4/c5)")
     ap.add_argument("--chains", type=int, default=None, help="chains per problem (default: 65536 c2, 4096 c3, 1024 c4/c5)")
     ap.add_argument("--thinning", type=int, default=5)
@@ -519,7 +521,7 @@ def main():
         if other == "strong" and a.workload == "c3" and a.chains is None:
             # the strong-scaling batch is SURVEY 8(d)'s S3: ONE batch of 1 680 generated pairs x 4 096 chains = 107 520 blocks of 64 chains,
             # 13 440 per GPU at 8 — the Crumb batch's 13 440 blocks leave 1 680 per GPU there, one ragged round of the chip's 2 048 slots
-            w2, C2, I2 = "s3", S3_STRONG_CHAINS, DEFAULT_ITERS["s3"]
+            w2, C2, I2 = "s3", a.strong_chains or S3_STRONG_CHAINS, a.iters_per_step or DEFAULT_ITERS["s3"]
         b2 = make_batch(w2, other, C2, a, ctx)
         dt2, kms2, chains2 = timed_region(b2, I2, a.steps, a.warmup, ctx)
         I_other = I2

@@ -210,7 +210,9 @@ def test_bench_default_line_carries_the_other_configurations():
     assert d["value"] == pytest.approx(210 * 4096 * d["config"]["iterations_per_step"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
     assert d["ms_per_step"] * d["steps"] > 300              # a timed region of the default size is no blink
     ow = d["other_workloads"]
-    assert sorted(ow) == ["c2", "c3_model1", "c4", "c5", "c5_moments"]
+    assert sorted(ow) == ["c2", "c3_model1", "c4", "c5", "c5_moments", "s3"]
+    assert "synthetic scaling set S3" in ow["s3"]["workload"] and ow["s3"]["chains"] == 1680 * 1024 and ow["s3"]["value"] > 1e10
+    assert all(e["ms_per_step"] * e["steps"] >= 450 for e in ow.values()), {k: e["ms_per_step"] * e["steps"] for k, e in ow.items()}   # >= ~0.5 s each
     assert "model 1" in ow["c3_model1"]["workload"] and ow["c3_model1"]["kernel"].startswith("mh_advance_kernel<1")
     assert "moments" in ow["c5_moments"]["workload"] and ow["c5_moments"]["kernel"] == "mh_advance_kernel<2, moments>"
     assert ow["c5_moments"]["algorithmic_bytes_per_launch"] == ow["c5"]["algorithmic_bytes_per_launch"]      # the same rows are written
@@ -220,6 +222,25 @@ def test_bench_default_line_carries_the_other_configurations():
         assert e["chains"] == chains and e["value"] == pytest.approx(chains * e["iterations_per_step"] * e["steps"] / (e["ms_per_step"] * e["steps"] * 1e-3), rel=1e-6)
         assert 0 < e["kernel_ms"] <= e["ms_per_step"] * 1.05 and 0 < e["roofline_frac"] < 1 and 0.05 < e["mean_acceptance"] < 0.6
         assert e["value"] > 1e9
+
+
+def test_bench_two_ranks_default_strong_region_is_the_synthetic_s3_batch():
+    """the driver's N > 1 command (default workload): `value` is the weak-scaling C3 figure and `strong_value` the split of ONE batch
+    of SURVEY 8(d)'s synthetic set S3 (1 680 generated pairs x 4 096 chains in the real run; here 210 x 256 so that two ranks fit
+    the one GPU of the rehearsal) by (pair, 64-chain block) units"""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "210", "--strong-chains", "256",
+           "--iters-per-step", "400", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PHF_BENCH_BACKEND="gloo"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "configs[2]" in d["config"]["workload"]
+    sr = d["strong_region"]
+    assert "synthetic scaling set S3" in sr["workload"] and sr["chains_all_gpus"] == 210 * 256 and abs(sr["chains_rank0"] - 210 * 128) <= 64
+    assert d["strong_value"] == pytest.approx(210 * 256 * 400 * 2 / (sr["ms_per_step"] * 2e-3), rel=1e-6) and d["strong_value"] > 0
 
 
 def test_bench_two_ranks_report_weak_and_strong_scaling():
