@@ -2,7 +2,7 @@
 
     python -m pyhillfit_amd.PyHillFit --data-file ../data/crumb_data.csv -m 2 -a [--hierarchical]
            [-i 500000] [-t 5] [-b 4] [-c N] [-Ne 0] [--num-APs 500] [-bfo]
-           [--num-chains 64] [--seed 25] [--device cuda:0] [--save-all-chains] [--segment 20000]
+           [--num-chains 64 | 128 with --hierarchical] [--seed 25] [--device cuda:0] [--save-all-chains] [--segment 20000]
 
 Same command-line flags, same output files in the same places (python/PyHillFit.py:33-65,645-971; chain-file
 contract: doseresponse.py:70-82,115-128), but every selected (drug, channel) pair is sampled AT ONCE by the HIP
@@ -47,7 +47,9 @@ def build_parser():
     req.add_argument("-m", "--model", type=int, help="For non-hierarchical: 1. fix Hill=1; 2. vary Hill", required=True)
     # new, GPU-side options (defaults keep old command lines working)
     new = parser.add_argument_group('MI355X options')
-    new.add_argument("--num-chains", type=int, default=64, help="independent chains per (drug, channel) pair")
+    new.add_argument("--num-chains", type=int, default=None, help="independent chains per (drug, channel) pair (default: 64; --hierarchical: 128 — "
+                     "measured on the full Crumb set, 128 chains per pair take the wall time of 64: 6.24 s against 6.21, the run being the latency of "
+                     "one wavefront-iteration on a chip the 420 wavefronts of 64 chains leave 59 %% idle; profiles/r05/cli_host_profile_hierarchical.txt)")
     new.add_argument("--seed", type=int, default=25, help="Philox seed (the reference seeds numpy with 25)")
     new.add_argument("--device", type=str, default=None, help="HIP device, default cuda:<LOCAL_RANK>")
     new.add_argument("--predictive-cdfs", action='store_true', default=False, help="hierarchical: also write the posterior-predictive CDFs and (Hill,pIC50) samples of construct_hierarchical_cdfs.py, accumulated on the GPU during sampling")
@@ -198,8 +200,13 @@ def main(argv=None):
         phfdist.finalize()       # also on an error or SystemExit of this rank: the others' next collective fails instead of hanging
 
 
+DEFAULT_CHAINS, DEFAULT_CHAINS_HIERARCHICAL = 64, 128
+
+
 def _run(args, rank, local_rank, world):
     device = args.device or "cuda:%d" % local_rank
+    if args.num_chains is None:
+        args.num_chains = DEFAULT_CHAINS_HIERARCHICAL if args.hierarchical else DEFAULT_CHAINS
     if args.write_workers is None:
         args.write_workers = chainio.default_write_workers(world)
     dr.define_model(args.model)                                        # PyHillFit.py:56
