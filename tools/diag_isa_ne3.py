@@ -20,12 +20,13 @@ C = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 packed = H.PackedHierPoints(exs)
 theta0 = np.array([bestfit.hierarchical_first_iteration(e, locs) for e in exs])
 res = {}
-for isa in (False, True, False, True):
+only = os.environ.get("PHF_DIAG_ONLY")                     # "isa" / "hipcc": one kernel only, 2 000-iteration launches only (PMC passes: every dispatch the same)
+for isa in ((False, True, False, True) if not only else ((only == "isa"),)):
     s = H.HierarchicalSampler(packed, list(range(len(exs))), C, thinning=5, seed=1, device="cuda:0")
     s.set_kernel_hint(lanes=1, isa=isa)
     s.init(theta0, cov_scale=0.01)
     s.advance(2000, save=False)
-    for I in (500, 2000):
+    for I in ((500, 2000) if not only else (2000,)):
         s.advance(I, save=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(3):
@@ -34,4 +35,5 @@ for isa in (False, True, False, True):
         print("%d pairs x %d chains, %4d iterations, %s: %.2f ms  (%.2f us per iteration; kernel %d)" % (
             len(exs), C, I, "gfx950 assembly" if isa else "hipcc one lane  ", dt * 1e3, dt / I * 1e6, H.last_kernel()), flush=True)
         res[(isa, I)] = dt
-print("ratio hipcc / assembly: 500 its %.3f, 2000 its %.3f" % (res[(False, 500)] / res[(True, 500)], res[(False, 2000)] / res[(True, 2000)]))
+if not only:
+    print("ratio hipcc / assembly: 500 its %.3f, 2000 its %.3f" % (res[(False, 500)] / res[(True, 500)], res[(False, 2000)] / res[(True, 2000)]))

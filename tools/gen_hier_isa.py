@@ -102,7 +102,7 @@ class Gen(object):
             v = k.v1()                                                      # is its one constant-bus read)
             k.mov32(v, Lit(val))
             self.c[n] = v
-        for n, val in (("PM0", M.PHILOX_M0), ("PM1", M.PHILOX_M1), ("ABSMASK", 0x7fffffff)):
+        for n, val in (("PM0", M.PHILOX_M0), ("PM1", M.PHILOX_M1), ("ABSMASK", 0x7fffffff), ("MANTHI", 0x000fffff), ("NORMBIAS", -48 * (0x3ff << 1))):
             r = k.s1()
             k.sop("s_mov_b32", r, Lit(val))
             self.c[n] = r

@@ -7,6 +7,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 C=${1:-1024}
+export PHF_DIAG_ONLY=${2:-isa}        # isa | hipcc: one kernel, launches of 2 000 iterations only (every dispatch the same)
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAVES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS" \
@@ -17,4 +18,4 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM
   rc=$?; echo "pmc pass $i rc=$rc"; tail -n 2 $R/gpurun_out/pmci_$i.log | cut -c1-300
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
 done
-cd $R && python tools/pmc_summary.py gpurun_out/pmci_*/ > gpurun_out/pmc_isa_ne3_$C.txt 2>&1; cat gpurun_out/pmc_isa_ne3_$C.txt | cut -c1-120
+cd $R && python tools/pmc_summary.py gpurun_out/pmci_*/ > gpurun_out/pmc_${PHF_DIAG_ONLY}_ne3_$C.txt 2>&1; cat gpurun_out/pmc_${PHF_DIAG_ONLY}_ne3_$C.txt | cut -c1-120

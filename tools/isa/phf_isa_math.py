@@ -27,7 +27,7 @@ CONSTS = [
     ("M746", -746.0), ("P710", 710.0), ("P40", 40.0), ("P6", 6.0),
     ("QUARTER", 0.25), ("DBLMIN", float.fromhex("0x1p-1022")), ("P2_1000", float.fromhex("0x1p1000")), ("LOGADD", None), ("MBITS", None),
 ]
-CONST_BITS = {"LOGADD": 0x3ff0000000000000 - 0x3fe6a09e667f3bcd, "MBITS": 0x3fe6a09e667f3bcd}
+CONST_BITS = {"LOGADD": (0x3ff0000000000000 - 0x3fe6a09e667f3bcd - (1023 << 52)) & 0xffffffffffffffff, "MBITS": 0x3fe6a09e667f3bcd}
 
 
 def const_index(name):
@@ -134,15 +134,16 @@ def log_pos(m, dsts, xs):
     e = [k.v1() for _ in range(n)]
     ad = [k.v1() for _ in range(n)]
     tab = [k.vq() for _ in range(n)]
+    # u = bits(x) + (bits(1) - bits(sqrt 1/2)) - (1023 << 52): the exponent field then holds e = floor(log2(x / sqrt(1/2))) as a signed
+    # number (one arithmetic shift), and the mantissa bits below it are what they would be without the last term
     _each(n, lambda i: k.emit("v_lshl_add_u64", [u[i]], [xs[i], 0, c["LOGADD"]], "valu", count="valu_int"))
-    _each(n, lambda i: k.vop("v_lshrrev_b32_e32", e[i], 20, u[i].hi()))
+    _each(n, lambda i: k.vop("v_ashrrev_i32_e32", e[i], 20, u[i].hi()))
     _each(n, lambda i: k.vop("v_and_b32_e32", u[i].hi(), Lit(0xfffff), u[i].hi()))
     _each(n, lambda i: k.emit("v_lshl_add_u64", [u[i]], [u[i], 0, c["MBITS"]], "valu", count="valu_int"))     # bits of m
     _each(n, lambda i: k.vop("v_add_u32_e32", ad[i], Lit(0x1000 - (LOG_TAB_BASE << 13)), u[i].hi()))
     _each(n, lambda i: k.vop("v_lshrrev_b32_e32", ad[i], 9, ad[i]))
     _each(n, lambda i: k.vop("v_and_b32_e32", ad[i], Lit(0x7ffff0), ad[i]))
     _each(n, lambda i: k.ds_read(tab[i], ad[i], LOG_OFF))
-    _each(n, lambda i: k.vop("v_add_u32_e32", e[i], Lit(-1023), e[i]))
     dk = [k.vd() for _ in range(n)]
     _each(n, lambda i: k.cvt_f64_i32(dk[i], e[i]))
     r = u
@@ -211,12 +212,10 @@ def normal_u32(m, dsts, ws):
     _each(n, lambda i: k.vop("v_lshl_or_b32", ad[i], ws[i], 1, 1))
     _each(n, lambda i: k.cvt_f64_u32(ab[i], ad[i]))
     _each(n, lambda i: k.vop("v_lshrrev_b32_e32", ad[i], 19, ab[i].hi()))
-    _each(n, lambda i: k.vop("v_add_u32_e32", ad[i], Lit(-(0x3ff << 1)), ad[i]))
-    _each(n, lambda i: k.vop("v_mul_u32_u24_e32", ad[i], 48, ad[i]))
+    _each(n, lambda i: k.vop("v_mad_u32_u24", ad[i], ad[i], 48, c["NORMBIAS"]))               # 48 (j + 2046) - 48 * 2046 (an SGPR)
     for j in (2, 1, 0):
         _each(n, lambda i: k.ds_read(tab[i][j], ad[i], NORMAL_OFF + 16 * j))
-    _each(n, lambda i: k.vop("v_and_b32_e32", ab[i].hi(), Lit(0xfffff), ab[i].hi()))
-    _each(n, lambda i: k.vop("v_or_b32_e32", ab[i].hi(), Lit(0x3ff00000), ab[i].hi()))
+    _each(n, lambda i: k.vop("v_bfi_b32", ab[i].hi(), c["MANTHI"], ab[i].hi(), c["ONEHI"]))    # mantissa bits under the exponent of 1.0
     sft = ab
     _each(n, lambda i: k.add(sft[i], ab[i], -1.0))
     cf = lambda i, j: tab[i][j // 2].sub(2 * (j % 2))
