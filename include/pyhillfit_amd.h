@@ -237,8 +237,8 @@ int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* pro
 
 /* The same advance as a WORK QUEUE inside one launch (ABI 6), as phf_single_level_advance_queued: where the launch runs the gfx950
  * assembly build (n_expts == 3, points_per_expt == 4, one lane per chain) AND has more 64-chain blocks than the chip holds wavefronts
- * (2 x phf_simd_count()) AND at least two quanta, it is cut into quanta of `quantum` iterations (0 = the library's choice, 125; rounded
- * down to a multiple of the thinning) and a grid as large as the chip pulls (quantum, block) tasks from a counter, a block's quanta
+ * (2 x phf_simd_count()) AND at least two quanta, it is cut into quanta of `quantum` iterations (0 = the library's choice: about 16 rounds
+ * of tasks on the chip's wavefront slots, at least 100 iterations; rounded down to a multiple of the thinning) and a grid as large as the chip pulls (quantum, block) tasks from a counter, a block's quanta
  * chaining through its state in HBM with agent-scope release / acquire — the ragged last round of a launch becomes a round of short
  * tasks (147 pairs x 1 024 chains: 2 352 wavefronts on 2 048 slots).  Every other launch runs exactly as phf_hierarchical_advance.
  * Results are identical either way (same chains, rows, state, moments).

@@ -1002,7 +1002,14 @@ int launch_isa3(const HierArgs& a, hipStream_t stream, bool* launched) {
   // the blocks do not fit the chip at once and the launch has at least two quanta; the quantum is a multiple of the thinning, so that
   // every quantum saves the same number of rows.
   const int64_t slots = 2LL * phf_simd_count();
-  int64_t quantum = a.quantum > 0 ? a.quantum : 125;
+  // the library's quantum: as long as leaves ~16 rounds of tasks on the chip's slots (the ragged last round is then ~3 % of the launch;
+  // every quantum costs a block one trip of its 91-double state through HBM), at least 100 iterations: 140 for C4's 2 000-iteration
+  // steps (2 352 blocks), 1 435 for the command line's 20 000-iteration segments at that width
+  int64_t quantum = a.quantum;
+  if (quantum <= 0) {
+    quantum = (a.t_end - a.t_begin) * total / (16 * slots);
+    if (quantum < 100) quantum = 100;
+  }
   quantum -= quantum % a.cfg.thinning;
   if (quantum < a.cfg.thinning) quantum = a.cfg.thinning;
   const int64_t nquanta = (a.t_end - a.t_begin + quantum - 1) / quantum;
