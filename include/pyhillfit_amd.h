@@ -78,7 +78,7 @@ typedef struct phf_problems {
   const double* temperature;     /* device [Q]  power the likelihood is raised to */
   const uint32_t* problem_id;    /* device [Q]  global problem number (Philox counter word 1) */
   uint32_t chain_id_base;        /* global number of local chain 0 (Philox counter word 0) */
-  uint32_t kernel_hint;          /* hierarchical launches (ABI 5; was `reserved`, must be 0 for single-level): which kernel THIS launch
+  uint32_t kernel_hint;          /* hierarchical launches (ABI 5; was `reserved`; single-level: 0, or bit 4 as below): which kernel THIS launch
                                     should get — bits 0-1 lanes per chain (1 | 2), bits 2-3 register build of the two-lane kernel (1 | 2
                                     wavefronts per SIMD), bit 4 (ABI 6) = 1: not the gfx950 assembly build of the Ne = 3 iteration (A/B timing,
                                     bit-identity tests); 0 = the library decides from the launch size.  A host that runs several
@@ -143,6 +143,12 @@ int phf_single_level_init(const phf_points* pts, const phf_problems* prob, int m
 int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, const phf_mh_config* cfg,
                              int64_t t_begin, int64_t t_end, double* state, double* rows,
                              double* moments, int64_t moments_after, void* stream);
+
+/* Which kernel the calling thread's last phf_single_level_advance[_queued] launched (ABI 6; 0 = none yet): 1 = mh_advance_kernel (hipcc),
+ * 2 = phf_sl3_advance, the hand-allocated gfx950 build of the model-2 iteration (launches without moments, more than one wavefront per
+ * SIMD, at most 32 entries per pair; phf_problems.kernel_hint bit 4 or PHF_SL_ISA=0 in the environment select the hipcc kernel: same
+ * numbers bit for bit), 3 = the same as a work queue. */
+int phf_single_level_last_kernel(void);
 
 /* The same advance as a WORK QUEUE inside one launch (ABI 3).  The launch is cut into quanta of `quantum` iterations; the grid is
  * only as large as the chip holds at once and its wavefronts pull (quantum, block) tasks — quantum-major, blocks in

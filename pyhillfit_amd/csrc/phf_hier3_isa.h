@@ -7,10 +7,18 @@
 
 #include "generated/phf_hier3_isa_layout.h"
 
+// the kernels' unsigned division n / d: magic = min(floor(2^32 / d), 2^32 - 1); the estimate floor(n magic / 2^32) is exact or one low,
+// the kernel corrects it once (tools/gen_hier_isa_main.py: udiv)
+inline uint32_t phf_isa_magic(uint32_t d) { const uint64_t m = (1ULL << 32) / (uint64_t)d; return m > 0xffffffffULL ? 0xffffffffu : (uint32_t)m; }
+
 // true once the embedded code object is loaded on the current device and holds the advance kernel
 bool phf_hier3_isa_available();
 // launch phf_hier3_advance: `a` complete except `consts` (filled here); (grid_waves + 3) / 4 workgroups of 256 threads — grid_waves =
 // a->total_waves for a plain launch (a->queue == NULL), the chip's wavefront slots for a queued one
 int phf_hier3_isa_advance(phf_hier3_isa_args* a, int grid_waves, hipStream_t stream);
+
+// the same for phf_sl3_advance: the single-level model-2 iteration (no moments), plain or queued
+bool phf_sl3_isa_available();
+int phf_sl3_isa_advance(phf_sl3_isa_args* a, int grid_waves, hipStream_t stream);
 
 #endif

@@ -45,13 +45,16 @@ struct DeviceModule {
   char msg[256] = "";
   hipModule_t module = nullptr;
   hipFunction_t advance = nullptr;
+  hipFunction_t sl_advance = nullptr;
   hipFunction_t unit[kNumUnits] = {};
   void* consts = nullptr;                      // tables + scalar constants, device memory, lives as long as the process
 };
 DeviceModule g_modules[kMaxDevices];
 
 std::vector<unsigned char> build_blob() {
-  std::vector<unsigned char> b(PHF_ISA_CONST_OFF + 8 * PHF_ISA_NUM_CONSTS + 64, 0);
+  static_assert(PHF_ISA_LOGPHI_BLOB_OFF >= PHF_ISA_CONST_OFF + 8 * PHF_ISA_NUM_CONSTS && PHF_ISA_LOGPHI_BLOB_OFF % 16 == 0, "blob layout");
+  std::vector<unsigned char> b(PHF_ISA_LOGPHI_BLOB_OFF + sizeof(phf_t_logphi) + 4096, 0);     // (+ slack: the staging loads whole rounds)
+  std::memcpy(b.data() + PHF_ISA_LOGPHI_BLOB_OFF, phf_t_logphi, sizeof(phf_t_logphi));
   static_assert(sizeof(phf_t_exp2) == 512 && sizeof(phf_t_log) == PHF_LOG_TAB_N * 16, "table sizes");
   static_assert(PHF_ISA_LOG_OFF == 512 && PHF_ISA_ERFC_OFF == PHF_ISA_LOG_OFF + PHF_LOG_TAB_N * 16, "LDS image of the tables");
   static_assert(PHF_ISA_NORMAL_OFF == PHF_ISA_ERFC_OFF + PHF_ERFC_TAB_N * 96 && PHF_ISA_TABLE_BYTES == PHF_ISA_NORMAL_OFF + PHF_NORMAL_TAB_N * 48,
@@ -97,6 +100,8 @@ void load_module(DeviceModule* m) {
   }
   e = hipModuleGetFunction(&m->advance, m->module, "phf_hier3_advance");
   if (e != hipSuccess) { m->advance = nullptr; (void)hipGetLastError(); }      // a units-only code object (generator bring-up)
+  e = hipModuleGetFunction(&m->sl_advance, m->module, "phf_sl3_advance");
+  if (e != hipSuccess) { m->sl_advance = nullptr; (void)hipGetLastError(); }
   const std::vector<unsigned char> blob = build_blob();
   e = hipMalloc(&m->consts, blob.size());
   if (e != hipSuccess) return fail("hipMalloc(constants)", e);
@@ -142,6 +147,20 @@ int phf_hier3_isa_advance(phf_hier3_isa_args* a, int grid_waves, hipStream_t str
   a->consts = m->consts;
   const unsigned blocks = (unsigned)((grid_waves + 3) / 4);
   return launch(m->advance, blocks, a, sizeof(*a), stream, "phf_hierarchical_advance (gfx950 assembly, Ne = 3)");
+}
+
+bool phf_sl3_isa_available() {
+  DeviceModule* m = nullptr;
+  if (get_module(&m) != PHF_OK) return false;
+  return m->sl_advance != nullptr;
+}
+
+int phf_sl3_isa_advance(phf_sl3_isa_args* a, int grid_waves, hipStream_t stream) {
+  DeviceModule* m = nullptr;
+  if (int rc = get_module(&m)) return rc;
+  if (!m->sl_advance) return phf_fail(PHF_ERR_UNSUPPORTED, "gfx950 code object holds no phf_sl3_advance");
+  a->consts = m->consts;
+  return launch(m->sl_advance, (unsigned)((grid_waves + 3) / 4), a, sizeof(*a), stream, "phf_single_level_advance (gfx950 assembly, model 2)");
 }
 
 extern "C" int phf_debug_isa(int fn, int64_t n, const void* in, void* out, void* stream) {

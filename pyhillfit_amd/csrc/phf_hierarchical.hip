@@ -978,7 +978,7 @@ int launch_isa3(const HierArgs& a, hipStream_t stream, bool* launched) {
   *launched = false;
   const int64_t bpp = a.blocks_per_problem;
   const int64_t total = bpp * a.prob.num_problems;
-  if (a.cfg.adapt_start < 0 || a.t_end >= 0xffffffffLL || total * bpp >= (1LL << 32) || total > 0x7fffffffLL) return PHF_OK;   // hipcc kernels
+  if (a.cfg.adapt_start < 0 || a.t_end >= 0xffffffffLL || total > 0x7fffffffLL) return PHF_OK;   // hipcc kernels
   if (!phf_hier3_isa_available()) return PHF_OK;
   phf_hier3_isa_args g{};
   g.state = a.state; g.rows = a.rows; g.moments = a.moments; g.gamma = a.cfg.gamma;
@@ -989,7 +989,7 @@ int launch_isa3(const HierArgs& a, hipStream_t stream, bool* launched) {
   g.thinning = a.cfg.thinning;
   g.moments_after = (uint32_t)(a.moments_after < 0 ? 0 : (a.moments_after > 0xffffffffLL ? 0xffffffffLL : a.moments_after));
   g.chains = a.prob.chains_per_problem; g.num_problems = a.prob.num_problems; g.bpp = (int32_t)bpp;
-  g.bpp_magic = bpp == 1 ? 0u : (uint32_t)((1ULL << 32) / (uint64_t)bpp + 1ULL);
+  g.bpp_magic = phf_isa_magic((uint32_t)bpp);
   g.total_waves = (int32_t)total;
   g.seed_lo = (uint32_t)a.cfg.seed; g.seed_hi = (uint32_t)(a.cfg.seed >> 32);
   g.chain_id_base = a.prob.chain_id_base; g.pts_stride = a.pts.stride;
@@ -1014,11 +1014,11 @@ int launch_isa3(const HierArgs& a, hipStream_t stream, bool* launched) {
   if (quantum < a.cfg.thinning) quantum = a.cfg.thinning;
   const int64_t nquanta = (a.t_end - a.t_begin + quantum - 1) / quantum;
   int64_t grid_waves = total;
-  if (a.queue && total > slots && nquanta >= 2 && nquanta * total * total < (1LL << 32) && a.t_begin % a.cfg.thinning == 0) {
+  if (a.queue && total > slots && nquanta >= 2 && nquanta * total < (1LL << 31) && a.t_begin % a.cfg.thinning == 0) {
     if (hipMemsetAsync(a.queue, 0, (size_t)(1 + total) * sizeof(int32_t), stream) != hipSuccess)
       return phf_check_launch("phf_hierarchical_advance_queued (memset)");
     g.queue = a.queue; g.quantum = (uint32_t)quantum; g.num_tasks = (int32_t)(nquanta * total);
-    g.blocks_magic = total == 1 ? 0u : (uint32_t)((1ULL << 32) / (uint64_t)total + 1ULL);
+    g.blocks_magic = phf_isa_magic((uint32_t)total);
     g.rows_per_quantum = (uint32_t)(quantum / a.cfg.thinning);
     grid_waves = slots;
   }

@@ -14,11 +14,13 @@
 
 #include "../../include/pyhillfit_amd.h"
 #include "phf_common.h"
+#include "phf_hier3_isa.h"
 #include "phf_model.h"
 
 namespace {
 
 constexpr int kBlock = 64;
+thread_local int g_last_sl_kernel = 0;        // phf_single_level_last_kernel(): 1 hipcc, 2 gfx950 assembly, 3 gfx950 assembly as a work queue
 constexpr int kQueuePoison = 0x40000000;     // task counter value that makes every wavefront of a queued launch leave
 constexpr int kQueueMaxRounds = 16;          // beyond this many rounds of the chip's wavefront slots the tail of a launch is negligible
 
@@ -493,6 +495,7 @@ int check_common(const phf_points* pts, const phf_problems* prob, int model) {
 extern "C" {
 
 int phf_version(void) { return PHF_ABI_VERSION; }
+int phf_single_level_last_kernel(void) { return g_last_sl_kernel; }
 
 int phf_single_level_state_size(int model) {
   if (model == 1) return 2 * 2 + 3 + 4;
@@ -546,6 +549,39 @@ static int advance_impl(const phf_points* pts, const phf_problems* prob, const p
       grid_blocks = slots;
     }
   }
+  // The hand-allocated gfx950 build of the model-2 iteration (phf_hier3_isa.hip: phf_sl3_advance; tools/gen_sl_isa_main.py): launches that
+  // do not ask for moments, give more than one wavefront per SIMD and whose pairs have at most PHF_ISA_SL_MAX_STRIDE entries; plain or
+  // queued exactly as decided above.  kernel_hint bit 4 or PHF_SL_ISA=0 (read once) select the hipcc kernels: same numbers bit for bit.
+  static const bool isa_on = [] { const char* e = getenv("PHF_SL_ISA"); return !(e && e[0] == '0' && e[1] == 0); }();
+  if (cfg->model == 2 && !moments && !lone && isa_on && !(prob->kernel_hint & 16u) && pts->stride <= PHF_ISA_SL_MAX_STRIDE &&
+      cfg->adapt_start >= 0 && t_end < 0xffffffffLL && nblocks <= 0x7fffffffLL && phf_sl3_isa_available()) {
+    phf_sl3_isa_args g{};
+    g.state = state; g.rows = rows; g.gamma = cfg->gamma;
+    g.ln_conc = pts->ln_conc; g.response = pts->response; g.weight = pts->weight; g.counts = pts->counts; g.pi_bit = pts->pi_bit; g.extra = pts->extra;
+    g.pair_index = prob->pair_index; g.temperature = prob->temperature; g.problem_id = prob->problem_id;
+    g.launch_order = prob->launch_order; g.chain_offset = prob->chain_offset;
+    g.t_begin = (uint32_t)t_begin; g.t_end = (uint32_t)t_end;
+    g.adapt_start = (uint32_t)(cfg->adapt_start > 0xffffffffLL ? 0xffffffffLL : cfg->adapt_start);
+    g.thinning = cfg->thinning; g.reset_mean = cfg->reset_mean_at_adapt_start != 0 ? 1u : 0u;
+    g.chains = prob->chains_per_problem; g.num_problems = prob->num_problems; g.bpp = a.blocks_per_problem;
+    g.bpp_magic = phf_isa_magic((uint32_t)a.blocks_per_problem); g.total_waves = (int32_t)nblocks;
+    g.seed_lo = (uint32_t)cfg->seed; g.seed_hi = (uint32_t)(cfg->seed >> 32);
+    g.chain_id_base = prob->chain_id_base; g.pts_stride = pts->stride;
+    g.until_save0 = cfg->thinning - (int32_t)(t_begin % cfg->thinning);
+    bool ok = true;
+    if (a.queue) {
+      // a quantum must save whole rows: a multiple of the thinning from a start that is one (what the queued callers use)
+      const int64_t nquanta = (t_end - t_begin + a.quantum - 1) / a.quantum;
+      ok = a.quantum % cfg->thinning == 0 && t_begin % cfg->thinning == 0 && nquanta * nblocks < (1LL << 31);
+      g.queue = a.queue; g.quantum = (uint32_t)a.quantum; g.num_tasks = (int32_t)(nquanta * nblocks);
+      g.blocks_magic = phf_isa_magic((uint32_t)nblocks); g.rows_per_quantum = (uint32_t)(a.quantum / cfg->thinning);
+    }
+    if (ok) {
+      g_last_sl_kernel = a.queue ? 3 : 2;
+      return phf_sl3_isa_advance(&g, (int)grid_blocks, s);
+    }
+  }
+  g_last_sl_kernel = 1;
   const dim3 grid((unsigned)grid_blocks), block(kBlock);
 #define PHF_LAUNCH_ADVANCE(M, MOM, W) hipLaunchKernelGGL((mh_advance_kernel<M, MOM, W>), grid, block, lds, s, a)
   if (cfg->model == 1) {

@@ -156,6 +156,15 @@ class SingleLevelSampler(object):
         self.row0 = None
         self._gamma = None
 
+    def set_kernel_hint(self, isa=True):
+        """isa=False: this sampler's launches run the hipcc kernel where they would run the hand-allocated gfx950 build of the model-2
+        iteration (phf_problems.kernel_hint bit 4).  Same numbers bit for bit; for A/B timing and the bit-identity tests."""
+        self.prob.kernel_hint = 0 if isa else 16
+
+    def last_kernel(self):
+        """which kernel this thread's last advance launched (phf_single_level_last_kernel): 1 hipcc, 2 gfx950 assembly, 3 the same queued"""
+        return int(self.lib.phf_single_level_last_kernel())
+
     # -- start: PyHillFit.py:748-751,789,814 / PyHillTemp.py:63-80 --------------------------------------------
     def init(self, theta0, cov_identity=False, cov_scale=0.05):
         """theta0: [d] (every chain), [Q][d] (per problem) or [Q][C][d]."""

@@ -161,3 +161,71 @@ def test_isa_work_queue_bit_identical_at_full_width(gpu):
     for name, a, b in zip(("rows", "state", "moments"), got[False], got[True]):
         same = a.view(torch.int64) == b.view(torch.int64)
         assert bool(same.all()), (name, int((~same).sum()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# phf_sl3_advance: the hand-allocated single-level model-2 iteration against the hipcc kernel and the scalar twin
+def _sl_runs(gpu, packed, Q, temps, C, thin, adapt, cuts, reset_mean=False, cov_identity=False, theta0=(6.0, 0.8, 8.0), queue_quanta=4, **kw):
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    got = {}
+    for isa in (False, True):
+        s = SingleLevelSampler(packed, 2, list(range(Q)) if "pair_index" not in kw else kw["pair_index"], temps, C, thinning=thin, seed=2024,
+                               adapt_start=adapt, reset_mean_at_adapt_start=reset_mean, device=gpu, queue_quanta=queue_quanta,
+                               chain_id_base=3, chain_offsets=kw.get("chain_offsets"), launch_order=kw.get("launch_order", "cost"))
+        s.set_kernel_hint(isa=isa)
+        s.init(np.asarray(theta0), cov_identity=cov_identity, cov_scale=1.0 if cov_identity else 0.05)
+        parts, kernels = [], []
+        for k in cuts:
+            parts.append(s.advance(k).cpu().numpy())
+            kernels.append(s.last_kernel())
+        got[isa] = (np.concatenate(parts), s.state.cpu().numpy(), kernels)
+    return got
+
+
+@pytest.mark.parametrize("C,thin,cuts,quanta", [(1024, 5, (300, 7, 493), 4), (1000, 1, (150, 250), 0)])
+def test_isa_single_level_bit_identical_to_the_hipcc_kernel(C, thin, cuts, quanta, gpu):
+    """every entry-count shape of the Crumb set (all 210 pairs: 0..5 uncensored x 0..4 censored entries — the run-time loops of the
+    assembly target against hipcc's twenty straight-line bodies and its generic one), tempered problems among them (t = 1, 0.125, 0),
+    a ragged last wavefront (1 000 chains), thinning 1 and 5, launches cut before / at / after the start of the adaptation"""
+    import os
+    from conftest import REPO
+    from pyhillfit_amd import doseresponse as dr
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json")); dr.define_model(2)
+    names = [(d, c) for d in dr.drugs for c in dr.channels]
+    packed = dr.pack_single_level(names)
+    temps = [(1.0, 0.125, 0.0, 1.0)[q % 4] for q in range(len(names))]
+    got = _sl_runs(gpu, packed, len(names), temps, C, thin, 200, cuts, reset_mean=True, cov_identity=True, theta0=(1.0, 1.0, 1.0), queue_quanta=quanta)
+    # the kernel meant is the kernel that ran: assembly (queued where the launch is queued and starts on a multiple of the thinning;
+    # a queued launch from a ragged start falls back to the hipcc queue) against hipcc
+    assert set(got[False][2]) == {1} and got[True][2][0] in (2, 3) and got[True][2][1] == 2, (got[False][2], got[True][2])
+    for name, a, b in zip(("rows", "state"), got[False][:2], got[True][:2]):
+        same = a.view(np.uint64) == b.view(np.uint64)
+        assert same.all(), (name, int((~same).sum()), np.argwhere(~same)[:5].tolist())
+
+
+def test_isa_single_level_queue_and_twin(gpu):
+    """the C3 shape in small: 210 pairs x 4 096 chains = 13 440 blocks through the work queue (quanta of a quarter launch) — rows and
+    state against the hipcc kernel's queued launch bit for bit, and sampled chains against the scalar twin"""
+    import os
+    from conftest import REPO
+    from oracle import c_oracle as co
+    from pyhillfit_amd import doseresponse as dr
+    from pyhillfit_amd.sampler import gamma_table
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json")); dr.define_model(2)
+    names = [(d, c) for d in dr.drugs for c in dr.channels]
+    packed = dr.pack_single_level(names)
+    C, thin, adapt = 4096, 5, 120
+    got = _sl_runs(gpu, packed, len(names), [1.0] * len(names), C, thin, adapt, (200, 400))
+    assert got[True][2][0] in (2, 3) and got[True][2][1] == 3 and got[False][2] == [1, 1], (got[True][2], got[False][2])
+    for name, a, b in zip(("rows", "state"), got[False][:2], got[True][:2]):
+        assert (a.view(np.uint64) == b.view(np.uint64)).all(), name
+    rows = got[True][0]
+    gam = gamma_table(600)
+    for q in (0, 57, 209):
+        ne, _, ex = dr.load_crumb_data(*names[q])
+        concs, y = dr.concatenate_experiments(ne, ex)
+        pk = co.PackedPair(concs, y, 2, 1.0)
+        for c in (0, 4095):
+            st = pk.init_state([6.0, 0.8, 8.0], False, 0.05)
+            want = pk.advance(st, 0, 600, thin, adapt, False, gam, seed=2024, chain_id=3 + c, problem_id=q)
+            assert np.array_equal(rows[:, q, :, c], want), (q, c)

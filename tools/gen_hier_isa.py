@@ -51,9 +51,9 @@ ARGS = [("consts", "const void*"), ("state", "double*"), ("rows", "double*"), ("
         ("prior_loc", "double[5]"), ("prior_inv_scale", "double[5]"), ("prior_shape_m1", "double[5]"), ("three_twelve", "double[2]")]
 
 
-def arg_layout():
+def arg_layout(args=None):
     off, out = 0, {}
-    for name, ty in ARGS:
+    for name, ty in (ARGS if args is None else args):
         if ty.endswith("*"):
             size = 8
         elif ty.startswith("double["):
@@ -68,6 +68,19 @@ def arg_layout():
 
 
 ARG_OFF, ARG_BYTES = arg_layout()
+
+# kernel arguments of phf_sl3_advance (single-level model 2).  The fields the shared task code reads (tools/gen_hier_isa_main.py:
+# task_fetch / task_done) carry the same names and the same order within their 16-byte groups as in ARGS.
+SL_ARGS = [("consts", "const void*"), ("state", "double*"), ("rows", "double*"), ("gamma", "const double*"),
+           ("ln_conc", "const double*"), ("response", "const double*"), ("weight", "const double*"), ("counts", "const int32_t*"),
+           ("pi_bit", "const double*"), ("extra", "const double*"), ("pair_index", "const int32_t*"), ("temperature", "const double*"),
+           ("problem_id", "const uint32_t*"), ("launch_order", "const int32_t*"), ("chain_offset", "const uint32_t*"), ("queue", "int32_t*"),
+           ("t_begin", "uint32_t"), ("t_end", "uint32_t"), ("adapt_start", "uint32_t"), ("thinning", "int32_t"),
+           ("reset_mean", "uint32_t"), ("chains", "int32_t"), ("num_problems", "int32_t"), ("bpp", "int32_t"),
+           ("bpp_magic", "uint32_t"), ("total_waves", "int32_t"), ("seed_lo", "uint32_t"), ("seed_hi", "uint32_t"),
+           ("chain_id_base", "uint32_t"), ("pts_stride", "int32_t"), ("until_save0", "int32_t"), ("quantum", "uint32_t"),
+           ("num_tasks", "int32_t"), ("blocks_magic", "uint32_t"), ("rows_per_quantum", "uint32_t"), ("pad0", "int32_t")]
+SL_ARG_OFF, SL_ARG_BYTES = arg_layout(SL_ARGS)
 
 
 class Gen(object):
@@ -130,6 +143,41 @@ class Gen(object):
             else:
                 k.ds_write(off[j], tmp[j], 0)
         k.free(off, tmp)
+        k.barrier()
+
+
+    def stage_ranges(self, s_consts, ranges):
+        """ranges: (byte offset in the blob, byte offset in LDS, bytes) — copied by all 256 threads, 8 bytes per thread and round; then
+        the workgroup's barrier"""
+        k = self.k
+        t8 = k.v1()
+        k.vop("v_lshlrev_b32_e32", t8, 3, self.tid)
+        for blob_off, lds_off, nbytes in ranges:
+            rounds = (nbytes // 8 + 255) // 256
+            for r0 in range(0, rounds, 4):
+                batch = list(range(r0, min(r0 + 4, rounds)))
+                offs = [k.v1() for _ in batch]
+                tmp = [k.vd() for _ in batch]
+                for i, j in enumerate(batch):
+                    k.vop("v_add_u32_e32", offs[i], Lit(2048 * j), t8)
+                for i, j in enumerate(batch):
+                    sb = k.sd()
+                    k.sop("s_add_u32", sb.lo(), s_consts.lo(), Lit(blob_off))
+                    k.sop("s_addc_u32", sb.hi(), s_consts.hi(), 0)
+                    k.gload(tmp[i], offs[i], sb)
+                    k.free(sb)
+                for i, j in enumerate(batch):
+                    if (j + 1) * 2048 > nbytes:
+                        save = k.sd()
+                        k.emit("v_cmp_gt_u32_e32", [VCC], [Lit(nbytes), offs[i]], "valu", count="valu_int")
+                        k.sop("s_and_saveexec_b64", save, VCC)
+                        k.ds_write(offs[i], tmp[i], lds_off)
+                        k.sop("s_mov_b64", EXEC, save)
+                        k.free(save)
+                    else:
+                        k.ds_write(offs[i], tmp[i], lds_off)
+                k.free(offs, tmp)
+        k.free(t8)
         k.barrier()
 
 
@@ -269,6 +317,13 @@ def layout_header():
     for name, _ in ARGS:
         lines.append("_Static_assert(__builtin_offsetof(phf_hier3_isa_args, %s) == %d, \"layout of %s\");" % (name, ARG_OFF[name], name))
     lines += ["_Static_assert(sizeof(phf_hier3_isa_args) == %d, \"size of the argument block\");" % ARG_BYTES, "",
+              "typedef struct phf_sl3_isa_args {"]
+    for name, ty in SL_ARGS:
+        lines.append("  %s %s;" % (ty, name))
+    lines += ["} phf_sl3_isa_args;", ""]
+    for name, _ in SL_ARGS:
+        lines.append("_Static_assert(__builtin_offsetof(phf_sl3_isa_args, %s) == %d, \"layout of %s\");" % (name, SL_ARG_OFF[name], name))
+    lines += ["_Static_assert(sizeof(phf_sl3_isa_args) == %d, \"size of the argument block\");" % SL_ARG_BYTES, "",
               "#endif", ""]
     return "\n".join(lines)
 
@@ -280,7 +335,11 @@ def generate(with_main=True):
         import gen_hier_isa_main as G
         main, info = G.main_kernel()
         kernels.append(main)
-        hdr_extra = G.header_extra(info)
+        import gen_sl_isa_main as GS
+        sl, sl_info = GS.main_kernel()
+        kernels.append(sl)
+        info.update(sl_info)
+        hdr_extra = G.header_extra(info) + ("#define PHF_ISA_LOGPHI_BLOB_OFF %d\n#define PHF_ISA_SL_MAX_STRIDE %d\n\n" % (GS.BLOB_LOGPHI_OFF, GS.MAX_STRIDE))
     else:
         hdr_extra = ""
     text = "; GENERATED by tools/gen_hier_isa.py — do not edit (regenerate; tests/test_isa_generator.py checks this file against the script)\n"

@@ -40,10 +40,11 @@ class Main(object):
         self.m = self.g.m
         self.c = self.g.c
         self.info = {}
+        self.ARG_OFF = ARG_OFF
 
     # ------------------------------------------------------------------------------------------------------------ small helpers
     def arg(self, dst, name, extra=0):
-        self.k.s_load(dst, self.g.kernarg, ARG_OFF[name] + extra)
+        self.k.s_load(dst, self.g.kernarg, self.ARG_OFF[name] + extra)
         return dst
 
     def add64(self, dst, a, b):
@@ -51,6 +52,19 @@ class Main(object):
         k = self.k
         k.sop("s_add_u32", dst.lo(), a.lo(), b.lo() if b.n == 2 else b)
         k.sop("s_addc_u32", dst.hi(), a.hi(), b.hi() if b.n == 2 else 0)
+
+    def udiv(self, q, r, n, d, magic, tmp):
+        """q = n / d, r = n % d for 32-bit unsigned n, d >= 1 with magic = min(floor(2^32 / d), 2^32 - 1) from the host: the estimate
+        floor(n magic / 2^32) is q or q - 1 (n magic / 2^32 > n / d - n / 2^32 > n / d - 1), one correction step makes it exact"""
+        k = self.k
+        k.sop("s_mul_hi_u32", q, n, magic)
+        k.sop("s_mul_i32", tmp, q, d)
+        k.sop("s_sub_u32", r, n, tmp)
+        k.sop("s_cmp_ge_u32", None, r, d)
+        k.sop("s_cselect_b32", tmp, d, 0)
+        k.sop("s_sub_u32", r, r, tmp)                        # (SCC is the borrow now)
+        k.sop("s_cmp_lg_u32", None, tmp, 0)                  # corrected (d >= 1)?
+        k.sop("s_addc_u32", q, q, 0)
 
     def lds_addr(self, slot):
         return self.v_lds, slot * 512
@@ -72,14 +86,14 @@ class Main(object):
     # ------------------------------------------------------------------------------------------------------------ prologue
     def ptr(self, name):
         r = self.k.sd()
-        self.k.s_load(r, self.g.kernarg, ARG_OFF[name])
+        self.k.s_load(r, self.g.kernarg, self.ARG_OFF[name])
         return r
 
     def prologue_once(self):
         """what a wavefront does once: constants, the workgroup's tables, its own LDS areas, the registers that live as long as it does"""
         k, g = self.k, self.g
         k.comment("---- once per wavefront: constants, tables -> LDS, LDS bases ----")
-        assert ARG_OFF["total_waves"] == ARG_OFF["num_problems"] + 12 and ARG_OFF["chains"] == ARG_OFF["adapt_start"] + 12
+        assert self.ARG_OFF["total_waves"] == self.ARG_OFF["num_problems"] + 12 and self.ARG_OFF["chains"] == self.ARG_OFF["adapt_start"] + 12
         s_consts = self.ptr("consts")
         g.load_constants(s_consts, RESIDENT)
         # every scalar that lives as long as the wavefront, allocated in one block (temporaries come and go behind it: no holes)
@@ -106,7 +120,7 @@ class Main(object):
         k.vop("v_add_u32_e32", self.v_lds, tmp, self.v_lane8)
         k.sop("s_add_u32", tmp, tmp, Lit(NSLOTS * 512))
         k.mov32(self.v_ulds, tmp)
-        k.s_load(self.s_queue, g.kernarg, ARG_OFF["queue"])
+        k.s_load(self.s_queue, g.kernarg, self.ARG_OFF["queue"])
         k.free(vt, tmp)
         # the chain state's registers
         self.th = [k.vd() for _ in range(D)]
@@ -135,14 +149,14 @@ class Main(object):
         k.label(self.l_task)
         k.sop("s_mov_b64", EXEC, -1)
         w4 = k.sx(4)
-        k.s_load(w4, g.kernarg, ARG_OFF["num_problems"])          # num_problems bpp bpp_magic total_waves
+        k.s_load(w4, g.kernarg, self.ARG_OFF["num_problems"])          # num_problems bpp bpp_magic total_waves
         a_np, a_bpp, a_magic, a_total = (w4.sub(i, 1) for i in range(4))
         q4 = k.sx(4)
-        k.s_load(q4, g.kernarg, ARG_OFF["quantum"])               # quantum num_tasks blocks_magic rows_per_quantum
+        k.s_load(q4, g.kernarg, self.ARG_OFF["quantum"])               # quantum num_tasks blocks_magic rows_per_quantum
         a_quant, a_ntasks, a_bmagic, a_rpq = (q4.sub(i, 1) for i in range(4))
-        assert ARG_OFF["rows_per_quantum"] == ARG_OFF["quantum"] + 12
+        assert self.ARG_OFF["rows_per_quantum"] == self.ARG_OFF["quantum"] + 12
         tb = k.sd()
-        k.s_load(tb, g.kernarg, ARG_OFF["t_begin"])               # t_begin t_end
+        k.s_load(tb, g.kernarg, self.ARG_OFF["t_begin"])               # t_begin t_end
         tmp, task = k.s1(), k.s1()
         k.sop("s_cmp_eq_u64", None, self.s_queue, 0)
         k.branch("s_cbranch_scc1", l_plain)
@@ -158,11 +172,7 @@ class Main(object):
         k.readfirstlane(task, vt)
         k.sop("s_cmp_ge_u32", None, task, a_ntasks)
         k.branch("s_cbranch_scc1", self.l_end)
-        k.sop("s_mul_hi_u32", self.s_quant, task, a_bmagic)      # quantum = task / blocks (host-checked magic; 0 = one block)
-        k.sop("s_cmp_eq_u32", None, a_bmagic, 0)
-        k.sop("s_cselect_b32", self.s_quant, task, self.s_quant)
-        k.sop("s_mul_i32", tmp, self.s_quant, a_total)
-        k.sop("s_sub_u32", self.s_block, task, tmp)
+        self.udiv(self.s_quant, self.s_block, task, a_total, a_bmagic, tmp)      # quantum = task / blocks, block = task % blocks
         # wait for this block's previous quantum: queue[1 + block] >= quantum
         cur = k.sd()
         polls = k.s1()
@@ -216,16 +226,18 @@ class Main(object):
         k.label(l_have)
         k.free(q4, tb)
         k.sop("s_mov_b32", self.s_t, self.s_first)
+        self.block_setup(w4, tmp, task)
+
+    def block_setup(self, w4, tmp, task):
+        """w4 = (num_problems, bpp, bpp_magic, total_waves), tmp a scalar temporary, task = rows saved by this block's earlier quanta"""
+        k, g = self.k, self.g
+        a_np, a_bpp, a_magic, a_total = (w4.sub(i, 1) for i in range(4))
         k.comment("---- the block: which problem, which chains; uniform area; addresses; state -> registers / LDS ----")
         a_C = k.s1()
-        k.s_load(a_C, g.kernarg, ARG_OFF["chains"])
+        k.s_load(a_C, g.kernarg, self.ARG_OFF["chains"])
         # slot = block / bpp (host-checked magic), chunk = block - slot * bpp
         slot, chunk = k.s1(), k.s1()
-        k.sop("s_mul_hi_u32", slot, self.s_block, a_magic)
-        k.sop("s_cmp_eq_u32", None, a_magic, 0)                   # bpp == 1: the magic does not fit 32 bits; slot = block
-        k.sop("s_cselect_b32", slot, self.s_block, slot)
-        k.sop("s_mul_i32", tmp, slot, a_bpp)
-        k.sop("s_sub_u32", chunk, self.s_block, tmp)
+        self.udiv(slot, chunk, self.s_block, a_bpp, a_magic, tmp)     # slot = block / bpp, chunk = block % bpp
         k.free(w4)
         # q = launch_order ? launch_order[slot] : slot
         q = k.s1()
@@ -253,7 +265,7 @@ class Main(object):
         k.label(l_nocoff)
         k.free(a_pi, a_pid, a_coff)
         a_stride = k.s1()
-        k.s_load(a_stride, g.kernarg, ARG_OFF["pts_stride"])
+        k.s_load(a_stride, g.kernarg, self.ARG_OFF["pts_stride"])
         lane = self.v_lane
         c0 = k.s1()
         k.sop("s_lshl_b32", c0, chunk, 6)
@@ -279,14 +291,14 @@ class Main(object):
         k.sop("s_mov_b64", EXEC, save)
         k.emit("v_cmp_gt_u32_e32", [VCC], [15, lane], "valu", count="valu_int")
         k.sop("s_and_saveexec_b64", save, VCC)
-        k.gload(u1, self.v_lane8, g.kernarg, ARG_OFF["prior_loc"])
+        k.gload(u1, self.v_lane8, g.kernarg, self.ARG_OFF["prior_loc"])
         k.vop("v_add_u32_e32", ua, self.v_ulds, self.v_lane8)
         k.ds_write(ua, u1, U_LOC)
         k.sop("s_mov_b64", EXEC, save)
         k.free(save, ua, u1, u2, a_lc, a_y, pp, s_pair, a_stride)
         more = k.sx(4)
-        k.s_load(more, g.kernarg, ARG_OFF["seed_lo"])             # seed_lo seed_hi chain_id_base pts_stride
-        assert ARG_OFF["prior_inv_scale"] == ARG_OFF["prior_loc"] + 40 and ARG_OFF["prior_shape_m1"] == ARG_OFF["prior_loc"] + 80
+        k.s_load(more, g.kernarg, self.ARG_OFF["seed_lo"])             # seed_lo seed_hi chain_id_base pts_stride
+        assert self.ARG_OFF["prior_inv_scale"] == self.ARG_OFF["prior_loc"] + 40 and self.ARG_OFF["prior_shape_m1"] == self.ARG_OFF["prior_loc"] + 80
         # lanes: c = chunk * 64 + lane < C
         k.sop("s_sub_u32", tmp, a_C, c0)
         k.cmp_u32("gt", VCC, tmp, lane)
@@ -300,7 +312,7 @@ class Main(object):
         k.sop("s_add_u32", self.s_g0, self.s_g0, c0)
         # nch8 = Q * C * 8 (64 bits)
         a_np = k.s1()
-        k.s_load(a_np, g.kernarg, ARG_OFF["num_problems"])
+        k.s_load(a_np, g.kernarg, self.ARG_OFF["num_problems"])
         k.sop("s_mul_i32", self.s_nch8.lo(), a_np, a_C)
         k.sop("s_mul_hi_u32", self.s_nch8.hi(), a_np, a_C)
         k.free(a_np)
@@ -340,13 +352,13 @@ class Main(object):
         s_state = k.sd()
         self.add64(s_state, a_state, t2)
         k.free(a_state)
-        k.s_load(self.s_gamma, g.kernarg, ARG_OFF["gamma"])
+        k.s_load(self.s_gamma, g.kernarg, self.ARG_OFF["gamma"])
         k.free(t2, q, c0)
         # loop scalars
         until0 = k.s1()
-        k.s_load(until0, g.kernarg, ARG_OFF["until_save0"])
+        k.s_load(until0, g.kernarg, self.ARG_OFF["until_save0"])
         c4 = k.sx(4)
-        k.s_load(c4, g.kernarg, ARG_OFF["adapt_start"])           # adapt_start thinning moments_after chains
+        k.s_load(c4, g.kernarg, self.ARG_OFF["adapt_start"])           # adapt_start thinning moments_after chains
         a_adapt, a_thin, a_mafter = (c4.sub(i, 1) for i in range(3))
         k.sop("s_mov_b32", self.s_adapt, a_adapt)
         k.sop("s_mov_b32", self.s_thin, a_thin)
@@ -365,12 +377,20 @@ class Main(object):
         k = self.k
         k.comment("---- the block's state: registers and LDS slots -> HBM; hand the block over ----")
         st, t2 = k.sd(), k.sd()
-        k.s_load(st, self.g.kernarg, ARG_OFF["state"])
+        k.s_load(st, self.g.kernarg, self.ARG_OFF["state"])
         k.sop("s_mov_b32", t2.lo(), self.s_g0)
         k.sop("s_mov_b32", t2.hi(), 0)
         k.sop("s_lshl_b64", t2, t2, 3)
         self.add64(st, st, t2)
         self.walk_state(st, load=False)
+        k.free(st, t2)
+        self.hand_over()
+
+    def hand_over(self):
+        """queued: release, publish queue[1 + block] = quantum + 1, next task; plain: the wavefront is done"""
+        k = self.k
+        t2 = k.sd()
+        st = None
         k.sop("s_cmp_eq_u64", None, self.s_queue, 0)
         k.branch("s_cbranch_scc1", self.l_end)
         k.sop("s_mov_b64", EXEC, -1)
@@ -389,7 +409,7 @@ class Main(object):
         k.sop("s_and_saveexec_b64", save, VCC)
         k.emit("global_store_dword", [], [self.v_zero, v, t2], "vmem", suffix="offset:4 sc1", mem="vm")
         k.sop("s_mov_b64", EXEC, save)
-        k.free(st, t2, v, tmp, save)
+        k.free(t2, v, tmp, save)
         k.branch("s_branch", self.l_task)
         k.label(self.l_end)
         k.endpgm()

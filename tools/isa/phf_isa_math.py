@@ -34,11 +34,17 @@ def const_index(name):
     return [n for n, _ in CONSTS].index(name)
 
 
-class Ctx(object):
-    """k: the Kernel; c: name -> SGPR pair (or VGPR pair) of a resident constant"""
+LOGPHI_TAB_N, LOGPHI_BYTES = 136, 136 * 80
 
-    def __init__(self, k, c):
+
+class Ctx(object):
+    """k: the Kernel; c: name -> SGPR pair (or VGPR pair) of a resident constant; off: LDS byte offset of each table in THIS kernel"""
+
+    def __init__(self, k, c, off=None):
         self.k, self.c = k, c
+        self.off = {"exp2": EXP2_OFF, "log": LOG_OFF, "erfc": ERFC_OFF, "normal": NORMAL_OFF}
+        if off:
+            self.off.update(off)
 
 
 def _each(n, f):
@@ -81,6 +87,48 @@ def sqrt_nonneg(m, dsts, xs, masks):
     k.free(g, h, r)
 
 
+def sqrt_pos_chain(m, g, h, xs):
+    """the Newton iteration of phf_sqrt_pos / phf_sqrt_rcp_pos: on return g[i] = sqrt(x) correctly rounded, h[i] ~ 1 / (2 sqrt x)"""
+    k = m.k
+    n = len(xs)
+    r = [k.vd() for _ in range(n)]
+    _each(n, lambda i: k.rsq_est(h[i], xs[i]))
+    _each(n, lambda i: k.mul(g[i], xs[i], h[i]))
+    _each(n, lambda i: k.mul(h[i], h[i], 0.5))
+    _each(n, lambda i: k.fma(r[i], Neg(h[i]), g[i], 0.5))
+    _each(n, lambda i: k.fma(g[i], g[i], r[i], g[i]))
+    _each(n, lambda i: k.fma(h[i], h[i], r[i], h[i]))
+    _each(n, lambda i: k.fma(r[i], Neg(g[i]), g[i], xs[i]))
+    _each(n, lambda i: k.fma(g[i], r[i], h[i], g[i]))
+    _each(n, lambda i: k.fma(r[i], Neg(g[i]), g[i], xs[i]))
+    _each(n, lambda i: k.fma(g[i], r[i], h[i], g[i]))
+    k.free(r)
+
+
+def sqrt_pos(m, dsts, xs):
+    """phf_sqrt_pos (no select: the caller guards x <= 0)"""
+    k = m.k
+    h = [k.vd() for _ in xs]
+    sqrt_pos_chain(m, dsts, h, xs)
+    k.free(h)
+
+
+def sqrt_rcp_pos(m, dsts, invs, xs):
+    """phf_sqrt_rcp_pos: g = sqrt(x) and 1 / g from ONE hardware estimate"""
+    k = m.k
+    n = len(xs)
+    h = [k.vd() for _ in range(n)]
+    e = [k.vd() for _ in range(n)]
+    sqrt_pos_chain(m, dsts, h, xs)
+    yi = invs
+    _each(n, lambda i: k.add(yi[i], h[i], h[i]))
+    _each(n, lambda i: k.fma(e[i], Neg(dsts[i]), yi[i], 1.0))
+    _each(n, lambda i: k.fma(yi[i], yi[i], e[i], yi[i]))
+    _each(n, lambda i: k.fma(e[i], Neg(dsts[i]), yi[i], 1.0))
+    _each(n, lambda i: k.fma(yi[i], e[i], yi[i], yi[i]))
+    k.free(h, e)
+
+
 # ------------------------------------------------------------------------------------------------------------------ exp
 def exp_core(m, dsts, xcs):
     """phf_exp_core_k on arguments already clamped; xcs[i] is destroyed (it becomes r); dsts[i] may not alias xcs[i]"""
@@ -94,7 +142,7 @@ def exp_core(m, dsts, xcs):
     _each(n, lambda i: k.vop("v_lshlrev_b32_e32", ad[i], 3, t[i].lo()))
     _each(n, lambda i: k.vop("v_and_b32_e32", ad[i], Lit(0x1f8), ad[i]))
     tj = dsts
-    _each(n, lambda i: k.ds_read(tj[i], ad[i], EXP2_OFF))
+    _each(n, lambda i: k.ds_read(tj[i], ad[i], m.off["exp2"]))
     r = xcs
     _each(n, lambda i: k.fma(r[i], nd[i], c["NLN2HI64"], xcs[i]))
     _each(n, lambda i: k.fma(r[i], nd[i], c["NLN2LO64"], r[i]))
@@ -143,7 +191,7 @@ def log_pos(m, dsts, xs):
     _each(n, lambda i: k.vop("v_add_u32_e32", ad[i], Lit(0x1000 - (LOG_TAB_BASE << 13)), u[i].hi()))
     _each(n, lambda i: k.vop("v_lshrrev_b32_e32", ad[i], 9, ad[i]))
     _each(n, lambda i: k.vop("v_and_b32_e32", ad[i], Lit(0x7ffff0), ad[i]))
-    _each(n, lambda i: k.ds_read(tab[i], ad[i], LOG_OFF))
+    _each(n, lambda i: k.ds_read(tab[i], ad[i], m.off["log"]))
     dk = [k.vd() for _ in range(n)]
     _each(n, lambda i: k.cvt_f64_i32(dk[i], e[i]))
     r = u
@@ -186,7 +234,7 @@ def erfc_tab(m, dsts, ys):
     _each(n, lambda i: k.vop("v_min_u32_e32", ad[i], ERFC_TAB_N - 1, t[i].lo()))
     _each(n, lambda i: k.vop("v_mul_u32_u24_e32", ad[i], Lit(96), ad[i]))
     for j in (5, 4, 3, 2, 1, 0):
-        _each(n, lambda i: k.ds_read(tab[i][j], ad[i], ERFC_OFF + 16 * j))
+        _each(n, lambda i: k.ds_read(tab[i][j], ad[i], m.off["erfc"] + 16 * j))
     _each(n, lambda i: k.add(t[i], t[i], Neg(c["MAGICV"])))
     _each(n, lambda i: k.fma(s[i], t[i], Neg(c["QUARTER"]), ys[i]))
     p = t
@@ -199,6 +247,37 @@ def erfc_tab(m, dsts, ys):
         k.cnd32_vcc(dsts[i].lo(), 0, p[i].lo())
         k.cnd32_vcc(dsts[i].hi(), 0, p[i].hi())
     k.free(t, s, ad, tab)
+
+
+# ------------------------------------------------------------------------------------------------------------------ log Phi table
+def log_ndtr_tab(m, dsts, xs):
+    """phf_log_ndtr_tab(x, y = -x / sqrt 2): log Phi(x) for x <= 0 from the table; xs kept; dsts[i] may not alias xs[i]"""
+    k, c = m.k, m.c
+    n = len(xs)
+    y = [k.vd() for _ in range(n)]
+    vb = [k.vd() for _ in range(n)]
+    ad = [k.v1() for _ in range(n)]
+    tab = [[k.vq() for _ in range(5)] for _ in range(n)]
+    _each(n, lambda i: k.mul(y[i], Neg(xs[i]), c["ISQRT2"]))                  # y = -x * (1 / sqrt 2)
+    _each(n, lambda i: k.add(vb[i], y[i], 1.0))
+    # jr = (hi >> 17) - (0x3ff << 3), clamped below 136 (unsigned: a negative jr is huge); 80 bytes per interval
+    _each(n, lambda i: k.vop("v_lshrrev_b32_e32", ad[i], 17, vb[i].hi()))
+    _each(n, lambda i: k.vop("v_add_u32_e32", ad[i], Lit(-(0x3ff << 3)), ad[i]))
+    _each(n, lambda i: k.vop("v_min_u32_e32", ad[i], Lit(LOGPHI_TAB_N - 1), ad[i]))
+    _each(n, lambda i: k.vop("v_mul_u32_u24_e32", ad[i], Lit(80), ad[i]))
+    for j in (4, 3, 2, 1, 0):
+        _each(n, lambda i: k.ds_read(tab[i][j], ad[i], m.off["logphi"] + 16 * j))
+    _each(n, lambda i: k.vop("v_bfi_b32", vb[i].hi(), c["MANTHI"], vb[i].hi(), c["ONEHI"]))
+    sft = vb
+    _each(n, lambda i: k.add(sft[i], vb[i], -1.0))
+    cf = lambda i, j: tab[i][j // 2].sub(2 * (j % 2))
+    gq = y
+    _each(n, lambda i: k.fma(gq[i], cf(i, 9), sft[i], cf(i, 8)))
+    for j in range(7, -1, -1):
+        _each(n, lambda i, j=j: k.fma(gq[i], gq[i], sft[i], cf(i, j)))
+    _each(n, lambda i: k.mul(sft[i], xs[i], -0.5))                            # -0.5 * x
+    _each(n, lambda i: k.fma(dsts[i], sft[i], xs[i], gq[i]))
+    k.free(y, vb, ad, tab)
 
 
 # ------------------------------------------------------------------------------------------------------------------ normals, uniforms
@@ -214,7 +293,7 @@ def normal_u32(m, dsts, ws):
     _each(n, lambda i: k.vop("v_lshrrev_b32_e32", ad[i], 19, ab[i].hi()))
     _each(n, lambda i: k.vop("v_mad_u32_u24", ad[i], ad[i], 48, c["NORMBIAS"]))               # 48 (j + 2046) - 48 * 2046 (an SGPR)
     for j in (2, 1, 0):
-        _each(n, lambda i: k.ds_read(tab[i][j], ad[i], NORMAL_OFF + 16 * j))
+        _each(n, lambda i: k.ds_read(tab[i][j], ad[i], m.off["normal"] + 16 * j))
     _each(n, lambda i: k.vop("v_bfi_b32", ab[i].hi(), c["MANTHI"], ab[i].hi(), c["ONEHI"]))    # mantissa bits under the exponent of 1.0
     sft = ab
     _each(n, lambda i: k.add(sft[i], ab[i], -1.0))
