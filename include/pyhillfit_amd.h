@@ -78,7 +78,7 @@ typedef struct phf_problems {
   const double* temperature;     /* device [Q]  power the likelihood is raised to */
   const uint32_t* problem_id;    /* device [Q]  global problem number (Philox counter word 1) */
   uint32_t chain_id_base;        /* global number of local chain 0 (Philox counter word 0) */
-  uint32_t kernel_hint;          /* hierarchical launches (ABI 5; was `reserved`; single-level: 0, or bit 4 as below): which kernel THIS launch
+  uint32_t kernel_hint;          /* hierarchical launches (ABI 5; was `reserved`; single-level: 0, bit 4 or bit 5 (phf_single_level_last_kernel)): which kernel THIS launch
                                     should get — bits 0-1 lanes per chain (1 | 2), bits 2-3 register build of the two-lane kernel (1 | 2
                                     wavefronts per SIMD), bit 4 (ABI 6) = 1: not the gfx950 assembly build of the Ne = 3 iteration (A/B timing,
                                     bit-identity tests); 0 = the library decides from the launch size.  A host that runs several
@@ -145,9 +145,9 @@ int phf_single_level_advance(const phf_points* pts, const phf_problems* prob, co
                              double* moments, int64_t moments_after, void* stream);
 
 /* Which kernel the calling thread's last phf_single_level_advance[_queued] launched (ABI 6; 0 = none yet): 1 = mh_advance_kernel (hipcc),
- * 2 = phf_sl3_advance, the hand-allocated gfx950 build of the model-2 iteration (launches without moments, more than one wavefront per
- * SIMD, at most 32 entries per pair; phf_problems.kernel_hint bit 4 or PHF_SL_ISA=0 in the environment select the hipcc kernel: same
- * numbers bit for bit), 3 = the same as a work queue. */
+ * 2 = phf_sl3_advance, the hand-allocated gfx950 build of the model-2 iteration — OPT-IN (phf_problems.kernel_hint bit 5, or PHF_SL_ISA=1
+ * in the environment; bit 4 vetoes it): launches without moments, more than one wavefront per SIMD, at most 32 entries per pair; same
+ * numbers bit for bit, not faster than the hipcc kernel (why: DESIGN.md section 3) —, 3 = the same as a work queue. */
 int phf_single_level_last_kernel(void);
 
 /* The same advance as a WORK QUEUE inside one launch (ABI 3).  The launch is cut into quanta of `quantum` iterations; the grid is

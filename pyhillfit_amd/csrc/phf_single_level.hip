@@ -549,11 +549,15 @@ static int advance_impl(const phf_points* pts, const phf_problems* prob, const p
       grid_blocks = slots;
     }
   }
-  // The hand-allocated gfx950 build of the model-2 iteration (phf_hier3_isa.hip: phf_sl3_advance; tools/gen_sl_isa_main.py): launches that
-  // do not ask for moments, give more than one wavefront per SIMD and whose pairs have at most PHF_ISA_SL_MAX_STRIDE entries; plain or
-  // queued exactly as decided above.  kernel_hint bit 4 or PHF_SL_ISA=0 (read once) select the hipcc kernels: same numbers bit for bit.
-  static const bool isa_on = [] { const char* e = getenv("PHF_SL_ISA"); return !(e && e[0] == '0' && e[1] == 0); }();
-  if (cfg->model == 2 && !moments && !lone && isa_on && !(prob->kernel_hint & 16u) && pts->stride <= PHF_ISA_SL_MAX_STRIDE &&
+  // The hand-allocated gfx950 build of the model-2 iteration (phf_hier3_isa.hip: phf_sl3_advance; tools/gen_sl_isa_main.py): OPT-IN —
+  // kernel_hint bit 5 per launch, or PHF_SL_ISA=1 in the environment (read once) — for launches that do not ask for moments, give more
+  // than one wavefront per SIMD and whose pairs have at most PHF_ISA_SL_MAX_STRIDE entries; plain or queued exactly as decided above.
+  // Same numbers bit for bit.  Not the default because it is not faster: 487 vector instructions per iteration against hipcc's 510, 126
+  // registers (four wavefronts per SIMD) against 256 — and 311 ms against 304 per 24 000 C3 iterations: both builds keep the vector pipe
+  // ~100 % busy, 74 % of its cycles on the 360 fp64 instructions the twin's operation sequence fixes (4 cycles each); what the hand
+  // allocation removes are 2-cycle integer instructions and copies (profiles/r05/c3_assembly_kernel.txt).
+  static const bool isa_on = [] { const char* e = getenv("PHF_SL_ISA"); return e && e[0] == '1' && e[1] == 0; }();
+  if (cfg->model == 2 && !moments && !lone && (isa_on || (prob->kernel_hint & 32u)) && !(prob->kernel_hint & 16u) && pts->stride <= PHF_ISA_SL_MAX_STRIDE &&
       cfg->adapt_start >= 0 && t_end < 0xffffffffLL && nblocks <= 0x7fffffffLL && phf_sl3_isa_available()) {
     phf_sl3_isa_args g{};
     g.state = state; g.rows = rows; g.gamma = cfg->gamma;
@@ -578,7 +582,10 @@ static int advance_impl(const phf_points* pts, const phf_problems* prob, const p
     }
     if (ok) {
       g_last_sl_kernel = a.queue ? 3 : 2;
-      return phf_sl3_isa_advance(&g, (int)grid_blocks, s);
+      // 126 VGPRs: FOUR wavefronts per SIMD — a queued launch's persistent grid is that large (the hipcc kernels': two per SIMD)
+      const int64_t isa_slots = 4LL * phf_simd_count();
+      const int64_t grid_waves = a.queue ? (nblocks < isa_slots ? nblocks : isa_slots) : nblocks;
+      return phf_sl3_isa_advance(&g, (int)grid_waves, s);
     }
   }
   g_last_sl_kernel = 1;

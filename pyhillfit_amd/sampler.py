@@ -156,10 +156,11 @@ class SingleLevelSampler(object):
         self.row0 = None
         self._gamma = None
 
-    def set_kernel_hint(self, isa=True):
-        """isa=False: this sampler's launches run the hipcc kernel where they would run the hand-allocated gfx950 build of the model-2
-        iteration (phf_problems.kernel_hint bit 4).  Same numbers bit for bit; for A/B timing and the bit-identity tests."""
-        self.prob.kernel_hint = 0 if isa else 16
+    def set_kernel_hint(self, isa=False):
+        """isa=True: this sampler's launches run the hand-allocated gfx950 build of the model-2 iteration where they are eligible
+        (phf_problems.kernel_hint bit 5; opt-in: it is bit-identical but not faster than the hipcc kernel, DESIGN.md section 3);
+        isa=False: the hipcc kernel, even with PHF_SL_ISA=1 in the environment (bit 4).  For A/B timing and the bit-identity tests."""
+        self.prob.kernel_hint = 32 if isa else 16
 
     def last_kernel(self):
         """which kernel this thread's last advance launched (phf_single_level_last_kernel): 1 hipcc, 2 gfx950 assembly, 3 the same queued"""

@@ -157,39 +157,57 @@ class Kernel(object):
         self.prog = []                      # instruction records in program order; text, waits and hazards come from finalize()
         self._streams = None                # inside parallel(): the instruction lists being filled
         self._deferred = None               # inside parallel(): registers freed by the streams, returned to the pools at the end
+        self._stream_free = self._stream_owned = self._stream_regs = None
 
     # ---- registers ----
+    def _alloc(self, pool, n, align=None):
+        """inside a parallel region a stream first re-uses what IT has freed (another stream's freed registers are off limits until the
+        region ends: the merge interleaves the streams, so their lifetimes overlap whatever the order they were written in)"""
+        if self._deferred is not None and self._streams:
+            own = self._stream_free[len(self._streams) - 1]
+            for i, r in enumerate(own):
+                if r.file == pool.file and r.n == n and (align is None or r.idx % align == 0):
+                    return own.pop(i)
+            r = pool.alloc(n, align)
+            self._stream_owned[len(self._streams) - 1].add(id(r))
+            self._stream_regs[len(self._streams) - 1].append(r)
+            return r
+        return pool.alloc(n, align)
+
     def vd(self, n=1):
         """n fp64 VGPR pairs"""
-        r = [self.v.alloc(2) for _ in range(n)]
+        r = [self._alloc(self.v, 2) for _ in range(n)]
         self._note()
         return r[0] if n == 1 else r
 
     def v1(self):
-        r = self.v.alloc(1)
+        r = self._alloc(self.v, 1)
         self._note()
         return r
 
     def vq(self):
-        r = self.v.alloc(4, 2)
+        r = self._alloc(self.v, 4, 2)
         self._note()
         return r
 
     def sd(self):
-        return self.s.alloc(2)
+        return self._alloc(self.s, 2)
 
     def s1(self):
-        return self.s.alloc(1)
+        return self._alloc(self.s, 1)
 
     def sx(self, n):
-        return self.s.alloc(n, 4 if n >= 4 else 2)
+        return self._alloc(self.s, n, 4 if n >= 4 else 2)
 
     def free(self, *rs):
         for r in rs:
             if isinstance(r, (list, tuple)):
                 self.free(*r)
             elif self._deferred is not None:
-                self._deferred.append(r)
+                if self._streams and id(r) in self._stream_owned[len(self._streams) - 1]:
+                    self._stream_free[len(self._streams) - 1].append(r)      # allocated by this stream: this stream may have it again
+                else:
+                    self._deferred.append(r)
             elif r.file == "v":
                 self.v.release(r)
             else:
@@ -607,15 +625,22 @@ class _Parallel(object):
         assert self.k._streams is None, "parallel regions do not nest"
         self.k._streams = []
         self.k._deferred = []
+        self.k._stream_free, self.k._stream_owned, self.k._stream_regs = [], [], []
         return self
 
     def stream(self):
         self.k._streams.append([])
+        self.k._stream_free.append([])
+        self.k._stream_owned.append(set())
+        self.k._stream_regs.append([])
 
     def __exit__(self, et, ev, tb):
         k = self.k
         streams, deferred = k._streams, k._deferred
+        for own in k._stream_free:                   # what the streams freed of their own and did not take again goes back now
+            deferred.extend(own)
         k._streams, k._deferred = None, None
+        k._stream_free = k._stream_owned = k._stream_regs = None
         if et is not None:
             return False
         real = [[r for r in s if r["kind"] != "comment"] for s in streams]
