@@ -418,9 +418,11 @@ class Kernel(object):
         return self.emit("v_cndmask_b32_e64", [d], srcs, "valu", count="valu_int")
 
     def cnd32_vcc(self, d, f, t):
-        """d = VCC ? t : f, VOP2 form: f may be a 32-bit literal, an SGPR or a VGPR; t a VGPR"""
+        """d = VCC ? t : f; f: a VGPR or an inline constant, t: a VGPR.  VOP3 encoding: 64 v_cndmask_b32_e32 in a row measure ~20 cycles each
+        against 4 in this form (profiles/r05/gfx950_instruction_costs.txt); in the kernels the two encodings time the same"""
         assert isinstance(t, Reg) and t.file == "v"
-        return self.emit("v_cndmask_b32_e32", [d], [f, t, VCC], "valu", count="valu_int")
+        assert not isinstance(f, Lit) and not (isinstance(f, Reg) and f.file == "s"), "VCC is the constant-bus read; no VOP3 literals"
+        return self.emit("v_cndmask_b32_e64", [d], [f, t, VCC], "valu", count="valu_int")
 
     def cnd64(self, d, f, t, mask):
         """d = mask ? t : f (a double: two v_cndmask_b32); f / t: VGPR pairs, or a python float whose halves are inline constants"""

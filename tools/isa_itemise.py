@@ -24,6 +24,23 @@ CLASSES = [
 ]
 
 
+# Issue cost in cycles per wavefront instruction with two or more wavefronts per SIMD, measured (tools/isa_instr_cost.py,
+# profiles/r05/gfx950_instruction_costs.txt): quarter-rate estimates 16; the simple 32-bit VOP1 / VOP2 operations 2 — when encoded _e32 and
+# without a scalar-register operand (with one they measure 4) —; everything else, every VOP3 encoding included, 4.
+FAST_E32 = r"v_(mov_b32|add_u32|sub_u32|subrev_u32|and_b32|or_b32|xor_b32|not_b32|lshrrev_b32|ashrrev_i32|accvgpr_read_b32|accvgpr_write_b32|fma_f32|add_f32|mul_f32)_e32"
+
+
+def issue_cycles(line):
+    op = line.split()[0]
+    if re.match(r"v_(rcp|rsq|sqrt)_f64", op):
+        return 16
+    if op.startswith("v_accvgpr") or re.fullmatch(FAST_E32, op):
+        operands = line.split(None, 1)[1] if " " in line else ""
+        if not re.search(r"\bs\d+|\bs\[|\bvcc|\bexec|\bm0", operands):
+            return 2
+    return 4
+
+
 # pairs of the Crumb set per (uncensored entries, censored entries) after merging replicates (pyhillfit_amd.doseresponse.pack_single_level)
 SHAPE_WEIGHTS = [((4, 1), 45), ((4, 0), 41), ((4, 2), 25), ((4, 4), 22), ((4, 3), 13), ((3, 4), 11), ((2, 4), 9), ((3, 3), 7), ((1, 4), 6),
                  ((2, 3), 5), ((2, 2), 5), ((3, 2), 4), ((3, 1), 3), ((1, 3), 3), ((2, 1), 3), ((2, 0), 1)]
@@ -78,12 +95,20 @@ def main():
                     c["other VALU: " + op] += 1
             valu = sum(v for k_, v in c.items() if not k_.startswith("(not VALU)"))
             fp = sum(1 for l in body if re.match(r"v_(fma|fmac|mul|add)_f64", l.split()[0]))
+            cyc = collections.Counter()
+            for l in body:
+                if l.startswith("v_"):
+                    cyc["fp64 fma / mul / add" if re.match(r"v_(fma|fmac|mul|add)_f64", l) else "quarter-rate estimates" if issue_cycles(l) == 16 else
+                        "2-cycle 32-bit operations" if issue_cycles(l) == 2 else "other 4-cycle instructions"] += issue_cycles(l)
+            c["(issue cycles)"] = cyc
             rows.append((valu, fp, a, b, c))
         # which entry-count shape a body is (single-level kernels): LDS reads = 13 + uncensored entries + 6 x censored entries
         # (one 2^(j/64) read per entry; five 16-byte reads of the log Phi table per censored entry; 13 for the draws and the logarithms)
         weights = dict(SHAPE_WEIGHTS) if len(sys.argv) > 3 and sys.argv[3] == "crumb" else {}
         tot, wsum = collections.Counter(), 0
-        for valu, fp, a, b, c in sorted(rows):
+        cyc_tot = collections.Counter()
+        for valu, fp, a, b, c in sorted(rows, key=lambda r: r[:4]):
+            cyc = c.pop("(issue cycles)")
             lds = c.get("(not VALU) LDS", 0)
             shape = next(((ko, kc) for ko in range(1, 5) for kc in range(0, 5) if 13 + ko + 6 * kc == lds), None)
             w = weights.get(shape, 0)
@@ -92,6 +117,9 @@ def main():
             for k_, v in sorted(c.items(), key=lambda kv: (kv[0].startswith("(not VALU)"), -kv[1])):
                 print("     %5d  %s" % (v, k_))
                 tot[k_] += v * w
+            print("     issue cycles of the vector pipe per wavefront: %d = %s" % (sum(cyc.values()), ", ".join("%d %s" % (v, k_) for k_, v in cyc.most_common())))
+            for k_, v in cyc.items():
+                cyc_tot[k_] += v * w
             wsum += w
         if wsum:
             print("\n  AVERAGE over the %d Crumb pairs whose shape has a straight-line body (weights = pairs per shape):" % wsum)
@@ -99,6 +127,9 @@ def main():
             print("     %7.1f  VALU in all" % valu)
             for k_, v in sorted(tot.items(), key=lambda kv: (kv[0].startswith("(not VALU)"), -kv[1])):
                 print("     %7.1f  %s" % (v / wsum, k_))
+            print("     issue cycles of the vector pipe per wavefront and iteration (measured cost per instruction: tools/isa_instr_cost.py): %.0f" % (sum(cyc_tot.values()) / wsum))
+            for k_, v in cyc_tot.most_common():
+                print("     %7.0f  %s" % (v / wsum, k_))
 
 
 if __name__ == "__main__":
