@@ -31,11 +31,21 @@ the same number each, pooled with their seeds 301, 302 —; the test then holds 
 scatter is what says how well the reference itself knows a heavy-tailed mean), and whatever still lies outside is REPORTED, not reseeded
 again.
 
+G10e (--replication, round 5; THIS RULE WAS COMMITTED BEFORE ANY OF ITS RUNS EXISTED): G10d was a second look at pairs that had failed, and the
+width bar was widened in the same commit (20 % -> 20 % + 4 standard errors of the reference's pooled sd) — VERDICT r04 weak #2.  The clean
+replication: the three pairs whose GPU width in the round-4 comparison against their ten reference seeds still lay beyond the PLAIN [0.8, 1.2]
+band (REPLICATION below: sd ratios 1.48, 1.42, 1.33 in gpurun_out/g10c_report.json), 48 FRESH seeds each (401..448), the reference's own length.
+The test (tests/test_gpu_hierarchical.py) holds a fresh GPU run (seed 2027, not used before) to the 48 fresh seeds ALONE — not pooled with
+seeds 301, 302, 311..318 — under the bar exactly as it stands in the tree at this commit: every column's mean within 1 % + 4 standard errors,
+its sd within 20 % + 4 standard errors of the reference's pooled sd (which 48 seeds make ~2.2 x narrower than ten did), acceptance within 0.02.
+Whatever fails is a finding about the sampler to chase, not a pair to name, and no further seeds are added.
+
 TEST INFRASTRUCTURE, generator side only (needs /root/reference; 18 runs of 3-6 minutes spread over worker processes).
     python tests/golden/make_golden_posteriors_hier.py [--iterations 500000] [--seeds 3] [--workers 7]
     python tests/golden/make_golden_posteriors_hier.py --per-drug [--workers 5]          (60 runs of 4-8 minutes)
     python tests/golden/make_golden_posteriors_hier.py --all-remaining [--workers 7]     (348 runs: ~4 hours on 7 cores)
     python tests/golden/make_golden_posteriors_hier.py --follow-up [--workers 7]         (64 runs: ~50 minutes)
+    python tests/golden/make_golden_posteriors_hier.py --replication [--workers 6]       (144 runs: ~95 minutes)
 """
 import argparse
 import contextlib
@@ -65,6 +75,10 @@ PAIRS = [("Amiodarone", "hERG"),          # Ne = 3: 4+4+4 points, informative
 FOLLOW_UP = [("Azithromycin", "Kir2.1"), ("Mexiletine", "Nav1.5-peak"), ("Moxifloxacin", "Cav1.2"), ("Nilotinib", "Kir2.1"),
              ("Ondansetron", "Kir2.1"), ("Propafenone", "Kir2.1"), ("Ranolazine", "Cav1.2"), ("Dofetilide", "Cav1.2")]
 FOLLOW_UP_SEEDS = tuple(range(311, 319))
+
+# G10e: the pre-registered replication (see the docstring): the pairs beyond the plain width band after G10d, 48 fresh seeds each
+REPLICATION = [("Azithromycin", "Kir2.1"), ("Ranolazine", "Cav1.2"), ("Dofetilide", "Cav1.2")]
+REPLICATION_SEEDS = tuple(range(401, 449))
 
 NB = 25                                   # batches for the batch-means standard error
 
@@ -115,6 +129,7 @@ def main():
     ap.add_argument("--per-drug", action="store_true", help="G10b: one pair of every drug (rule in the docstring), seeds 201, 202")
     ap.add_argument("--all-remaining", action="store_true", help="G10c: every pair in neither G10 nor G10b, seeds 301, 302 (resumable)")
     ap.add_argument("--follow-up", action="store_true", help="G10d: the FOLLOW_UP pairs, seeds 311..318 (resumable)")
+    ap.add_argument("--replication", action="store_true", help="G10e: the REPLICATION pairs, 48 fresh seeds 401..448 (resumable)")
     a = ap.parse_args()
     import _ref_loader as R
     import make_golden as G
@@ -128,6 +143,8 @@ def main():
     if a.follow_up:
         return all_remaining(a, dr, locs, pairs=list(FOLLOW_UP), seeds=FOLLOW_UP_SEEDS, tag="g10d", fixture="g10d_hier_posteriors_follow_up.json",
                              keep_quantiles=True)
+    if a.replication:
+        return all_remaining(a, dr, locs, pairs=list(REPLICATION), seeds=REPLICATION_SEEDS, tag="g10e", fixture="g10e_hier_posteriors_replication.json")
     if a.per_drug:
         drugs, channels = list(dr.drugs), list(dr.channels)
         chosen = []
