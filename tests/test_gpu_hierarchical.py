@@ -463,6 +463,24 @@ def test_hierarchical_posterior_of_every_remaining_pair_matches_the_reference_lo
     assert not failures, failures                                   # no pair, no column excepted
 
 
+def test_g10e_replication_of_the_widest_pairs_against_48_fresh_reference_seeds(gpu, dr_setup):
+    """Golden G10e (make_golden_posteriors_hier.py --replication; rule AND this test committed before any of its runs existed): the three
+    pairs whose GPU width still lay beyond the plain [0.8, 1.2] band against their ten reference seeds in round 4 — 48 FRESH seeds each
+    (401..448), a GPU seed not used before, the 48 seeds ALONE, the helper's bar exactly as it stands (mean 1 % + 4 s.e., sd 20 % + 4 s.e. of
+    the reference's pooled sd — ~2.2 x narrower with 48 seeds than with ten —, acceptance 0.02, and its fixture-level clause: at most 3 % of the
+    (pair, column) entries beyond the plain band).  No pair, no column excepted; nothing is topped up."""
+    path = os.path.join(GOLDEN, "g10e_hier_posteriors_replication.json")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated (tests/golden/make_golden_posteriors_hier.py --replication)")
+    with open(path) as f:
+        g10e = json.load(f)
+    assert [(e["drug"], e["channel"]) for e in g10e] == [("Azithromycin", "Kir2.1"), ("Ranolazine", "Cav1.2"), ("Dofetilide", "Cav1.2")]
+    assert all([r["seed"] for r in e["runs"]] == list(range(401, 449)) for e in g10e)
+    failures = []
+    _hier_posteriors_against_reference_loop(gpu, dr_setup, g10e, 512, 2027, "g10e", failures=failures)
+    assert not failures, failures
+
+
 def test_all_pairs_alpha_mu_against_the_reference_stored_samples(gpu):
     """every Crumb pair at the reference's run length (500 000 iterations, first quarter dropped), 128 chains each: pooled
     posterior means of (alpha, mu) against the reference's own stored hierarchical samples (chaste/samples: 500 draws of ONE
