@@ -41,17 +41,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROAR
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 64 fp64 FMA lanes x 2 x 2.4 GHz (vector, non-MFMA)
 FP64_VALU_MEASURED_TFLOPS = 58.3  # tools/microbench.hip: v_fma_f64 saturates at 2.25 ns per wave-instruction per SIMD
 
-DEFAULT_CHAINS = {"c2": 65536, "c3": 4096, "c4": 1024, "c5": 1024, "s3": 1024}
+DEFAULT_CHAINS = {"c2": 65536, "c3": 4096, "c4": 1024, "c5": 1024, "s3": 1024, "s3h": 1024}
 # s3: SURVEY 8(d)'s synthetic scaling set (pyhillfit_amd/synthetic.py): P generated pairs, model 2; N > 1 splits ONE 1 680 x 4 096 batch
 S3_PAIRS, S3_STRONG_CHAINS = 1680, 4096
 # c3: 24 000 iterations per step = one queued launch of ~0.3 s (6 quanta of 4 000), so that the driver's 20 timed steps last > 6 s;
 # c4: 2 000 per step — the command line runs 20 000 per launch, and at 500 a third of the HBM traffic was the state going in and out
-DEFAULT_ITERS = {"c2": 2000, "c3": 24000, "c4": 2000, "c5": 500, "s3": 4000}
+DEFAULT_ITERS = {"c2": 2000, "c3": 24000, "c4": 2000, "c5": 500, "s3": 4000, "s3h": 2000}
 # (timed steps, warm-up steps) of the short regions after the headline; each region lasts 0.1 .. 0.5 s
 # (steps, warm-up) of the short regions: every one of them at least half a second of timed work (c2 2.3 ms, c4 ~48, c5 ~50, s3 ~100,
 # c3 model 1 ~270 ms per step)
-OTHER_STEPS = {"c2": (250, 10), "c4": (12, 3), "c5": (12, 4), "c5_moments": (12, 4), "c3_model1": (3, 2), "s3": (6, 2)}
-OTHER_SPECS = {"c2": ("c2", 2, False), "c4": ("c4", 2, False), "c5": ("c5", 2, False), "s3": ("s3", 2, False),          # name -> (workload, model, moments)
+OTHER_STEPS = {"c2": (250, 10), "c4": (12, 3), "c5": (12, 4), "c5_moments": (12, 4), "c3_model1": (3, 2), "s3": (6, 2), "s3h": (3, 1)}
+OTHER_SPECS = {"c2": ("c2", 2, False), "c4": ("c4", 2, False), "c5": ("c5", 2, False), "s3": ("s3", 2, False), "s3h": ("s3h", 2, False),          # name -> (workload, model, moments)
                "c5_moments": ("c5", 2, True), "c3_model1": ("c3", 1, False)}
 
 
@@ -137,7 +137,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10, help="untimed steps before the timed ones (the first launches of a process run ~10 %% slow while the clocks settle)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "s3"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "s3", "s3h"])
     ap.add_argument("--pairs", type=int, default=None, help="s3: number of generated pairs (default %d; SURVEY 8(d): 210 or 1 680)" % S3_PAIRS)
     ap.add_argument("--strong-chains", type=int, default=None, help="N > 1, default c3 run: chains per pair of the S3 batch that the strong-scaling "
                     "region splits (default %d)" % S3_STRONG_CHAINS)
@@ -178,14 +178,16 @@ class HierarchicalBatch(object):
     units: None = every pair with chains [chain_id_base, chain_id_base + C); or this rank's (pair, 64-chain block) units
     (distributed.shard_blocks over all 210 pairs) — each block then is a problem of 64 chains with its own chain offset."""
     is_hier = True
-    kernel_name = "hier_advance_kernel<Ne=3..6> (one stream each; hier_advance2_kernel for groups that do not fill the chip together)"
+    kernel_name = ("phf_hier3_advance (hand-allocated gfx950 build: the pairs of 3 x 4 points) + hier_advance_kernel<Ne=3..6> for the other groups, "
+                   "one stream each (hier_advance2_kernel for groups that do not fill the chip together)")
 
-    def __init__(self, dr, names, C, thinning, chain_id_base, dev, torch, units=None):
+    def __init__(self, dr, names, C, thinning, chain_id_base, dev, torch, units=None, experiments=None):
+        """experiments: the pairs' experiments when they are not Crumb pairs (s3h: the generated set)"""
         from pyhillfit_amd import hierarchical as H
         self.torch, self.dev = torch, dev
         groups = {}
         for p, (d_, c_) in enumerate(names):
-            ne, _, ex = dr.load_crumb_data(d_, c_)
+            ex = dr.load_crumb_data(d_, c_)[2] if experiments is None else experiments[p]
             groups.setdefault(H.group_key(ex), []).append((p, ex))
         shapes, scales, locs = H.prior_params()
         self.samplers = []
@@ -210,6 +212,8 @@ class HierarchicalBatch(object):
         self.adapt_start = max(h.adapt_start for h in self.samplers)
         self.bytes_per_iter = sum(h.Q * h.C * 8.0 * (h.d + 1) for h in self.samplers) / thinning
         self.chains = sum(h.Q * h.C for h in self.samplers)
+        if len(self.samplers) == 1 and H.group_key is not None and all(H.group_key(ex) == (3, 4) for _, ms in groups.items() for _, ex in ms):
+            self.kernel_name = "phf_hier3_advance (hand-allocated gfx950 build of the Ne = 3 iteration, work queue)"
         H.hint_side_by_side(self.samplers)                 # the groups run side by side: one lane per chain once they fill the chip together
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.samplers]
 
@@ -317,6 +321,9 @@ def workload_label(workload, n_pairs, C, per, model=2):
     if workload == "s3":
         return ("synthetic scaling set S3 (SURVEY 8d; pyhillfit_amd/synthetic.py, seed 12345): %d generated pairs of 3 x 4 points, non-hierarchical %s, "
                 "%d chains each %s" % (n_pairs, m, C, per))
+    if workload == "s3h":
+        return ("synthetic scaling set S3 (SURVEY 8d), HIERARCHICAL model: %d generated pairs of 3 x 4 points, %d chains each %s — every pair has the "
+                "shape the hand-allocated gfx950 kernel takes: one launch per step, no mixing of Ne groups" % (n_pairs, C, per))
     if workload == "c5":
         return "thermodynamic-integration ladder: 32 rungs x %d pairs x %d chains %s, %s (BASELINE configs[4])" % (n_pairs, C, per, m)
     return ("hierarchical model, all %d Crumb pairs, %d chains each %s (BASELINE configs[3]); one stream per Ne group, "
@@ -330,18 +337,24 @@ def make_batch(workload, scaling, C, a, ctx):
     dr, D, torch, dev, rank, world = ctx["dr"], ctx["D"], ctx["torch"], ctx["dev"], ctx["rank"], ctx["world"]
     all_names = [(d, c) for d in dr.drugs for c in dr.channels]
     names = [("Amiodarone", "hERG")] if workload == "c2" else all_names
-    if workload == "s3":
+    if workload in ("s3", "s3h"):
         names = [("synthetic", str(p)) for p in range(a.pairs or S3_PAIRS)]
     strong = scaling == "strong" and world > 1
     chain_id_base = 0 if scaling == "strong" else rank * C
-    if workload == "c4":
-        units = None
+    if workload in ("c4", "s3h"):
+        units, exs = None, None
+        if workload == "s3h":                                         # generated, deterministic (seed 12345): every rank makes the same set
+            from pyhillfit_amd import synthetic
+            exs = synthetic.generate(len(names))[0]
         if strong:
             if C % 64:
                 raise SystemExit("bench.py: --scaling strong splits a batch by 64-chain blocks: --chains must be a multiple of 64")
-            costs = [len(dr.concatenate_experiments(*dr.load_crumb_data(d_, c_)[::2])[0]) + 20.0 * len(dr.load_crumb_data(d_, c_)[2]) for d_, c_ in names]
+            if exs is None:
+                costs = [len(dr.concatenate_experiments(*dr.load_crumb_data(d_, c_)[::2])[0]) + 20.0 * len(dr.load_crumb_data(d_, c_)[2]) for d_, c_ in names]
+            else:
+                costs = [sum(len(e) for e in ex) + 20.0 * len(ex) for ex in exs]
             units = D.shard_blocks(costs, C // 64, world)[rank]
-        b = HierarchicalBatch(dr, names, C, a.thinning, chain_id_base, dev, torch, units=units)
+        b = HierarchicalBatch(dr, names, C, a.thinning, chain_id_base, dev, torch, units=units, experiments=exs)
     else:
         if workload == "s3":                                          # generated, deterministic: rank 0 makes it, the others get it by broadcast
             from pyhillfit_amd import synthetic
@@ -364,7 +377,7 @@ def make_batch(workload, scaling, C, a, ctx):
             units = D.shard_blocks(costs, C // 64, world)[rank]
         b = SingleLevelBatch(packed, pair_index, temps, C, a, chain_id_base, dev, torch, workload == "c5", units=units)
     b.label = workload_label(workload, len(names), C, "in all, split by 64-chain blocks over the GPUs" if scaling == "strong" else "per GPU",
-                             2 if workload == "c4" else a.model)
+                             2 if workload in ("c4", "s3h") else a.model)
     if a.moments:
         b.enable_moments()
         b.label += " + on-device moments and <log L(t=1)> (the sums the command lines and compute_bayes_factors.py:11-27 need)"
@@ -373,7 +386,7 @@ def make_batch(workload, scaling, C, a, ctx):
 
 def facts_key(workload, a):
     """the entry of profiles/pmc_facts.json a launch shape goes by: c2 | c3 | c4 | c5, + _model1 / _moments for the other kernels"""
-    return workload + ("_model1" if a.model == 1 and workload != "c4" else "") + ("_moments" if a.moments else "")
+    return workload + ("_model1" if a.model == 1 and workload not in ("c4", "s3h") else "") + ("_moments" if a.moments else "")
 
 
 def timed_region(b, I, steps, warmup, ctx):
@@ -501,7 +514,7 @@ def main():
             "metric": "MCMC samples/sec (whole node)", "value": chains_total * I * a.steps / dt, "unit": "MH samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
-            "data": ("synthetic dose-response rows (SURVEY 8d S3, pyhillfit_amd/synthetic.py), synthetic chain batch" if a.workload == "s3"
+            "data": ("synthetic dose-response rows (SURVEY 8d S3, pyhillfit_amd/synthetic.py), synthetic chain batch" if a.workload in ("s3", "s3h")
                      else "real Crumb dose-response rows (data/crumb_dataset.json), synthetic chain batch"),
             "config": {"workload": b.label, "iterations_per_step": I, "thinning": a.thinning, "chains_per_gpu": b.chains,
                        "chains_all_gpus": chains_total,
@@ -536,7 +549,7 @@ def main():
     if world == 1 and a.workload == "c3" and a.chains is None and a.iters_per_step is None and not a.no_other_workloads \
             and a.model == 2 and not a.moments:
         others = {}
-        for name in ("c2", "c4", "c5", "c5_moments", "c3_model1", "s3"):
+        for name in ("c2", "c4", "c5", "c5_moments", "c3_model1", "s3", "s3h"):
             w, model_w, moments_w = OTHER_SPECS[name]
             aw = argparse.Namespace(**vars(a))
             aw.model, aw.moments = model_w, moments_w

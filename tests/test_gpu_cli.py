@@ -210,8 +210,12 @@ def test_bench_default_line_carries_the_other_configurations():
     assert d["value"] == pytest.approx(210 * 4096 * d["config"]["iterations_per_step"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
     assert d["ms_per_step"] * d["steps"] > 300              # a timed region of the default size is no blink
     ow = d["other_workloads"]
-    assert sorted(ow) == ["c2", "c3_model1", "c4", "c5", "c5_moments", "s3"]
+    assert sorted(ow) == ["c2", "c3_model1", "c4", "c5", "c5_moments", "s3", "s3h"]
     assert "synthetic scaling set S3" in ow["s3"]["workload"] and ow["s3"]["chains"] == 1680 * 1024 and ow["s3"]["value"] > 1e10
+    # the hierarchical model on the same generated set: every pair has the shape of the hand-allocated gfx950 kernel, one launch per step —
+    # per block of 64 chains faster than the Crumb mix of C4, whose other Ne groups run through hipcc kernels beside it
+    assert "HIERARCHICAL" in ow["s3h"]["workload"] and ow["s3h"]["chains"] == 1680 * 1024 and ow["s3h"]["kernel"].startswith("phf_hier3_advance")
+    assert ow["s3h"]["value"] > 1.05 * ow["c4"]["value"]
     assert all(e["ms_per_step"] * e["steps"] >= 450 for e in ow.values()), {k: e["ms_per_step"] * e["steps"] for k, e in ow.items()}   # >= ~0.5 s each
     assert "model 1" in ow["c3_model1"]["workload"] and ow["c3_model1"]["kernel"].startswith("mh_advance_kernel<1")
     assert "moments" in ow["c5_moments"]["workload"] and ow["c5_moments"]["kernel"] == "mh_advance_kernel<2, moments>"

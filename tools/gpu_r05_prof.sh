@@ -1,17 +1,17 @@
 #!/bin/bash
-# Round-5 profiling pass: for every driver-timed region of bench.py (c3 headline, c2, c4, c5, c5_moments, c3_model1, s3) ONE
+# Round-5 profiling pass: for every driver-timed region of bench.py (c3 headline, c2, c4, c5, c5_moments, c3_model1, s3, s3h) ONE
 # `rocprofv3 --kernel-trace --stats` run and five `--pmc` passes (counters only, one set per run) of the same bench command,
 # summarised per kernel into gpurun_out/pmc_<name>_summary.txt; tools/collect_profiles.py copies them into profiles/r05/.
 # PHF_NAMES selects the regions (default all), PHF_STEPS what runs (stats pmc).
 set -u
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-NAMES="${PHF_NAMES:-c3 c2 c4 c5 c5_moments c3_model1 s3}"
+NAMES="${PHF_NAMES:-c3 c2 c4 c5 c5_moments c3_model1 s3 s3h}"
 STEPS="${PHF_STEPS:-stats pmc}"
 want() { [[ " $STEPS " == *" $1 "* ]]; }
 args_of() { case $1 in
   c3) echo "--workload c3";; c2) echo "--workload c2";; c4) echo "--workload c4";; c5) echo "--workload c5";;
-  c5_moments) echo "--workload c5 --moments";; c3_model1) echo "--workload c3 --model 1";; s3) echo "--workload s3";; esac; }
+  c5_moments) echo "--workload c5 --moments";; c3_model1) echo "--workload c3 --model 1";; s3) echo "--workload s3";; s3h) echo "--workload s3h";; esac; }
 step() { local name=$1 to=$2; shift 2
   timeout -k 10 "$to" "$@" > "$R/gpurun_out/$name.log" 2>&1; local rc=$?
   echo "$name rc=$rc $(grep -o '"ms_per_step": [0-9.]*' "$R/gpurun_out/$name.log" | head -1)"
