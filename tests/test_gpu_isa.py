@@ -127,6 +127,41 @@ def test_isa_advance_bit_identical_to_the_twin(gpu, oracle_pair):
             assert np.array_equal(state[:, q, c], st), (q, c)
 
 
+def test_isa_on_the_synthetic_set_bit_identical_to_the_hipcc_kernel_and_the_twin(gpu):
+    """bench.py --workload s3h in small: 48 pairs of SURVEY 8(d)'s generated set S3 (three experiments of four points, ~23 % of the
+    responses exactly 0 or 100: the censored ends of the hierarchical likelihood's truncated Gaussian on every pair) x 192 chains through
+    phf_hier3_advance and through the hipcc kernel — rows, state and moments bit for bit — and chains of three pairs against the twin"""
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H, synthetic
+    from pyhillfit_amd.sampler import gamma_table
+    exs = synthetic.generate(48)[0]
+    assert 0.15 < synthetic.censoring_rate(exs) < 0.35
+    shapes, scales, locs = H.prior_params()
+    start = np.array([H.first_iteration(e, locs) for e in exs])
+    C, T, thin, adapt = 192, 400, 5, 120
+    got = {}
+    for isa in (False, True):
+        s = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(len(exs))), C, thinning=thin, seed=31337, adapt_start=adapt, chain_id_base=5, device=gpu)
+        s.set_kernel_hint(lanes=1, isa=isa)
+        s.init(start, cov_scale=0.01)
+        s.enable_moments(after_iteration=adapt)
+        chain = np.concatenate([s.advance(k).cpu().numpy() for k in (adapt + 7, T - adapt - 7)])
+        assert H.last_kernel() == (4 if isa else 1)
+        got[isa] = (chain, s.state.cpu().numpy(), s.moments.cpu().numpy())
+    for name, a, b in zip(("rows", "state", "moments"), got[False], got[True]):
+        same = a.view(np.uint64) == b.view(np.uint64)
+        assert same.all(), (name, int((~same).sum()), np.argwhere(~same)[:5].tolist())
+    chain = got[True][0]
+    assert np.isfinite(chain).all()
+    gam = gamma_table(T)
+    for q in (0, 17, 47):
+        pk = co.PackedHierPair(exs[q], shapes, scales, locs)
+        for c in (0, C - 1):
+            st = pk.init_state(start[q], 0.01)
+            rows = pk.advance(st, 0, T, thin, adapt, gam, seed=31337, chain_id=5 + c, problem_id=q)
+            assert np.array_equal(chain[:, q, :, c], rows), (q, c)
+
+
 def test_isa_work_queue_bit_identical_at_full_width(gpu):
     """all 147 Crumb pairs with 3 x 4 points x 1 024 chains = 2 352 blocks on 2 048 wavefront slots: the launch runs as a work queue
     (quanta of 125 iterations, blocks chaining through their state in HBM) — rows, state and moments against the hipcc kernel's plain

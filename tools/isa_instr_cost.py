@@ -116,6 +116,11 @@ INSTR = [
     ("mix_fma_and", "v_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_and_b32_e32 v{d4}, v106, v107"),
     ("mix_fma_ds_read", "v_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tds_read_b64 v[{d4}:{d4b}], v108"),
     ("mix_4fma_ds_read", "v_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tds_read_b64 v[{d4}:{d4b}], v108"),
+    ("mix_fma_cnd_e32", "v_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_cndmask_b32_e32 v{d4}, v106, v107, vcc"),
+    ("mix_fma_cnd_e64", "v_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_cndmask_b32_e64 v{d4}, v106, v107, s[12:13]"),
+    ("mix_3fma_cnd_e32", "v_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_cndmask_b32_e32 v{d4}, v106, v107, vcc"),
+    ("mix_cmp_2cnd_e32_4fma", "v_cmp_lt_f64_e32 vcc, v[100:101], v[102:103]\n\tv_cndmask_b32_e32 v{d4}, v106, v107, vcc\n\tv_cndmask_b32_e32 v{d4b}, v106, v107, vcc\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]"),
+    ("mix_cmp_2cnd_e64_4fma", "v_cmp_lt_f64_e64 s[12:13], v[100:101], v[102:103]\n\tv_cndmask_b32_e64 v{d4}, v106, v107, s[12:13]\n\tv_cndmask_b32_e64 v{d4b}, v106, v107, s[12:13]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\tv_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]"),
     ("mix_fma_salu", "v_fma_f64 v[{d}:{d1}], v[100:101], v[102:103], v[104:105]\n\ts_mov_b32 s12, s8"),
     # pairs: a dependent chain inside ONE wavefront (latency, visible at one wavefront per SIMD)
     ("dep_fma_f64", "v_fma_f64 v[0:1], v[0:1], v[102:103], v[104:105]"),
