@@ -525,6 +525,8 @@ static int advance_impl(const phf_points* pts, const phf_problems* prob, const p
   if (!state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "null state");
   if (cfg->thinning <= 0) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "thinning must be positive");
   if (t_begin < 0 || t_end < t_begin || t_end > 0xffffffffLL) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad iteration range");
+  if (prob->kernel_hint & ~48u)
+    return phf_fail(PHF_ERR_INVALID_ARGUMENT, "kernel_hint of a single-level launch: bit 4 = the hipcc kernel, bit 5 = the gfx950 assembly build; the other bits must be 0");
   // gamma[0] is read (and multiplied by zero) on every iteration before the adaptation starts: the table is always needed
   if (!cfg->gamma) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "gamma table required (gamma[0] is read even before adaptation starts)");
   if (t_end == t_begin) return PHF_OK;

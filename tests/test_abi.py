@@ -79,6 +79,10 @@ def test_argument_validation_without_gpu(lib):
     assert b"kernel_hint" in lib.phf_last_error()
     prob.kernel_hint = 32
     assert lib.phf_hierarchical_advance(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
+    prob.kernel_hint = 64                                  # a single-level launch knows bits 4 and 5 only
+    pts.stride = 16
+    assert lib.phf_single_level_advance(C.byref(pts), C.byref(prob), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
+    assert b"kernel_hint of a single-level launch" in lib.phf_last_error()
     prob.kernel_hint = 16 | 1
     hp.points_per_expt = 7                                 # 3 experiments x 7 points do not fit a stride of 16
     assert lib.phf_hierarchical_advance(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
