@@ -247,6 +247,26 @@ def test_bench_two_ranks_default_strong_region_is_the_synthetic_s3_batch():
     assert d["strong_value"] == pytest.approx(210 * 256 * 400 * 2 / (sr["ms_per_step"] * 2e-3), rel=1e-6) and d["strong_value"] > 0
 
 
+def test_bench_two_ranks_split_the_hierarchical_synthetic_batch():
+    """`bench.py --gpus 2 --workload s3h` rehearsed on the one GPU (gloo): the weak value = two full batches of the hierarchical model on the
+    generated set, `strong_value` = ONE batch split by (pair, 64-chain block) units — every rank's share is one launch of the gfx950
+    assembly kernel (all generated pairs have three experiments of four points)"""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", "s3h", "--pairs", "96", "--chains", "256", "--steps", "2", "--warmup", "1",
+           "--iters-per-step", "400", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PHF_BENCH_BACKEND="gloo"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and "HIERARCHICAL" in d["config"]["workload"] and d["config"]["chains_all_gpus"] == 2 * 96 * 256
+    assert "synthetic dose-response rows" in d["data"] and d["roofline"]["kernel"].startswith("phf_hier3_advance")
+    sr = d["strong_region"]
+    assert sr["chains_all_gpus"] == 96 * 256 and abs(sr["chains_rank0"] - 96 * 128) <= 64
+    assert d["strong_value"] == pytest.approx(96 * 256 * 400 * 2 / (sr["ms_per_step"] * 2e-3), rel=1e-6) and d["strong_value"] > 0
+
+
 def test_bench_two_ranks_report_weak_and_strong_scaling():
     """`bench.py --gpus 2` rehearsed on the one GPU (gloo; RCCL refuses two ranks on a device): ONE JSON line with `value` (weak:
     every rank its own full batch) AND `strong_value` (one batch split by (pair, 64-chain block) units, distributed.shard_blocks)"""
