@@ -162,6 +162,72 @@ def test_isa_on_the_synthetic_set_bit_identical_to_the_hipcc_kernel_and_the_twin
             assert np.array_equal(chain[:, q, :, c], rows), (q, c)
 
 
+def test_isa_randomized_launch_shapes_bit_identical_to_the_hipcc_kernels(gpu):
+    """twelve seeded random launch shapes of the generated set — pairs, chains per pair (ragged last wavefronts, more blocks than the chip
+    has wavefront slots so that the work queue runs, fewer so that it does not), thinning, start of the adaptation, where the launches are
+    cut, start of the moments, per-problem chain offsets, a permuted launch order, tempered problems — through the hierarchical assembly
+    kernel and the hipcc one-lane kernel, and (model 2, no moments) through the single-level assembly kernel and the hipcc kernel: rows,
+    states, moments bit for bit, and the kernel meant is the kernel that ran"""
+    import torch
+    from pyhillfit_amd import doseresponse as dr, hierarchical as H, synthetic
+    from pyhillfit_amd.sampler import SingleLevelSampler
+    rng = np.random.default_rng(20261005)
+    shapes, scales, locs = H.prior_params()
+    for case in range(12):
+        P = int(rng.integers(1, 40))
+        exs = synthetic.generate(P, seed=1000 + case)[0]
+        C = int(rng.choice([1, 63, 64, 65, 130, 200, 256, 1000, 4096]))
+        thin = int(rng.choice([1, 2, 5, 7]))
+        adapt = int(rng.integers(0, 90))
+        cuts = [int(x) for x in rng.integers(1, 160, size=int(rng.integers(1, 4)))]
+        order = rng.permutation(P).astype(np.int32)
+        offsets = [int(x) * 64 for x in rng.integers(0, 5, size=P)]
+        seed = int(rng.integers(1, 2 ** 40))
+        mom_after = int(rng.integers(0, sum(cuts) + 1))
+        quanta = int(rng.choice([0, 3]))
+        temps = [float(t) for t in rng.choice([1.0, 0.5, 0.0], size=P)]
+        what = (case, P, C, thin, adapt, cuts, mom_after, quanta)
+        # ---- hierarchical
+        start = np.array([H.first_iteration(e, locs) for e in exs])
+        got = {}
+        for isa in (False, True):
+            s = H.HierarchicalSampler(H.PackedHierPoints(exs), list(range(P)), C, thinning=thin, seed=seed, adapt_start=adapt, chain_id_base=3,
+                                      chain_offsets=offsets, device=gpu)
+            s.launch_order = torch.tensor(order, device=gpu)
+            s.prob.launch_order = s.launch_order.data_ptr()
+            s.set_kernel_hint(lanes=1, isa=isa)
+            s.init(start, cov_scale=0.01)
+            s.enable_moments(after_iteration=mom_after)
+            parts, kernels = [], []
+            for k_ in cuts:
+                parts.append(s.advance(k_).cpu().numpy())
+                kernels.append(H.last_kernel())
+            got[isa] = (np.concatenate(parts), s.state.cpu().numpy(), s.moments.cpu().numpy(), kernels)
+        assert set(got[False][3]) == {1} and set(got[True][3]) <= {4, 5}, (what, got[False][3], got[True][3])
+        for name, a, b in zip(("rows", "state", "moments"), got[False][:3], got[True][:3]):
+            same = a.view(np.uint64) == b.view(np.uint64)
+            assert same.all(), ("hierarchical", what, name, int((~same).sum()))
+        # ---- single level, model 2
+        packed = dr.PackedPoints(synthetic.single_level_pairs(exs))
+        got = {}
+        for isa in (False, True):
+            s = SingleLevelSampler(packed, 2, list(range(P)), temps, C, thinning=thin, seed=seed, adapt_start=adapt, device=gpu, chain_id_base=3,
+                                   chain_offsets=offsets, queue_quanta=quanta, reset_mean_at_adapt_start=bool(case % 2))
+            s.set_kernel_hint(isa=isa)
+            s.init(np.array([6.0, 0.8, 8.0]), cov_identity=bool(case % 3 == 0), cov_scale=0.05)
+            parts, kernels = [], []
+            for k_ in cuts:
+                parts.append(s.advance(k_).cpu().numpy())
+                kernels.append(s.last_kernel())
+            got[isa] = (np.concatenate(parts), s.state.cpu().numpy(), kernels)
+        lone = P * ((C + 63) // 64) <= 1024                       # one wavefront per SIMD or fewer: the assembly build is not used (by design)
+        assert set(got[False][2]) == {1}, (what, got[False][2])
+        assert set(got[True][2]) == {1} if lone else bool({2, 3} & set(got[True][2])), (what, got[True][2])
+        for name, a, b in zip(("rows", "state"), got[False][:2], got[True][:2]):
+            same = a.view(np.uint64) == b.view(np.uint64)
+            assert same.all(), ("single level", what, name, int((~same).sum()))
+
+
 def test_isa_work_queue_bit_identical_at_full_width(gpu):
     """all 147 Crumb pairs with 3 x 4 points x 1 024 chains = 2 352 blocks on 2 048 wavefront slots: the launch runs as a work queue
     (quanta of 125 iterations, blocks chaining through their state in HBM) — rows, state and moments against the hipcc kernel's plain
