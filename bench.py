@@ -212,7 +212,7 @@ class HierarchicalBatch(object):
         self.adapt_start = max(h.adapt_start for h in self.samplers)
         self.bytes_per_iter = sum(h.Q * h.C * 8.0 * (h.d + 1) for h in self.samplers) / thinning
         self.chains = sum(h.Q * h.C for h in self.samplers)
-        if len(self.samplers) == 1 and H.group_key is not None and all(H.group_key(ex) == (3, 4) for _, ms in groups.items() for _, ex in ms):
+        if set(groups) == {(3, 4)}:                        # every pair has three experiments of four points (s3h): one launch of the assembly kernel
             self.kernel_name = "phf_hier3_advance (hand-allocated gfx950 build of the Ne = 3 iteration, work queue)"
         H.hint_side_by_side(self.samplers)                 # the groups run side by side: one lane per chain once they fill the chip together
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.samplers]
