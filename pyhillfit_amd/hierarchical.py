@@ -14,7 +14,7 @@ import torch
 
 from . import _lib, bestfit, chainio
 from . import doseresponse as dr
-from .sampler import _ptr, _stream_ptr, gamma_table
+from .sampler import _ptr, _stream_ptr, gamma_table, raise_if_drained
 
 # ---- Gamma hyper-priors: python/PyHillFit.py:301,340-364 (numbers from Elkins et al., as in the reference) ----------
 ELKINS_HILL_ALPHAS = np.array([1.188, 1.744, 1.530, 0.930, 0.605, 1.325, 1.179, 0.979, 1.790, 1.708, 1.586, 1.469,
@@ -265,10 +265,34 @@ class HierarchicalSampler(object):
         self.t = t_end
         return rows
 
+    def check_queue(self):
+        """The gfx950 assembly build's queued launches raise the workspace's sticky fault word (its last int32) when a wavefront gives
+        up waiting for its block's previous quantum: the launch drains and leaves stale chains behind a PHF_OK.  Read wherever the host
+        hands results on (acceptance, posterior_moments, state_dict, the end of a run) — PhfError instead of such results."""
+        raise_if_drained(self.queue, "hierarchical")
+
     def acceptance(self):
+        self.check_queue()
         return self.state[-1].view(self.Q, self.C) / max(self.t, 1)
 
+    def state_dict(self):
+        """the sampler's position (iteration count) and chain state, for a bit-identical continuation (load_state_dict)"""
+        self.check_queue()
+        return {"t": self.t, "state": self.state.clone(), "n_expts": self.n_expts, "chains": self.C, "problems": self.Q,
+                "philox_rounds": int(self.lib.phf_philox_rounds()), "abi_version": int(self.lib.phf_version())}
+
+    def load_state_dict(self, sd):
+        have = (int(self.lib.phf_philox_rounds()), int(self.lib.phf_version()))
+        got = (sd.get("philox_rounds"), sd.get("abi_version"))
+        if got != have:
+            raise _lib.PhfError("checkpoint written by generator / ABI %s, this library is %s: the chains would not continue bit-identically"
+                                % (got, have))
+        if (sd["n_expts"], sd["chains"], sd["problems"]) != (self.n_expts, self.C, self.Q):
+            raise ValueError("checkpoint of another batch shape")
+        self.state.copy_(sd["state"]); self.t = int(sd["t"])
+
     def posterior_moments(self):
+        self.check_queue()
         n = self.t // self.thinning - self.moments_after // self.thinning
         k = self.d + 1
         s1 = self.moments[:k].view(k, self.Q, self.C); s2 = self.moments[k:].view(k, self.Q, self.C)

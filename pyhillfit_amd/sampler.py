@@ -87,10 +87,10 @@ def queue_quantum(n_iterations, queue_quanta, thinning):
     return min(quantum, max(cap, thinning))
 
 
-def raise_if_drained(queue):
-    """queue: the int32 workspace of phf_single_level_advance_queued ([2 + blocks], last word = sticky fault flag) or None"""
+def raise_if_drained(queue, what="single-level"):
+    """queue: the int32 workspace of phf_{single_level,hierarchical}_advance_queued ([2 + blocks], last word = sticky fault flag) or None"""
     if queue is not None and int(queue[-1].item()) != 0:
-        raise _lib.PhfError("a queued single-level launch drained (a wavefront's wait for its block's previous quantum did not end): "
+        raise _lib.PhfError("a queued " + what + " launch drained (a wavefront's wait for its block's previous quantum did not end): "
                             "chains, moments and state written since are stale — discard them")
 
 

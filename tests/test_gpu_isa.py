@@ -264,6 +264,37 @@ def test_isa_work_queue_bit_identical_at_full_width(gpu):
         assert bool(same.all()), (name, int((~same).sum()))
 
 
+def test_hierarchical_drained_queue_raises_and_checkpoint_continues_bit_identically(gpu, oracle_pair):
+    """(i) the queue workspace's sticky fault word — which a wavefront of the assembly kernel raises when its wait for a block's previous
+    quantum does not end — reaches the host as PhfError at every point that hands results on (written here by hand, as such a launch would
+    leave it; the library never clears it); (ii) state_dict / load_state_dict: a second sampler continues a checkpoint bit for bit, and a
+    checkpoint of another generator / ABI is refused"""
+    import torch
+    from pyhillfit_amd import _lib
+    adapt = 140
+    s, _ = _setup(gpu, UNIFORM4, oracle_pair, 256, 5, adapt, 31337, True)
+    s.init(np.array(THETA0), cov_scale=0.01)
+    s.enable_moments(after_iteration=0)
+    s.advance(200, save=False)
+    s.acceptance(); s.posterior_moments()                                   # a healthy queue: no raise
+    sd = s.state_dict()
+    rows = s.advance(300).cpu().numpy()
+    s2, _ = _setup(gpu, UNIFORM4, oracle_pair, 256, 5, adapt, 31337, False)   # the continuation runs the hipcc kernel: same bits
+    s2.load_state_dict(sd)
+    rows2 = s2.advance(300).cpu().numpy()
+    assert _bits_equal(rows, rows2) and _bits_equal(s.state.cpu().numpy(), s2.state.cpu().numpy())
+    bad = dict(sd); bad["philox_rounds"] = 10 if sd["philox_rounds"] != 10 else 7
+    with pytest.raises(_lib.PhfError, match="bit-identically"):
+        s2.load_state_dict(bad)
+    s.queue[-1] = 1
+    s.advance(100, save=False)
+    torch.cuda.synchronize()
+    assert int(s.queue[-1].item()) == 1                                      # sticky
+    for call in (s.acceptance, s.posterior_moments, s.state_dict):
+        with pytest.raises(_lib.PhfError, match="drained"):
+            call()
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # phf_sl3_advance: the hand-allocated single-level model-2 iteration against the hipcc kernel and the scalar twin
 def _sl_runs(gpu, packed, Q, temps, C, thin, adapt, cuts, reset_mean=False, cov_identity=False, theta0=(6.0, 0.8, 8.0), queue_quanta=4, **kw):
