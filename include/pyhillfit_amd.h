@@ -201,10 +201,13 @@ typedef struct phf_hier_points {
   int32_t num_pairs;          /* P */
   int32_t stride;             /* doubles per pair row in ln_conc/response */
   int32_t n_expts;            /* Ne, the same for every pair of this set */
-  int32_t points_per_expt;    /* ABI 6 (was `reserved`): n > 0 = EVERY experiment of EVERY pair of this set has exactly n points (the caller's
-                                 statement about its data, like n_expts; expt_start must say the same); 0 = experiments differ, or unknown.
-                                 With n_expts == 3 and points_per_expt == 4 (147 of the Crumb set's 210 pairs) launches that get one lane
-                                 per chain run the hand-allocated gfx950 build of the iteration (two wavefronts per SIMD): same numbers. */
+  int32_t points_per_expt;    /* ABI 6 (was `reserved`): the point SHAPE of every pair of this set, the caller's statement about its data (like
+                                 n_expts; expt_start must say the same): per | last << 4 — EVERY experiment of EVERY pair has `per` points
+                                 (1..15), except that the last one has `last` (1..15) if those bits are not 0; so n > 0 alone = n points in
+                                 every experiment; 0 = the pairs differ, the shape has no such code, or unknown.  (PHF_HIER_SHAPE of
+                                 pyhillfit_amd/csrc/phf_hier_model.h.)  Launches that get one lane per chain run the hand-allocated gfx950
+                                 build of the iteration (two wavefronts per SIMD: same numbers) where the library has one for (n_expts,
+                                 shape): n_expts == 3 with 4 + 4 + 4 points (147 of the Crumb set's 210 pairs), 2 + 2 + 2 (6), 5 + 5 + 4 (1). */
   const double* ln_conc;      /* device [P][stride] */
   const double* response;     /* device [P][stride] */
   const int32_t* expt_start;  /* device [P][Ne+1]  first point of each experiment; [Ne] = number of points */

@@ -11,11 +11,13 @@
 // the kernel corrects it once (tools/gen_hier_isa_main.py: udiv)
 inline uint32_t phf_isa_magic(uint32_t d) { const uint64_t m = (1ULL << 32) / (uint64_t)d; return m > 0xffffffffULL ? 0xffffffffu : (uint32_t)m; }
 
-// true once the embedded code object is loaded on the current device and holds the advance kernel
-bool phf_hier3_isa_available();
-// launch phf_hier3_advance: `a` complete except `consts` (filled here); (grid_waves + 3) / 4 workgroups of 256 threads — grid_waves =
+// which kernel of the code object (generated/phf_hier3_isa_layout.h: phf_isa_hier_kernels[]) runs pairs of n_expts experiments whose
+// point shape has this PHF_HIER_SHAPE code (phf_hier_points.points_per_expt): its index once the embedded code object is loaded on the
+// current device and holds it, -1 if there is none
+int phf_hier_isa_find(int n_expts, int shape_code);
+// launch it: `a` complete except `consts` (filled here); (grid_waves + 3) / 4 workgroups of 256 threads — grid_waves =
 // a->total_waves for a plain launch (a->queue == NULL), the chip's wavefront slots for a queued one
-int phf_hier3_isa_advance(phf_hier3_isa_args* a, int grid_waves, hipStream_t stream);
+int phf_hier_isa_advance(int which, phf_hier3_isa_args* a, int grid_waves, hipStream_t stream);
 
 // the same for phf_sl3_advance: the single-level model-2 iteration (no moments), plain or queued
 bool phf_sl3_isa_available();

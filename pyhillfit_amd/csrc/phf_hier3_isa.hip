@@ -44,7 +44,7 @@ struct DeviceModule {
   int rc = PHF_ERR_HIP;
   char msg[256] = "";
   hipModule_t module = nullptr;
-  hipFunction_t advance = nullptr;
+  hipFunction_t advance[PHF_ISA_HIER_NUM_KERNELS] = {};      // phf_isa_hier_kernels[]: one per (experiments, point shape)
   hipFunction_t sl_advance = nullptr;
   hipFunction_t unit[kNumUnits] = {};
   void* consts = nullptr;                      // tables + scalar constants, device memory, lives as long as the process
@@ -98,8 +98,10 @@ void load_module(DeviceModule* m) {
     e = hipModuleGetFunction(&m->unit[i], m->module, kUnitNames[i]);
     if (e != hipSuccess) return fail(kUnitNames[i], e);
   }
-  e = hipModuleGetFunction(&m->advance, m->module, "phf_hier3_advance");
-  if (e != hipSuccess) { m->advance = nullptr; (void)hipGetLastError(); }      // a units-only code object (generator bring-up)
+  for (int i = 0; i < PHF_ISA_HIER_NUM_KERNELS; ++i) {
+    e = hipModuleGetFunction(&m->advance[i], m->module, phf_isa_hier_kernels[i].name);
+    if (e != hipSuccess) { m->advance[i] = nullptr; (void)hipGetLastError(); }   // a units-only code object (generator bring-up)
+  }
   e = hipModuleGetFunction(&m->sl_advance, m->module, "phf_sl3_advance");
   if (e != hipSuccess) { m->sl_advance = nullptr; (void)hipGetLastError(); }
   const std::vector<unsigned char> blob = build_blob();
@@ -134,19 +136,24 @@ int launch(hipFunction_t f, unsigned blocks, void* args, size_t bytes, hipStream
 
 }  // namespace
 
-bool phf_hier3_isa_available() {
+int phf_hier_isa_find(int n_expts, int shape_code) {
+  int which = -1;
+  for (int i = 0; i < PHF_ISA_HIER_NUM_KERNELS; ++i)
+    if (phf_isa_hier_kernels[i].n_expts == n_expts && phf_isa_hier_kernels[i].shape_code == shape_code) which = i;
+  if (which < 0) return -1;                                  // (before the module is touched: most launches have no such kernel)
   DeviceModule* m = nullptr;
-  if (get_module(&m) != PHF_OK) return false;
-  return m->advance != nullptr;
+  if (get_module(&m) != PHF_OK) return -1;
+  return m->advance[which] ? which : -1;
 }
 
-int phf_hier3_isa_advance(phf_hier3_isa_args* a, int grid_waves, hipStream_t stream) {
+int phf_hier_isa_advance(int which, phf_hier3_isa_args* a, int grid_waves, hipStream_t stream) {
   DeviceModule* m = nullptr;
   if (int rc = get_module(&m)) return rc;
-  if (!m->advance) return phf_fail(PHF_ERR_UNSUPPORTED, "gfx950 code object holds no phf_hier3_advance");
+  if (which < 0 || which >= PHF_ISA_HIER_NUM_KERNELS || !m->advance[which])
+    return phf_fail(PHF_ERR_UNSUPPORTED, "gfx950 code object holds no such hierarchical kernel");
   a->consts = m->consts;
   const unsigned blocks = (unsigned)((grid_waves + 3) / 4);
-  return launch(m->advance, blocks, a, sizeof(*a), stream, "phf_hierarchical_advance (gfx950 assembly, Ne = 3)");
+  return launch(m->advance[which], blocks, a, sizeof(*a), stream, "phf_hierarchical_advance (gfx950 assembly)");
 }
 
 bool phf_sl3_isa_available() {

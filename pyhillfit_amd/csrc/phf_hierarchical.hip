@@ -923,8 +923,12 @@ int check(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_p
     if ((prob->kernel_hint & 3u) == 3u || ((prob->kernel_hint >> 2) & 3u) == 3u || (prob->kernel_hint & ~31u))
       return phf_fail(PHF_ERR_INVALID_ARGUMENT, "kernel_hint: bits 0-1 and 2-3 hold 0, 1 or 2; bit 4 = not the gfx950 assembly build; the other bits must be 0");
   }
-  if (pts->points_per_expt < 0 || (pts->points_per_expt > 0 && pts->points_per_expt * pts->n_expts > pts->stride))
-    return phf_fail(PHF_ERR_INVALID_ARGUMENT, "phf_hier_points.points_per_expt: 0 (experiments differ / unknown) or the number of points of EVERY experiment");
+  if (pts->points_per_expt != 0) {                          // a PHF_HIER_SHAPE code: `per` points in every experiment, `last` in the last one if that differs
+    const int per = pts->points_per_expt & 15, last = pts->points_per_expt >> 4;
+    if (pts->points_per_expt < 0 || per == 0 || last > 15 || (pts->n_expts - 1) * per + (last ? last : per) > pts->stride)
+      return phf_fail(PHF_ERR_INVALID_ARGUMENT, "phf_hier_points.points_per_expt: 0 (unknown / no such code) or per | last << 4: the points of EVERY experiment "
+                                                "(and of the last one if it differs) of EVERY pair");
+  }
   return PHF_OK;
 }
 
@@ -974,12 +978,13 @@ bool hier_isa_enabled() {
   return on;
 }
 
-int launch_isa3(const HierArgs& a, hipStream_t stream, bool* launched) {
+int launch_isa(const HierArgs& a, hipStream_t stream, bool* launched) {
   *launched = false;
   const int64_t bpp = a.blocks_per_problem;
   const int64_t total = bpp * a.prob.num_problems;
   if (a.cfg.adapt_start < 0 || a.t_end >= 0xffffffffLL || total > 0x7fffffffLL) return PHF_OK;   // hipcc kernels
-  if (!phf_hier3_isa_available()) return PHF_OK;
+  const int which = phf_hier_isa_find(a.pts.n_expts, a.pts.points_per_expt);
+  if (which < 0) return PHF_OK;
   phf_hier3_isa_args g{};
   g.state = a.state; g.rows = a.rows; g.moments = a.moments; g.gamma = a.cfg.gamma;
   g.ln_conc = a.pts.ln_conc; g.response = a.pts.response; g.pair_index = a.prob.pair_index; g.problem_id = a.prob.problem_id;
@@ -1024,7 +1029,7 @@ int launch_isa3(const HierArgs& a, hipStream_t stream, bool* launched) {
   }
   *launched = true;
   g_last_kernel = g.queue ? PHF_HIER_KERNEL_GFX950_ISA_QUEUED : PHF_HIER_KERNEL_GFX950_ISA;
-  return phf_hier3_isa_advance(&g, (int)grid_waves, stream);
+  return phf_hier_isa_advance(which, &g, (int)grid_waves, stream);
 }
 
 int hier_wps_override(const HierArgs& a) {
@@ -1091,12 +1096,10 @@ int launch_advance(const HierArgs& a, hipStream_t stream) {
     if (two) return launch_advance2<NE>(a, stream);
   }
 #endif
-  if constexpr (NE == 3) {
-    if (a.pts.points_per_expt == 4 && !(a.prob.kernel_hint & 16u) && hier_isa_enabled()) {
-      bool launched = false;
-      const int rc = launch_isa3(a, stream, &launched);
-      if (rc != PHF_OK || launched) return rc;
-    }
+  if (a.pts.points_per_expt != 0 && !(a.prob.kernel_hint & 16u) && hier_isa_enabled()) {
+    bool launched = false;
+    const int rc = launch_isa(a, stream, &launched);
+    if (rc != PHF_OK || launched) return rc;
   }
   return launch_advance1<NE>(a, stream);
 }

@@ -56,14 +56,27 @@ def make_prior(shapes=None, scales=None, locs=None):
     return pr
 
 
+def shape_code(sizes):
+    """PHF_HIER_SHAPE(per, last) of a pair's point shape (pyhillfit_amd/csrc/phf_hier_model.h; phf_hier_points.points_per_expt): `per` points in
+    every experiment but the last, `last` there (coded only if it differs); 0 for a shape that code cannot express"""
+    sizes = [int(n) for n in sizes]
+    per, last = sizes[0], sizes[-1]
+    if len(sizes) < 2 or any(n != per for n in sizes[:-1]) or not (0 < per < 16 and 0 < last < 16):
+        return 0
+    return per if last == per else per | (last << 4)
+
+
+# (experiments, shape code) of the point shapes the hand-allocated gfx950 code object has a kernel for (tools/gen_hier_isa_main.py:
+# HIER_KERNELS — the library looks the launch's shape up in its own table and runs the hipcc kernels for any other)
+ISA_SHAPES = {(3, shape_code((4, 4, 4))), (3, shape_code((2, 2, 2))), (3, shape_code((5, 5, 4)))}
+
+
 def group_key(experiments):
-    """Which launch group a pair belongs to: pairs of one group share a kernel instantiation.  (Ne, 0) in general; (3, 4) for the pairs
-    with three experiments of exactly four points (147 of the Crumb set's 210), which run the hand-allocated gfx950 build of the
-    iteration (phf_hier_points.points_per_expt)."""
-    ne = len(experiments)
-    if ne == 3 and all(len(x) == 4 for x in experiments):
-        return (ne, 4)
-    return (ne, 0)
+    """Which launch group a pair belongs to: pairs of one group share a kernel instantiation.  (Ne, 0) in general; (Ne, shape code) for the
+    pairs whose point shape the gfx950 assembly build has a kernel for (three experiments of 4 + 4 + 4 points: 147 of the Crumb set's 210
+    pairs; 2 + 2 + 2: 6; 5 + 5 + 4: 1) — a group of its own each, so that the launch can state its shape (phf_hier_points.points_per_expt)."""
+    key = (len(experiments), shape_code([len(x) for x in experiments]))
+    return key if key in ISA_SHAPES else (key[0], 0)
 
 
 class PackedHierPoints(object):
@@ -86,9 +99,9 @@ class PackedHierPoints(object):
                 self.ln_conc[p, :len(conc)] = np.log(conc)
             self.response[p, :len(y)] = y
             self.expt_start[p] = np.concatenate([[0], np.cumsum([len(x) for x in expts])])
-        # phf_hier_points.points_per_expt (ABI 6): n if EVERY experiment of EVERY pair has n points, else 0
-        sizes = {len(x) for e in experiments_per_pair for x in e}
-        self.points_per_expt = sizes.pop() if len(sizes) == 1 else 0
+        # phf_hier_points.points_per_expt (ABI 6): the shape code of EVERY pair (n if every experiment has n points), 0 if the pairs differ
+        codes = {shape_code([len(x) for x in e]) for e in experiments_per_pair}
+        self.points_per_expt = codes.pop() if len(codes) == 1 else 0
 
 
 class DeviceHierPoints(object):

@@ -87,6 +87,10 @@ def test_argument_validation_without_gpu(lib):
     hp.points_per_expt = 7                                 # 3 experiments x 7 points do not fit a stride of 16
     assert lib.phf_hierarchical_advance(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1
     assert b"points_per_expt" in lib.phf_last_error()
+    for bad in (-4, 16, 5 | (12 << 4), 1 << 8):             # negative; per = 0; 5 + 5 + 12 points beyond the stride; last > 15
+        hp.points_per_expt = bad
+        assert lib.phf_hierarchical_advance(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, None) == -1, bad
+        assert b"points_per_expt" in lib.phf_last_error()
     hp.points_per_expt = 4
     assert lib.phf_hierarchical_advance_queued(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, 0, None, None) == -1
     assert b"queue" in lib.phf_last_error()

@@ -67,7 +67,7 @@ def _setup(gpu, names, oracle_pair, C, thin, adapt, seed, isa, chain_offsets=Non
     from pyhillfit_amd import hierarchical as H
     pairs = [oracle_pair(d, c) for d, c in names]
     packed = H.PackedHierPoints([p.experiments for p in pairs])
-    assert packed.n_expts == 3 and packed.points_per_expt == 4
+    assert packed.n_expts == 3 and (3, packed.points_per_expt) in H.ISA_SHAPES
     Q = len(names)
     s = H.HierarchicalSampler(packed, list(range(Q)), C, thinning=thin, seed=seed, adapt_start=adapt, problem_ids=[7 + 3 * q for q in range(Q)],
                               chain_id_base=9, chain_offsets=chain_offsets, device=gpu)
@@ -104,6 +104,45 @@ def test_isa_advance_bit_identical_to_the_hipcc_kernel(C, thin, cuts, gpu, oracl
         assert same.all(), (name, int((~same).sum()), np.argwhere(~same)[:5].tolist())
     acc = got[True][1][-1].mean() / sum(cuts)
     assert 0.01 < acc < 0.95, acc
+
+
+OTHER_SHAPES = {"2 + 2 + 2": [("Rufinamide", "hERG"), ("Rufinamide", "Cav1.2"), ("Rufinamide", "Kir2.1")],
+                "5 + 5 + 4": [("Verapamil", "hERG")] * 3}
+
+
+@pytest.mark.parametrize("shape", sorted(OTHER_SHAPES))
+def test_isa_other_point_shapes_bit_identical_to_the_hipcc_kernel_and_the_twin(shape, gpu, oracle_pair):
+    """the code object's kernels for the other point shapes of the Crumb set's three-experiment pairs (2 + 2 + 2: a half without points;
+    5 + 5 + 4: a half with a pair AND an odd point): rows, state and moments against the hipcc one-lane kernel (run-time point loops)
+    bit for bit, launches cut around the start of the adaptation, a ragged last wavefront; four chains against the scalar twin"""
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import gamma_table
+    names = OTHER_SHAPES[shape]
+    C, thin, adapt, cuts = 200, 5, 140, (137, 9, 354)
+    got = {}
+    for isa in (False, True):
+        s, pairs = _setup(gpu, names, oracle_pair, C, thin, adapt, 20240229, isa)
+        s.init(np.array(THETA0), cov_scale=0.01)
+        s.enable_moments(after_iteration=adapt + 10)
+        chain = np.concatenate([s.advance(k).cpu().numpy() for k in cuts])
+        assert H.last_kernel() == (4 if isa else 1), H.last_kernel()
+        got[isa] = (chain, s.state.cpu().numpy(), s.moments.cpu().numpy())
+    for name, a, b in zip(("rows", "state", "moments"), got[False], got[True]):
+        same = a.view(np.uint64) == b.view(np.uint64)
+        assert same.all(), (shape, name, int((~same).sum()), np.argwhere(~same)[:5].tolist())
+    acc = got[True][1][-1].mean() / sum(cuts)
+    assert 0.01 < acc < 0.95, acc
+    shapes, scales, locs = H.prior_params()
+    gam = gamma_table(sum(cuts))
+    state = got[True][1].reshape(-1, 3, C)
+    for q in (0, 2):
+        pk = co.PackedHierPair(pairs[q].experiments, shapes, scales, locs)
+        for c in (0, C - 1):
+            st = pk.init_state(THETA0[q], 0.01)
+            rows = pk.advance(st, 0, sum(cuts), thin, adapt, gam, seed=20240229, chain_id=9 + c, problem_id=7 + 3 * q)
+            assert np.array_equal(got[True][0][:, q, :, c], rows), (shape, q, c)
+            assert np.array_equal(state[:, q, c], st), (shape, q, c)
 
 
 def test_isa_advance_bit_identical_to_the_twin(gpu, oracle_pair):

@@ -37,8 +37,20 @@ def test_generated_kernel_fits_two_wavefronts_per_simd_and_assembles(tmp_path):
     r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", src, "-o", obj], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     names = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-s", obj], capture_output=True, text=True).stdout
-    for k in ("phf_hier3_advance", "phf_isa_unit_exp_fast", "phf_isa_unit_philox7"):
+    for k in ("phf_hier3_advance", "phf_hier3_advance_s222", "phf_hier3_advance_s554", "phf_sl3_advance", "phf_isa_unit_exp_fast", "phf_isa_unit_philox7"):
         assert k in names
+
+
+@pytest.mark.parametrize("ne,shape", [(3, (2, 2, 2)), (3, (5, 5, 4)), (3, (3, 3, 3)), (3, (8, 8, 8)), (3, (7, 5, 1))])
+def test_generator_places_other_point_shapes_within_the_same_budget(ne, shape):
+    """the target phase is emitted per point shape (a half's pairs, then its odd point; halves side by side where both have a pair): every
+    shape of up to eight points per experiment fits the registers and the LDS of two workgroups per CU — the allocator raises otherwise"""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    sys.path.insert(0, os.path.join(REPO, "tools", "isa"))
+    import gen_hier_isa_main as G
+    (lines, meta), info = G.main_kernel(ne, shape)
+    assert info["vgpr_high_water"] <= 256 and 2 * info["lds_bytes_per_workgroup"] <= 160 * 1024
+    assert "scratch_" not in "\n".join(lines)
 
 
 def test_builder_inserts_waits_and_hazard_nops():

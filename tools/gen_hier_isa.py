@@ -333,13 +333,18 @@ def generate(with_main=True):
     info = {}
     if with_main:
         import gen_hier_isa_main as G
-        main, info = G.main_kernel()
-        kernels.append(main)
+        mains = G.main_kernels()
+        info = dict(mains[0][5])
+        for ne, shape, code, name, built, kinfo in mains:
+            kernels.append(built)
+            if name != "phf_hier3_advance":
+                info["%s" % name] = {"vgpr_high_water": kinfo["vgpr_high_water"], "lds_bytes_per_workgroup": kinfo["lds_bytes_per_workgroup"],
+                                     "count_iteration": kinfo["count_iteration"]}
         import gen_sl_isa_main as GS
         sl, sl_info = GS.main_kernel()
         kernels.append(sl)
         info.update(sl_info)
-        hdr_extra = G.header_extra(info) + ("#define PHF_ISA_LOGPHI_BLOB_OFF %d\n#define PHF_ISA_SL_MAX_STRIDE %d\n\n" % (GS.BLOB_LOGPHI_OFF, GS.MAX_STRIDE))
+        hdr_extra = G.header_extra(mains) + ("#define PHF_ISA_LOGPHI_BLOB_OFF %d\n#define PHF_ISA_SL_MAX_STRIDE %d\n\n" % (GS.BLOB_LOGPHI_OFF, GS.MAX_STRIDE))
     else:
         hdr_extra = ""
     text = "; GENERATED by tools/gen_hier_isa.py — do not edit (regenerate; tests/test_isa_generator.py checks this file against the script)\n"

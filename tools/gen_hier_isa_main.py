@@ -5,28 +5,70 @@ Each phase below names the C it restates (pyhillfit_amd/csrc/phf_hierarchical.hi
 pyhillfit_amd/csrc/phf_hier_model.h: phf_hier_log_target_n / phf_hier_target_half / phf_hier_draws_k) — same fp64 operations, same
 order per value, so that chains, states and moments are bit-identical to the hipcc kernels and to the twin (oracle/phf_oracle.c).
 """
+import struct
+
 import gfx950_asm as A
 import phf_isa_math as M
 from gfx950_asm import EXEC, VCC, Lit, Neg, Reg
-from gen_hier_isa import ARG_BYTES, ARG_OFF, D, NE, S_LOGA, S_LT, S_MEAN, S_NACC, S_TH, S_TRI, TRI, Gen
+from gen_hier_isa import ARG_BYTES, ARG_OFF, Gen
 
-# ---- what lives where ---------------------------------------------------------------------------------------------------------
-# LDS, per wavefront: [slot][64 lanes] doubles.  slots 0..10 the running mean, 11..21 the diagonal d, then the elements of L listed here
-# (row i, column k < i); every other element of L stays in VGPRs.
-LDS_L = [(i, 0) for i in range(1, D)] + [(i, 1) for i in range(2, 5)]
-SLOT_MEAN, SLOT_D, SLOT_L = 0, D, 2 * D
-NSLOTS = 2 * D + len(LDS_L)
+# ---- what lives where: set by configure(ne, shape) before a kernel is built (one kernel per number of experiments and point shape) ------
+# LDS, per wavefront: [slot][64 lanes] doubles.  slots 0..D-1 the running mean, D..2D-1 the diagonal d, then the elements of L listed in
+# LDS_L (row i, column k < i); every other element of L stays in VGPRs.
 # ... and the wavefront's UNIFORM values, read with one address for all lanes (a broadcast): the pair's points, experiment by experiment
-# [ln c (4)][y (4)], then the prior's loc[5], 1/scale[5], shape-1[5].  (Scalar loads would do — but they share lgkmcnt with the LDS and
-# return out of order, so every table look-up behind one waits for it: ~11 exposed scalar-memory latencies per iteration, measured as
-# 20 % of the wavefront's cycles in s_waitcnt.)
-U_POINTS, U_LOC, U_ISC, U_SM1, U_BYTES = 0, 192, 232, 272, 320
-WAVE_LDS = NSLOTS * 512 + U_BYTES
+# [ln c (n, padded to even)][y (n, padded to even)], then the prior's loc[5], 1/scale[5], shape-1[5].  (Scalar loads would do — but they
+# share lgkmcnt with the LDS and return out of order, so every table look-up behind one waits for it: ~11 exposed scalar-memory latencies
+# per iteration, measured as 20 % of the wavefront's cycles in s_waitcnt.)
 WAVE_BASE = 8064                                    # behind the workgroup's tables (M.TABLE_BYTES, padded)
-LDS_BYTES = WAVE_BASE + 4 * WAVE_LDS
 
 RESIDENT = ["L2E64", "NLN2HI64", "NLN2LO64", "KE0", "KE1", "K100", "KL0", "KL1", "KL2", "LN2HI", "LN2LO", "LN10", "ISQRT2",
             "M746", "P710", "P40", "P6", "QUARTER", "LOGADD", "MBITS"]
+
+
+def shape_code(shape):
+    """PHF_HIER_SHAPE(per, last) of a point shape (phf_hier_model.h; phf_hier_points.points_per_expt): every experiment `per` points,
+    the last one `last` if that differs; None for a shape that code cannot express"""
+    per, last = shape[0], shape[-1]
+    if any(n != per for n in shape[:-1]) or not (0 < per < 16 and 0 < last < 16):
+        return None
+    return per if last == per else per | (last << 4)
+
+
+def kernel_name(ne, shape):
+    if ne == 3 and tuple(shape) == (4, 4, 4):
+        return "phf_hier3_advance"
+    return "phf_hier%d_advance_s%s" % (ne, "".join(str(n) for n in shape))
+
+
+def configure(ne, shape):
+    """the module's layout constants for a kernel of `ne` experiments with shape[i] points in experiment i"""
+    global NE, D, TRI, S_TH, S_LT, S_MEAN, S_TRI, S_LOGA, S_NACC, SHAPE, N_PTS, PT_START, PT_OFF, PT_YOFF, LDS_L, SLOT_MEAN, SLOT_D, SLOT_L, NSLOTS
+    global U_POINTS, U_LOC, U_ISC, U_SM1, U_BYTES, WAVE_LDS, LDS_BYTES, NAME
+    assert len(shape) == ne and all(1 <= n <= 8 for n in shape)
+    NE, D = ne, 5 + 2 * ne
+    TRI = D * (D + 1) // 2
+    S_TH, S_LT, S_MEAN, S_TRI, S_LOGA, S_NACC = 0, D, D + 1, 2 * D + 1, 2 * D + 1 + TRI, 2 * D + 2 + TRI       # state rows (phf_hierarchical.hip)
+    SHAPE, N_PTS, NAME = tuple(shape), sum(shape), kernel_name(ne, shape)
+    PT_START = [sum(shape[:i]) for i in range(ne)]                     # experiment i's first point in the pair's arrays
+    pad = [n + (n & 1) for n in shape]
+    PT_OFF = [16 * sum(pad[:i]) for i in range(ne)]                    # its block in the uniform area: [ln c (pad)][y (pad)]
+    PT_YOFF = [8 * pad[i] for i in range(ne)]
+    LDS_L = [(i, 0) for i in range(1, D)] + [(i, 1) for i in range(2, 5)]
+    SLOT_MEAN, SLOT_D, SLOT_L = 0, D, 2 * D
+    NSLOTS = 2 * D + len(LDS_L)
+    U_POINTS, U_LOC = 0, 16 * sum(pad)
+    U_ISC, U_SM1, U_BYTES = U_LOC + 40, U_LOC + 80, U_LOC + 128
+    WAVE_LDS = NSLOTS * 512 + U_BYTES
+    LDS_BYTES = WAVE_BASE + 4 * WAVE_LDS
+    assert 2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU"
+
+
+configure(3, (4, 4, 4))
+
+
+def dbl_words(x):
+    lo, hi = struct.unpack("<II", struct.pack("<d", float(x)))
+    return lo, hi
 
 
 def tri_index(i, k):
@@ -35,7 +77,7 @@ def tri_index(i, k):
 
 class Main(object):
     def __init__(self):
-        self.g = Gen("phf_hier3_advance", NSLOTS)
+        self.g = Gen(NAME, NSLOTS)
         self.k = self.g.k
         self.m = self.g.m
         self.c = self.g.c
@@ -279,15 +321,39 @@ class Main(object):
         self.add64(a_y, a_y, pp)
         save = k.sd()
         ua, u1, u2 = k.v1(), k.vd(), k.vd()
-        k.emit("v_cmp_gt_u32_e32", [VCC], [12, lane], "valu", count="valu_int")
+        k.emit("v_cmp_gt_u32_e32", [VCC], [N_PTS, lane], "valu", count="valu_int")
         k.sop("s_and_saveexec_b64", save, VCC)
         k.gload(u1, self.v_lane8, a_lc)
         k.gload(u2, self.v_lane8, a_y)
-        k.vop("v_and_b32_e32", ua, Lit(0xfffffffc), lane)            # point p of experiment p >> 2: doubles 8 (p >> 2) + (p & 3) [+ 4 for y]
-        k.vop("v_add_u32_e32", ua, ua, lane)
-        k.vop("v_lshl_add_u32", ua, ua, 3, self.v_ulds)
-        k.ds_write(ua, u1, U_POINTS)
-        k.ds_write(ua, u2, U_POINTS + 32)
+        per = SHAPE[0]
+        if all(n == per for n in SHAPE) and per & (per - 1) == 0:
+            k.vop("v_and_b32_e32", ua, Lit(0x100000000 - per), lane)     # point p of experiment p / per: doubles 2 per (p / per) + (p % per) [+ per for y]
+            k.vop("v_add_u32_e32", ua, ua, lane)
+            k.vop("v_lshl_add_u32", ua, ua, 3, self.v_ulds)
+            k.ds_write(ua, u1, U_POINTS)
+            k.ds_write(ua, u2, U_POINTS + 8 * per)
+        else:
+            # point p of experiment e (p in [PT_START[e], PT_START[e] + SHAPE[e])): ln c at double PT_OFF[e] / 8 + (p - PT_START[e]), y PT_YOFF[e] / 8
+            # further on: p + a constant per experiment, built up boundary by boundary (once per task)
+            uy, vtmp = k.v1(), k.v1()
+            cl = [PT_OFF[e] // 8 - PT_START[e] for e in range(NE)]
+            cy = [cl[e] + PT_YOFF[e] // 8 for e in range(NE)]
+            k.vop("v_add_u32_e32", ua, cl[0], lane)
+            k.vop("v_add_u32_e32", uy, cy[0], lane)
+            for e in range(1, NE):
+                if cl[e] != cl[e - 1] or cy[e] != cy[e - 1]:
+                    k.cmp_u32("le", VCC, PT_START[e], lane)
+                    for reg, cc in ((ua, cl), (uy, cy)):
+                        if cc[e] != cc[e - 1]:
+                            assert 0 < cc[e] - cc[e - 1] <= 64
+                            k.mov32(vtmp, cc[e] - cc[e - 1])
+                            k.cnd32_vcc(vtmp, 0, vtmp)
+                            k.vop("v_add_u32_e32", reg, reg, vtmp)
+            k.vop("v_lshl_add_u32", ua, ua, 3, self.v_ulds)
+            k.vop("v_lshl_add_u32", uy, uy, 3, self.v_ulds)
+            k.ds_write(ua, u1, U_POINTS)
+            k.ds_write(uy, u2, U_POINTS)
+            k.free(uy, vtmp)
         k.sop("s_mov_b64", EXEC, save)
         k.emit("v_cmp_gt_u32_e32", [VCC], [15, lane], "valu", count="valu_int")
         k.sop("s_and_saveexec_b64", save, VCC)
@@ -767,7 +833,9 @@ class Main(object):
         # weights that are computed: -Ne beta, beta - 1
         k.free(f_isc)
         three, twelve = k.sd(), k.sd()                       # (double)Ne and (double)n_pts: literals (their low words are zero)
-        for r, hi in ((three, 0x40080000), (twelve, 0x40280000)):
+        for r, val in ((three, NE), (twelve, N_PTS)):
+            lo, hi = dbl_words(val)
+            assert lo == 0
             k.sop("s_mov_b32", r.lo(), 0)
             k.sop("s_mov_b32", r.hi(), Lit(hi))
         wnb, wb1 = k.vd(), k.vd()
@@ -775,9 +843,11 @@ class Main(object):
         k.add(wb1, beta, -1.0)
         # half 0: ln alpha, ln Hill_1..3, ln beta, ln(alpha - loc0)
         part0, part1 = k.vd(), k.vd()
-        lg0 = [k.vd() for _ in range(4)]
-        M.log_fast(m, lg0[:2], [alpha, hill[0]])
-        M.log_fast(m, lg0[2:], hill[1:])
+        assert NE in (3, 4), "the halves' shares of the first batch of logarithms: half 0 = alpha, Hill_i, beta, alpha - loc0"
+        lg0 = [k.vd() for _ in range(NE + 1)]
+        args0 = [alpha] + hill
+        for j in range(0, NE + 1, 2):
+            M.log_fast(m, lg0[j:j + 2], args0[j:j + 2])
         k.fma(part0, wnb, lg0[0], 0.0)
         for i in range(NE):
             k.fma(part0, wb1, lg0[1 + i], part0)
@@ -795,6 +865,8 @@ class Main(object):
         M.log_fast(m, t2, [s_, sigma])
         k.fma(part1, Neg(three), t2[0], part1)
         k.fma(part1, Neg(twelve), t2[1], part1)
+        if (9 + NE) % 2:                                     # the pad of half 1: fma(0, ln 1, part) with ln 1 = +0 exactly
+            k.add(part1, part1, 0.0)
         k.free(t4, xl, f_sm1, three, twelve)
         # la0_i = 1 + (Hill_i / alpha)^beta = 1 + exp(beta (ln Hill_i - ln alpha));  la1_i = 1 + exp(-z_i)
         la0, la1 = [k.vd() for _ in range(NE)], [k.vd() for _ in range(NE)]
@@ -817,10 +889,10 @@ class Main(object):
         k.free(lin0, lin1)
         # -2 ln prod_i la_i, term by term where the product is not below 2^1000 (rare: a uniform branch)
         prod = t2
-        k.mul(prod[0], la0[0], la0[1])
-        k.mul(prod[0], prod[0], la0[2])
-        k.mul(prod[1], la1[0], la1[1])
-        k.mul(prod[1], prod[1], la1[2])
+        for h, la in ((0, la0), (1, la1)):
+            k.mul(prod[h], la[0], la[1])
+            for i in range(2, NE):
+                k.mul(prod[h], prod[h], la[i])
         vlog = [k.vd(), k.vd()]
         big = [k.sd(), k.sd()]
         for h in range(2):
@@ -847,85 +919,149 @@ class Main(object):
         k.fma(part0, -2.0, vlog[0], part0)
         k.fma(part1, -2.0, vlog[1], part1)
         k.free(vlog, prod)
-        # the points: experiment i's four points, two for each half (:117-125)
+        # the points (:117-125): experiment i's n points, the first 2 floor((n + 2) / 4) for half 0, the others for half 1; a half takes its
+        # points two at a time behind one reciprocal, then the odd one (phf_hier_target_half) — here a pair of half 0 and a pair of half 1
+        # advance side by side where both exist (four points per experiment: exactly that)
         sse, mass = [k.vd(), k.vd()], [k.vd(), k.vd()]
+        started = {"sse": [False, False], "mass": [False, False]}
+
+        def acc_sse(h, r):
+            k.fma(sse[h], r, r, sse[h] if started["sse"][h] else 0.0)
+            started["sse"][h] = True
+
+        def acc_mass(h, v):
+            k.mul(mass[h], mass[h] if started["mass"][h] else 1.0, v)
+            started["mass"][h] = True
+
         for i in range(NE):
-            pl = [k.vq(), k.vq()]                                 # ln conc of points 4 i .. 4 i + 3
-            py = [k.vq(), k.vq()]                                 # their responses (used some fifty instructions further down)
-            for j in range(2):
-                self.uload(pl[j], U_POINTS + 64 * i + 16 * j)
-            for j in range(2):
-                self.uload(py[j], U_POINTS + 64 * i + 32 + 16 * j)
-            lcs = [pl[j // 2].sub(2 * (j % 2)) for j in range(4)]
-            ys = [py[j // 2].sub(2 * (j % 2)) for j in range(4)]
-            lnic = k.vd()
-            k.sub(lnic, c["P6"], pic[i])
-            k.mul(lnic, c["LN10"], lnic)
-            x = [k.vd() for _ in range(4)]
-            d = [k.vd() for _ in range(4)]
-            for j in range(4):
-                k.sub(x[j], lcs[j], lnic)
-                k.mul(x[j], hill[i], x[j])
-                k.fmin(x[j], x[j], c["P40"])
-            k.free(lnic, pl)
-            M.exp_capped(m, d, x)
-            for j in range(4):
-                k.add(d[j], d[j], 1.0)
-            inv = [x[0], x[1]]
-            pred = [x[2], x[3], k.vd(), k.vd()]
-            k.mul(pred[0], d[0], d[1])
-            k.mul(pred[1], d[2], d[3])
-            M.rcp(m, inv, [pred[0], pred[1]])
-            # pred0 = fma(-100, inv * d1, 100), pred1 = fma(-100, inv * d0, 100)
-            tt = [k.vd() for _ in range(4)]
-            for h in range(2):
-                k.mul(tt[2 * h], inv[h], d[2 * h + 1])
-                k.mul(tt[2 * h + 1], inv[h], d[2 * h])
-            k.free(d)
-            for j in range(4):
-                k.fma(pred[j], Neg(c["K100"]), tt[j], c["K100"])
-            for j in range(4):
-                k.sub(tt[j], ys[j], pred[j])
-            for h in range(2):
-                k.fma(sse[h], tt[2 * h], tt[2 * h], 0.0 if i == 0 else sse[h])
-                k.fma(sse[h], tt[2 * h + 1], tt[2 * h + 1], sse[h])
-            k.free(tt, inv, py)
-            # truncation masses (phf_trunc_mass_x2, upper tails skipped unless some lane needs one), a pair of points at a time
-            for h in range(2):
-                p0, p1 = pred[2 * h], pred[2 * h + 1]
-                ya = [k.vd(), k.vd()]
-                yb = [k.vd(), k.vd()]
-                for j, p in enumerate((p0, p1)):
-                    k.mul(ya[j], p, inv_s)
-                    k.mul(ya[j], ya[j], c["ISQRT2"])
-                    k.sub(yb[j], c["K100"], p)
-                    k.mul(yb[j], yb[j], inv_s)
-                    k.mul(yb[j], yb[j], c["ISQRT2"])
-                tl = [p0, p1]                                        # the predictions are spent: their registers take the tails
-                M.erfc_tab(m, tl, ya)
-                k.free(ya)
-                need = k.sd()
-                l_skip = k.new_label("noupper")
-                k.cmp("lt", need, yb[0], c["P6"])
-                k.cmp("lt", VCC, yb[1], c["P6"])
-                k.sop("s_or_b64", need, need, VCC)
-                k.sop("s_cmp_eq_u64", None, need, 0)
-                k.branch("s_cbranch_scc1", l_skip)
-                tu = [k.vd(), k.vd()]
-                M.erfc_tab(m, tu, yb)
-                k.add(tl[0], tl[0], tu[0])
-                k.add(tl[1], tl[1], tu[1])
-                k.free(tu)
-                k.label(l_skip)
-                k.free(need, yb)
-                k.fma(tl[0], -0.5, tl[0], 1.0)
-                k.fma(tl[1], -0.5, tl[1], 1.0)
-                k.mul(tl[0], tl[0], tl[1])
-                if i == 0:
-                    k.mul(mass[h], 1.0, tl[0])
-                else:
-                    k.mul(mass[h], mass[h], tl[0])
-            k.free(pred)
+            n = SHAPE[i]
+            nf = min(2 * ((n + 2) // 4), n)
+            units = []                                       # (half, points): a pair or a single, in each half's own order
+            for h, idx in ((0, list(range(nf))), (1, list(range(nf, n)))):
+                units += [(h, idx[j:j + 2]) for j in range(0, len(idx) - 1, 2)]
+                if len(idx) % 2:
+                    units.append((h, idx[-1:]))
+            pairs0 = [u for u in units if u[0] == 0 and len(u[1]) == 2]
+            pairs1 = [u for u in units if u[0] == 1 and len(u[1]) == 2]
+            chunks = []
+            while pairs0 and pairs1:                         # a pair of each half side by side
+                chunks.append([pairs0.pop(0), pairs1.pop(0)])
+            chunks += [[u] for u in pairs0 + pairs1]
+            singles = [u for u in units if len(u[1]) == 1]
+            chunks += [[u] for u in singles]
+            # (a half's pairs come before its single, and chunks keep each half's order: its sums see the C order)
+            lnic = None
+            for ci, chunk in enumerate(chunks):
+                pts = [p_ for _, ps in chunk for p_ in ps]
+                # this chunk's points: ln c, then y (used some fifty instructions further down); a pair is one 16-byte read
+                lreg, yreg, held = {}, {}, {0: [], 1: []}
+                for which, (base_off, regs) in enumerate(((0, lreg), (PT_YOFF[i], yreg))):
+                    for _, ps in chunk:
+                        r = k.vq() if len(ps) == 2 else k.vd()
+                        assert len(ps) == 1 or ps[0] % 2 == 0
+                        self.uload(r, U_POINTS + PT_OFF[i] + base_off + 8 * ps[0])
+                        held[which].append(r)
+                        for j, p_ in enumerate(ps):
+                            regs[p_] = r.sub(2 * j) if len(ps) == 2 else r
+                if lnic is None:
+                    lnic = k.vd()
+                    k.sub(lnic, c["P6"], pic[i])
+                    k.mul(lnic, c["LN10"], lnic)
+                x = [k.vd() for _ in pts]
+                d = [k.vd() for _ in pts]
+                for j, p_ in enumerate(pts):
+                    k.sub(x[j], lreg[p_], lnic)
+                    k.mul(x[j], hill[i], x[j])
+                    k.fmin(x[j], x[j], c["P40"])
+                if ci == len(chunks) - 1:
+                    k.free(lnic)
+                k.free(held[0])
+                M.exp_capped(m, d, x)
+                for j in range(len(pts)):
+                    k.add(d[j], d[j], 1.0)
+                nu = len(chunk)
+                inv = x[:nu]
+                pred = x[nu:] + [k.vd() for _ in range(nu)]
+                den, pos = [], 0
+                for u, (h, ps) in enumerate(chunk):
+                    if len(ps) == 2:
+                        k.mul(pred[u], d[pos], d[pos + 1])
+                        den.append(pred[u])
+                    else:
+                        den.append(d[pos])
+                    pos += len(ps)
+                M.rcp(m, inv, den)
+                # pair: pred0 = fma(-100, inv * d1, 100), pred1 = fma(-100, inv * d0, 100); single: pred = fma(-100, inv, 100)
+                tt, pos = [], 0
+                for u, (h, ps) in enumerate(chunk):
+                    if len(ps) == 2:
+                        t0, t1 = k.vd(), k.vd()
+                        k.mul(t0, inv[u], d[pos + 1])
+                        k.mul(t1, inv[u], d[pos])
+                        tt += [t0, t1]
+                    else:
+                        tt.append(inv[u])
+                    pos += len(ps)
+                k.free(d)
+                for j in range(len(pts)):
+                    k.fma(pred[j], Neg(c["K100"]), tt[j], c["K100"])
+                for j, p_ in enumerate(pts):
+                    if tt[j] in inv:                             # a single's w sits in inv: its residual needs a register of its own
+                        tt[j] = k.vd()
+                    k.sub(tt[j], yreg[p_], pred[j])
+                pos = 0
+                for h, ps in chunk:
+                    for j in range(len(ps)):
+                        acc_sse(h, tt[pos + j])
+                    pos += len(ps)
+                k.free([t for t in tt if t not in inv], inv, held[1])
+                # truncation masses (phf_trunc_mass_x2: upper tails skipped unless some lane needs one; phf_trunc_mass for the odd point)
+                pos = 0
+                for h, ps in chunk:
+                    pp = pred[pos:pos + len(ps)]
+                    pos += len(ps)
+                    ya = [k.vd() for _ in pp]
+                    yb = [k.vd() for _ in pp]
+                    for j, p_ in enumerate(pp):
+                        k.mul(ya[j], p_, inv_s)
+                        k.mul(ya[j], ya[j], c["ISQRT2"])
+                        k.sub(yb[j], c["K100"], p_)
+                        k.mul(yb[j], yb[j], inv_s)
+                        k.mul(yb[j], yb[j], c["ISQRT2"])
+                    tl = list(pp)                                        # the predictions are spent: their registers take the tails
+                    M.erfc_tab(m, tl, ya)
+                    k.free(ya)
+                    if len(pp) == 2:
+                        need = k.sd()
+                        l_skip = k.new_label("noupper")
+                        k.cmp("lt", need, yb[0], c["P6"])
+                        k.cmp("lt", VCC, yb[1], c["P6"])
+                        k.sop("s_or_b64", need, need, VCC)
+                        k.sop("s_cmp_eq_u64", None, need, 0)
+                        k.branch("s_cbranch_scc1", l_skip)
+                        tu = [k.vd(), k.vd()]
+                        M.erfc_tab(m, tu, yb)
+                        k.add(tl[0], tl[0], tu[0])
+                        k.add(tl[1], tl[1], tu[1])
+                        k.free(tu)
+                        k.label(l_skip)
+                        k.free(need, yb)
+                        k.fma(tl[0], -0.5, tl[0], 1.0)
+                        k.fma(tl[1], -0.5, tl[1], 1.0)
+                        k.mul(tl[0], tl[0], tl[1])
+                    else:
+                        tu = [k.vd()]
+                        M.erfc_tab(m, tu, yb)
+                        k.add(tl[0], tl[0], tu[0])
+                        k.free(tu, yb)
+                        k.fma(tl[0], -0.5, tl[0], 1.0)
+                    acc_mass(h, tl[0])
+                k.free(pred)
+        for h in range(2):                                   # a half without points: SSE 0, mass 1
+            if not started["sse"][h]:
+                k.mov64(sse[h], 0.0)
+            if not started["mass"][h]:
+                k.mov64(mass[h], 1.0)
         # halves: part_h - fma(sse_h, (0.5 inv_s) inv_s, ln mass_h), -inf if the mass underflowed; sum; -inf outside the support
         hs = k.vd()
         k.mul(hs, inv_s, 0.5)
@@ -1005,9 +1141,35 @@ class Main(object):
         return lines_meta, self.info
 
 
-def main_kernel():
-    return Main().build()
+# the kernels of the code object: (experiments, points per experiment).  The Crumb set's 154 pairs with three experiments are 147 x (4, 4, 4),
+# 6 x (2, 2, 2) and 1 x (5, 5, 4)
+HIER_KERNELS = [(3, (4, 4, 4)), (3, (2, 2, 2)), (3, (5, 5, 4))]
 
 
-def header_extra(info):
-    return ("#define PHF_ISA_HIER3_LDS_BYTES %d\n#define PHF_ISA_HIER3_VGPRS %d\n\n" % (info["lds_bytes_per_workgroup"], info["vgpr_high_water"]))
+def main_kernel(ne=3, shape=(4, 4, 4)):
+    configure(ne, shape)
+    try:
+        return Main().build()
+    finally:
+        configure(3, (4, 4, 4))
+
+
+def main_kernels():
+    """[(n_expts, shape, shape code, kernel name, (lines, meta), info)]"""
+    out = []
+    for ne, shape in HIER_KERNELS:
+        built, info = main_kernel(ne, shape)
+        out.append((ne, shape, shape_code(shape), kernel_name(ne, shape), built, dict(info)))
+    return out
+
+
+def header_extra(kernels):
+    info = kernels[0][5]
+    text = "#define PHF_ISA_HIER3_LDS_BYTES %d\n#define PHF_ISA_HIER3_VGPRS %d\n\n" % (info["lds_bytes_per_workgroup"], info["vgpr_high_water"])
+    text += ("/* the hierarchical iteration's kernels: experiments, PHF_HIER_SHAPE code of the point shape (phf_hier_points.points_per_expt), name */\n"
+             "#define PHF_ISA_HIER_NUM_KERNELS %d\n"
+             "static const struct { int n_expts; int shape_code; const char* name; } phf_isa_hier_kernels[PHF_ISA_HIER_NUM_KERNELS] = {\n" % len(kernels))
+    for ne, shape, code, name, _, _ in kernels:
+        assert code is not None
+        text += "    {%d, %d, \"%s\"}, /* %s */\n" % (ne, code, name, " + ".join(str(n) for n in shape))
+    return text + "};\n\n"
