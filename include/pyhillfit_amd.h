@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PHF_ABI_VERSION 6
+#define PHF_ABI_VERSION 7
 
 enum {
   PHF_OK = 0,
@@ -80,8 +80,9 @@ typedef struct phf_problems {
   uint32_t chain_id_base;        /* global number of local chain 0 (Philox counter word 0) */
   uint32_t kernel_hint;          /* hierarchical launches (ABI 5; was `reserved`; single-level: 0, bit 4 or bit 5 (phf_single_level_last_kernel)): which kernel THIS launch
                                     should get — bits 0-1 lanes per chain (1 | 2), bits 2-3 register build of the two-lane kernel (1 | 2
-                                    wavefronts per SIMD), bit 4 (ABI 6) = 1: not the gfx950 assembly build of the Ne = 3 iteration (A/B timing,
-                                    bit-identity tests); 0 = the library decides from the launch size.  A host that runs several
+                                    wavefronts per SIMD), bit 4 (ABI 6) = 1: not the gfx950 assembly build of the iteration (A/B timing,
+                                    bit-identity tests), bit 6 (ABI 7) = 1: the queue workspace of phf_hierarchical_advance_queued holds
+                                    phf_hierarchical_queue_words() words; 0 = the library decides from the launch size.  A host that runs several
                                     groups side by side sets it per launch (the groups together fill the chip although each alone
                                     would not); a process-wide policy (phf_hierarchical_set_kernel_policy, PHF_HIER_LANES / _WPS) overrides it.
                                     Every choice gives the same numbers bit for bit. */
@@ -207,7 +208,9 @@ typedef struct phf_hier_points {
                                  every experiment; 0 = the pairs differ, the shape has no such code, or unknown.  (PHF_HIER_SHAPE of
                                  pyhillfit_amd/csrc/phf_hier_model.h.)  Launches that get one lane per chain run the hand-allocated gfx950
                                  build of the iteration (two wavefronts per SIMD: same numbers) where the library has one for (n_expts,
-                                 shape): n_expts == 3 with 4 + 4 + 4 points (147 of the Crumb set's 210 pairs), 2 + 2 + 2 (6), 5 + 5 + 4 (1). */
+                                 shape): n_expts == 3 with 4 + 4 + 4 points (147 of the Crumb set's 210 pairs), 2 + 2 + 2 (6), 5 + 5 + 4 (1);
+                                 ABI 7: n_expts == 4 with 4 + 4 + 4 + 1 (32), + 2 (5), + 3 (2) — through phf_hierarchical_advance_queued with a
+                                 workspace of phf_hierarchical_queue_words() words and kernel_hint bit 6. */
   const double* ln_conc;      /* device [P][stride] */
   const double* response;     /* device [P][stride] */
   const int32_t* expt_start;  /* device [P][Ne+1]  first point of each experiment; [Ne] = number of points */
@@ -252,11 +255,19 @@ int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* pro
  * tasks (147 pairs x 1 024 chains: 2 352 wavefronts on 2 048 slots).  Every other launch runs exactly as phf_hierarchical_advance.
  * Results are identical either way (same chains, rows, state, moments).
  *   queue   device int32 [2 + Q * ceil(C / 64)], owned by the caller, zeroed by the caller when allocated; words 0 .. Q ceil(C/64) are
- *           zeroed here, on the stream, before a queued launch; the LAST word is the sticky fault flag of
- *           phf_single_level_queue_status (same layout, same meaning: check it there wherever the host synchronises anyway). */
+ *           zeroed here, on the stream, before a queued launch; word 1 + Q ceil(C/64) is the sticky fault flag of
+ *           phf_single_level_queue_status (same layout, same meaning: check it there wherever the host synchronises anyway).
+ *           ABI 7: a workspace of phf_hierarchical_queue_words(pts, prob) words — which the caller states with kernel_hint bit 6 —
+ *           also holds the device-memory scratch in which the gfx950 build of the Ne = 4 iteration keeps the last rows of the proposal
+ *           factor (21 KB per resident wavefront, at most 44 MB); without that statement such launches run the hipcc kernels. */
 int phf_hierarchical_advance_queued(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
                                     const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
                                     double* moments, int64_t moments_after, int32_t quantum, int32_t* queue, void* stream);
+
+/* int32 words the queue workspace of phf_hierarchical_advance_queued has to hold for launches of this (pts, prob) shape (ABI 7):
+ * 2 + Q ceil(C / 64), plus the scratch of a gfx950 kernel that keeps part of the chain state in device memory (n_expts == 4 with
+ * 4 + 4 + 4 + 1 / 2 / 3 points).  Reads only n_expts, points_per_expt, num_problems and chains_per_problem; no device call.  < 0: error. */
+int64_t phf_hierarchical_queue_words(const phf_hier_points* pts, const phf_problems* prob);
 
 /* Which kernel runs groups with Ne = 3..6, PROCESS-WIDE (ABI 4; A/B timing and the bit-identity tests): lanes 1 | 2 = one | two lanes
  * per chain, wps 1 | 2 = the register build of the two-lane kernel (512 | 256 registers); 0 = not forced: the launch's own

@@ -15,6 +15,9 @@ inline uint32_t phf_isa_magic(uint32_t d) { const uint64_t m = (1ULL << 32) / (u
 // point shape has this PHF_HIER_SHAPE code (phf_hier_points.points_per_expt): its index once the embedded code object is loaded on the
 // current device and holds it, -1 if there is none
 int phf_hier_isa_find(int n_expts, int shape_code);
+// doubles per lane of device-memory scratch the kernel for (n_expts, shape_code) keeps part of a resident wavefront's chain state in
+// (a->scratch: 512 bytes x slots x the launch's wavefronts); 0 for none or no such kernel.  A property of the generated table: no device call.
+int phf_hier_isa_scratch_slots(int n_expts, int shape_code);
 // launch it: `a` complete except `consts` (filled here); (grid_waves + 3) / 4 workgroups of 256 threads — grid_waves =
 // a->total_waves for a plain launch (a->queue == NULL), the chip's wavefront slots for a queued one
 int phf_hier_isa_advance(int which, phf_hier3_isa_args* a, int grid_waves, hipStream_t stream);

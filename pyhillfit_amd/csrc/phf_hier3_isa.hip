@@ -146,6 +146,12 @@ int phf_hier_isa_find(int n_expts, int shape_code) {
   return m->advance[which] ? which : -1;
 }
 
+int phf_hier_isa_scratch_slots(int n_expts, int shape_code) {
+  for (int i = 0; i < PHF_ISA_HIER_NUM_KERNELS; ++i)
+    if (phf_isa_hier_kernels[i].n_expts == n_expts && phf_isa_hier_kernels[i].shape_code == shape_code) return phf_isa_hier_kernels[i].scratch_slots;
+  return 0;
+}
+
 int phf_hier_isa_advance(int which, phf_hier3_isa_args* a, int grid_waves, hipStream_t stream) {
   DeviceModule* m = nullptr;
   if (int rc = get_module(&m)) return rc;

@@ -920,8 +920,9 @@ int check(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_p
     const int64_t bpp = (pts->n_expts > PHF_HIER_FAST_EXPTS) ? prob->chains_per_problem : (prob->chains_per_problem + kBlock - 1) / kBlock;
     if (bpp * prob->num_problems > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
     if ((int64_t)prob->num_problems * prob->chains_per_problem > 0x7fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains");
-    if ((prob->kernel_hint & 3u) == 3u || ((prob->kernel_hint >> 2) & 3u) == 3u || (prob->kernel_hint & ~31u))
-      return phf_fail(PHF_ERR_INVALID_ARGUMENT, "kernel_hint: bits 0-1 and 2-3 hold 0, 1 or 2; bit 4 = not the gfx950 assembly build; the other bits must be 0");
+    if ((prob->kernel_hint & 3u) == 3u || ((prob->kernel_hint >> 2) & 3u) == 3u || (prob->kernel_hint & ~(31u | 64u)))
+      return phf_fail(PHF_ERR_INVALID_ARGUMENT, "kernel_hint: bits 0-1 and 2-3 hold 0, 1 or 2; bit 4 = not the gfx950 assembly build; bit 6 = the queue workspace "
+                                                "holds phf_hierarchical_queue_words() words; the other bits must be 0");
   }
   if (pts->points_per_expt != 0) {                          // a PHF_HIER_SHAPE code: `per` points in every experiment, `last` in the last one if that differs
     const int per = pts->points_per_expt & 15, last = pts->points_per_expt >> 4;
@@ -978,11 +979,31 @@ bool hier_isa_enabled() {
   return on;
 }
 
+// layout of the queue workspace (phf_hierarchical_queue_words): [task counter][progress word per block][sticky fault word], then — for
+// the kernels with a scratch tier — up to 512 bytes of alignment and 512 bytes x slots for each of min(blocks, the chip's wavefront slots)
+// (+ 3: a grid is whole workgroups of four) resident wavefronts
+double* hier_queue_scratch(int32_t* queue, int64_t total) {
+  const uintptr_t p = reinterpret_cast<uintptr_t>(queue + 2 + total);
+  return reinterpret_cast<double*>((p + 511) & ~(uintptr_t)511);
+}
+int64_t hier_queue_words(int n_expts, int shape_code, int64_t total) {
+  int64_t words = 2 + total;
+  const int scratch_slots = phf_hier_isa_scratch_slots(n_expts, shape_code);
+  if (scratch_slots > 0) {
+    const int64_t slots = 2LL * phf_simd_count();
+    words += 128 + ((total < slots ? total : slots) + 3) * scratch_slots * 128;
+  }
+  return words;
+}
+
 int launch_isa(const HierArgs& a, hipStream_t stream, bool* launched) {
   *launched = false;
   const int64_t bpp = a.blocks_per_problem;
   const int64_t total = bpp * a.prob.num_problems;
   if (a.cfg.adapt_start < 0 || a.t_end >= 0xffffffffLL || total > 0x7fffffffLL) return PHF_OK;   // hipcc kernels
+  // a kernel that keeps part of the state in device-memory scratch needs the caller's word that the workspace holds it (kernel_hint bit 6)
+  const int scratch_slots = phf_hier_isa_scratch_slots(a.pts.n_expts, a.pts.points_per_expt);
+  if (scratch_slots > 0 && (!a.queue || !(a.prob.kernel_hint & 64u))) return PHF_OK;
   const int which = phf_hier_isa_find(a.pts.n_expts, a.pts.points_per_expt);
   if (which < 0) return PHF_OK;
   phf_hier3_isa_args g{};
@@ -1026,6 +1047,10 @@ int launch_isa(const HierArgs& a, hipStream_t stream, bool* launched) {
     g.blocks_magic = phf_isa_magic((uint32_t)total);
     g.rows_per_quantum = (uint32_t)(quantum / a.cfg.thinning);
     grid_waves = slots;
+  }
+  if (scratch_slots > 0) {
+    if (grid_waves > slots) return PHF_OK;                  // more blocks than the chip holds and no queue to pull them through: hipcc kernels
+    g.scratch = hier_queue_scratch(a.queue, total);
   }
   *launched = true;
   g_last_kernel = g.queue ? PHF_HIER_KERNEL_GFX950_ISA_QUEUED : PHF_HIER_KERNEL_GFX950_ISA;
@@ -1225,6 +1250,13 @@ static int hier_advance_impl(const phf_hier_points* pts, const phf_problems* pro
   a.queue = queue; a.quantum = quantum;
   if (int rc = phf_require_device_memory(queue, "queue workspace")) return rc;
   return dispatch_advance(a, (hipStream_t)stream);
+}
+
+int64_t phf_hierarchical_queue_words(const phf_hier_points* pts, const phf_problems* prob) {
+  if (!pts || !prob || prob->num_problems <= 0 || prob->chains_per_problem <= 0 || pts->n_expts < 1)
+    return phf_fail(PHF_ERR_INVALID_ARGUMENT, "phf_hierarchical_queue_words: incomplete phf_hier_points / phf_problems");
+  const int64_t total = (int64_t)((prob->chains_per_problem + kBlock - 1) / kBlock) * prob->num_problems;
+  return hier_queue_words(pts->n_expts, pts->points_per_expt, total);
 }
 
 int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,

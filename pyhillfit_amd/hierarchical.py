@@ -68,15 +68,23 @@ def shape_code(sizes):
 
 # (experiments, shape code) of the point shapes the hand-allocated gfx950 code object has a kernel for (tools/gen_hier_isa_main.py:
 # HIER_KERNELS — the library looks the launch's shape up in its own table and runs the hipcc kernels for any other)
-ISA_SHAPES = {(3, shape_code((4, 4, 4))), (3, shape_code((2, 2, 2))), (3, shape_code((5, 5, 4)))}
+ISA_SHAPES = {(3, shape_code((4, 4, 4))), (3, shape_code((2, 2, 2))), (3, shape_code((5, 5, 4))),
+              (4, shape_code((4, 4, 4, 1))), (4, shape_code((4, 4, 4, 2))), (4, shape_code((4, 4, 4, 3)))}
 
 
-def group_key(experiments):
+# ... and the shapes whose pairs get a launch group of their own.  The Ne = 4 kernels are measured and NOT grouped by default: alone they
+# beat the hipcc kernel by 11 % (15.3 against 17.2 ms per 2 000 iterations of 32 pairs x 1 024 chains), beside the other groups of a Crumb
+# run their 256-thread workgroups pack worse than the hipcc kernel's lone wavefronts (profiles/r05/c4_ne4_assembly_vs_hipcc.txt);
+# PHF_HIER_ISA_NE4=1 groups them.
+GROUPED_SHAPES = {k for k in ISA_SHAPES if k[0] == 3 or os.environ.get("PHF_HIER_ISA_NE4") == "1"}
+
+
+def group_key(experiments, shapes=None):
     """Which launch group a pair belongs to: pairs of one group share a kernel instantiation.  (Ne, 0) in general; (Ne, shape code) for the
     pairs whose point shape the gfx950 assembly build has a kernel for (three experiments of 4 + 4 + 4 points: 147 of the Crumb set's 210
     pairs; 2 + 2 + 2: 6; 5 + 5 + 4: 1) — a group of its own each, so that the launch can state its shape (phf_hier_points.points_per_expt)."""
     key = (len(experiments), shape_code([len(x) for x in experiments]))
-    return key if key in ISA_SHAPES else (key[0], 0)
+    return key if key in (GROUPED_SHAPES if shapes is None else shapes) else (key[0], 0)
 
 
 class PackedHierPoints(object):
@@ -126,6 +134,8 @@ def _bind(lib):
     lib.phf_hierarchical_advance_queued.argtypes = [C.POINTER(HierPoints), C.POINTER(_lib.Problems), C.POINTER(HierPrior),
                                                     C.POINTER(_lib.MhConfig), i64, i64, vp, vp, vp, i64, C.c_int32, vp, vp]
     lib.phf_hierarchical_log_target.argtypes = [C.POINTER(HierPoints), C.POINTER(HierPrior), i64, vp, vp, vp, vp]
+    lib.phf_hierarchical_queue_words.argtypes = [C.POINTER(HierPoints), C.POINTER(_lib.Problems)]
+    lib.phf_hierarchical_queue_words.restype = i64
     lib._phf_hier_bound = True
 
 
@@ -218,7 +228,14 @@ class HierarchicalSampler(object):
         self.moments, self.moments_after, self.t, self.row0, self._gamma = None, 0, 0, None, None
         # work-queue workspace of phf_hierarchical_advance_queued (used by launches that run the gfx950 assembly build on more blocks
         # than the chip holds wavefronts; ignored by every other launch); quantum 0 = the library's choice
-        self.queue = torch.zeros(2 + self.Q * (-(-self.C // 64)), dtype=torch.int32, device=dev)
+        # (ABI 7: the library says how many words — 2 + blocks, plus the device-memory scratch of the Ne = 4 assembly kernels — and
+        # kernel_hint bit 6 states that the workspace has them; the sticky fault word is word 1 + blocks)
+        words = int(self.lib.phf_hierarchical_queue_words(C.byref(self.points.struct), C.byref(self.prob)))
+        if words < 0:
+            raise _lib.PhfError(self.lib.phf_last_error().decode())
+        self.nblocks = self.Q * (-(-self.C // 64))
+        self.queue = torch.zeros(words, dtype=torch.int32, device=dev)
+        self.prob.kernel_hint |= 64
         self.quantum = 0
 
     def set_kernel_hint(self, lanes=0, wps=0, isa=None):
@@ -228,7 +245,7 @@ class HierarchicalSampler(object):
         if lanes not in (0, 1, 2) or wps not in (0, 1, 2):
             raise ValueError("kernel hint: lanes and wps must be 0 (automatic), 1 or 2")
         keep = (self.prob.kernel_hint & 16) if isa is None else (0 if isa else 16)      # isa=None: leave that bit as it is
-        self.prob.kernel_hint = int(lanes) | (int(wps) << 2) | keep
+        self.prob.kernel_hint = int(lanes) | (int(wps) << 2) | keep | (self.prob.kernel_hint & 64)
 
     def init(self, theta0, cov_scale=0.01):
         """theta0: [dim], [Q][dim] or [Q][C][dim]"""
@@ -282,7 +299,7 @@ class HierarchicalSampler(object):
         """The gfx950 assembly build's queued launches raise the workspace's sticky fault word (its last int32) when a wavefront gives
         up waiting for its block's previous quantum: the launch drains and leaves stale chains behind a PHF_OK.  Read wherever the host
         hands results on (acceptance, posterior_moments, state_dict, the end of a run) — PhfError instead of such results."""
-        raise_if_drained(self.queue, "hierarchical")
+        raise_if_drained(self.queue[:2 + self.nblocks], "hierarchical")
 
     def acceptance(self):
         self.check_queue()

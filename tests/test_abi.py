@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_state_sizes(lib):
-    assert lib.phf_version() == 6
+    assert lib.phf_version() == 7
     assert lib.phf_hierarchical_last_kernel() == 0       # nothing launched yet in this thread
     assert lib.phf_philox_rounds() == 7                  # phf_philox.h: PHF_PHILOX_ROUNDS
     assert lib.phf_debug_philox_rounds(8, 1, 1, 1, None) == -1 and b"rounds" in lib.phf_last_error()

@@ -67,7 +67,7 @@ def _setup(gpu, names, oracle_pair, C, thin, adapt, seed, isa, chain_offsets=Non
     from pyhillfit_amd import hierarchical as H
     pairs = [oracle_pair(d, c) for d, c in names]
     packed = H.PackedHierPoints([p.experiments for p in pairs])
-    assert packed.n_expts == 3 and (3, packed.points_per_expt) in H.ISA_SHAPES
+    assert (packed.n_expts, packed.points_per_expt) in H.ISA_SHAPES
     Q = len(names)
     s = H.HierarchicalSampler(packed, list(range(Q)), C, thinning=thin, seed=seed, adapt_start=adapt, problem_ids=[7 + 3 * q for q in range(Q)],
                               chain_id_base=9, chain_offsets=chain_offsets, device=gpu)
@@ -143,6 +143,85 @@ def test_isa_other_point_shapes_bit_identical_to_the_hipcc_kernel_and_the_twin(s
             rows = pk.advance(st, 0, sum(cuts), thin, adapt, gam, seed=20240229, chain_id=9 + c, problem_id=7 + 3 * q)
             assert np.array_equal(got[True][0][:, q, :, c], rows), (shape, q, c)
             assert np.array_equal(state[:, q, c], st), (shape, q, c)
+
+
+NE4 = {"4 + 4 + 4 + 1": [("Amiodarone", "Nav1.5-peak"), ("Amitriptyline", "KvLQT1/mink"), ("Azithromycin", "KvLQT1/mink")],
+       "4 + 4 + 4 + 2": [("Bepridil", "Nav1.5-peak"), ("Dofetilide", "Cav1.2"), ("Propafenone", "hERG")],
+       "4 + 4 + 4 + 3": [("Amiodarone", "Kv4.3"), ("Saquinavir", "hERG"), ("Amiodarone", "Kv4.3")]}
+THETA0_4 = [np.concatenate([t[:4], np.tile(t[4:6], 4), t[-1:]]) for t in THETA0]
+
+
+@pytest.mark.parametrize("shape", sorted(NE4))
+def test_isa_four_experiments_bit_identical_to_the_hipcc_kernel_and_the_twin(shape, gpu, oracle_pair):
+    """phf_hier4_advance_*: the Ne = 4 iteration (13 parameters, 135 doubles of state per chain) at two wavefronts per SIMD — 27 elements
+    of L in registers, 9 + mean + d in LDS, rows 9..12 of L in a device-memory scratch tier inside the queue workspace (ABI 7:
+    phf_hierarchical_queue_words, kernel_hint bit 6).  Rows, state and moments against the hipcc one-lane kernel bit for bit: plain launches
+    cut around the start of the adaptation, a ragged last wavefront; four chains against the scalar twin"""
+    from oracle import c_oracle as co
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import gamma_table
+    names = NE4[shape]
+    C, thin, adapt, cuts = 200, 5, 140, (137, 9, 354)
+    got = {}
+    for isa in (False, True):
+        s, pairs = _setup(gpu, names, oracle_pair, C, thin, adapt, 20240301, isa)
+        assert s.queue.numel() > 2 + s.nblocks + 42 * 128          # the scratch tier is in the workspace
+        s.init(np.array(THETA0_4), cov_scale=0.01)
+        s.enable_moments(after_iteration=adapt + 10)
+        chain = np.concatenate([s.advance(k).cpu().numpy() for k in cuts])
+        assert H.last_kernel() == (4 if isa else 1), H.last_kernel()
+        got[isa] = (chain, s.state.cpu().numpy(), s.moments.cpu().numpy())
+    for name, a, b in zip(("rows", "state", "moments"), got[False], got[True]):
+        same = a.view(np.uint64) == b.view(np.uint64)
+        assert same.all(), (shape, name, int((~same).sum()), np.argwhere(~same)[:5].tolist())
+    acc = got[True][1][-1].mean() / sum(cuts)
+    assert 0.01 < acc < 0.95, acc
+    shapes, scales, locs = H.prior_params()
+    gam = gamma_table(sum(cuts))
+    state = got[True][1].reshape(-1, 3, C)
+    for q in (0, 1):
+        pk = co.PackedHierPair(pairs[q].experiments, shapes, scales, locs)
+        for c in (0, C - 1):
+            st = pk.init_state(THETA0_4[q], 0.01)
+            rows = pk.advance(st, 0, sum(cuts), thin, adapt, gam, seed=20240301, chain_id=9 + c, problem_id=7 + 3 * q)
+            assert np.array_equal(got[True][0][:, q, :, c], rows), (shape, q, c)
+            assert np.array_equal(state[:, q, c], st), (shape, q, c)
+
+
+def test_isa_four_experiments_work_queue_at_full_width(gpu):
+    """all 32 Crumb pairs with 4 + 4 + 4 + 1 points x 4 160 chains = 2 080 blocks on 2 048 wavefront slots: the launch runs as a work queue
+    (a block's quanta chain through its state in HBM, the scratch tier belongs to the resident wavefront, not to the block) — rows, state
+    and moments against the hipcc kernel's plain launch, bit for bit"""
+    import os
+    import torch
+    from conftest import REPO
+    from pyhillfit_amd import bestfit, doseresponse as dr, hierarchical as H
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    shapes, scales, locs = H.prior_params()
+    exs = []
+    for d in dr.drugs:
+        for c in dr.channels:
+            ne, _, ex = dr.load_crumb_data(d, c)
+            if H.group_key(ex, H.ISA_SHAPES) == (4, H.shape_code((4, 4, 4, 1))):
+                exs.append(ex)
+    assert len(exs) == 32
+    packed = H.PackedHierPoints(exs)
+    theta0 = np.array([bestfit.hierarchical_first_iteration(e, locs) for e in exs])
+    got = {}
+    for isa in (False, True):
+        s = H.HierarchicalSampler(packed, list(range(len(exs))), 4160, thinning=5, seed=78, adapt_start=500, device=gpu)
+        s.set_kernel_hint(lanes=1, isa=isa)
+        s.init(theta0, cov_scale=0.01)
+        s.enable_moments(after_iteration=600)
+        s.advance(400, save=False)
+        assert H.last_kernel() == (5 if isa else 1), H.last_kernel()
+        rows = torch.cat([s.advance(k) for k in (300, 200)])
+        torch.cuda.synchronize()
+        s.check_queue()
+        got[isa] = (rows, s.state.clone(), s.moments.clone())
+    for name, a, b in zip(("rows", "state", "moments"), got[False], got[True]):
+        same = a.view(torch.int64) == b.view(torch.int64)
+        assert bool(same.all()), (name, int((~same).sum()))
 
 
 def test_isa_advance_bit_identical_to_the_twin(gpu, oracle_pair):
@@ -296,7 +375,7 @@ def test_isa_work_queue_bit_identical_at_full_width(gpu):
         assert H.last_kernel() == (5 if isa else 1), H.last_kernel()
         rows = torch.cat([s.advance(k) for k in (300, 500)])
         torch.cuda.synchronize()
-        assert int(s.queue[-1]) == 0                                  # the queue's sticky fault word
+        assert int(s.queue[1 + s.nblocks]) == 0                                  # the queue's sticky fault word
         got[isa] = (rows, s.state.clone(), s.moments.clone())
     for name, a, b in zip(("rows", "state", "moments"), got[False], got[True]):
         same = a.view(torch.int64) == b.view(torch.int64)
@@ -325,10 +404,10 @@ def test_hierarchical_drained_queue_raises_and_checkpoint_continues_bit_identica
     bad = dict(sd); bad["philox_rounds"] = 10 if sd["philox_rounds"] != 10 else 7
     with pytest.raises(_lib.PhfError, match="bit-identically"):
         s2.load_state_dict(bad)
-    s.queue[-1] = 1
+    s.queue[1 + s.nblocks] = 1
     s.advance(100, save=False)
     torch.cuda.synchronize()
-    assert int(s.queue[-1].item()) == 1                                      # sticky
+    assert int(s.queue[1 + s.nblocks].item()) == 1                                      # sticky
     for call in (s.acceptance, s.posterior_moments, s.state_dict):
         with pytest.raises(_lib.PhfError, match="drained"):
             call()

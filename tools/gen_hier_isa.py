@@ -48,7 +48,8 @@ ARGS = [("consts", "const void*"), ("state", "double*"), ("rows", "double*"), ("
         ("bpp_magic", "uint32_t"), ("total_waves", "int32_t"), ("seed_lo", "uint32_t"), ("seed_hi", "uint32_t"),
         ("chain_id_base", "uint32_t"), ("pts_stride", "int32_t"), ("until_save0", "int32_t"), ("quantum", "uint32_t"),
         ("num_tasks", "int32_t"), ("blocks_magic", "uint32_t"), ("rows_per_quantum", "uint32_t"), ("pad0", "int32_t"),
-        ("prior_loc", "double[5]"), ("prior_inv_scale", "double[5]"), ("prior_shape_m1", "double[5]"), ("three_twelve", "double[2]")]
+        ("prior_loc", "double[5]"), ("prior_inv_scale", "double[5]"), ("prior_shape_m1", "double[5]"), ("three_twelve", "double[2]"),
+        ("scratch", "double*")]
 
 
 def arg_layout(args=None):

@@ -20,6 +20,7 @@ from gen_hier_isa import ARG_BYTES, ARG_OFF, Gen
 # share lgkmcnt with the LDS and return out of order, so every table look-up behind one waits for it: ~11 exposed scalar-memory latencies
 # per iteration, measured as 20 % of the wavefront's cycles in s_waitcnt.)
 WAVE_BASE = 8064                                    # behind the workgroup's tables (M.TABLE_BYTES, padded)
+GLB_FIRST_ROW, G_AHEAD = 9, 3                       # Ne = 4: rows 9..12 of L live in the scratch tier, fetched three columns ahead
 
 RESIDENT = ["L2E64", "NLN2HI64", "NLN2LO64", "KE0", "KE1", "K100", "KL0", "KL1", "KL2", "LN2HI", "LN2LO", "LN10", "ISQRT2",
             "M746", "P710", "P40", "P6", "QUARTER", "LOGADD", "MBITS"]
@@ -43,7 +44,7 @@ def kernel_name(ne, shape):
 def configure(ne, shape):
     """the module's layout constants for a kernel of `ne` experiments with shape[i] points in experiment i"""
     global NE, D, TRI, S_TH, S_LT, S_MEAN, S_TRI, S_LOGA, S_NACC, SHAPE, N_PTS, PT_START, PT_OFF, PT_YOFF, LDS_L, SLOT_MEAN, SLOT_D, SLOT_L, NSLOTS
-    global U_POINTS, U_LOC, U_ISC, U_SM1, U_BYTES, WAVE_LDS, LDS_BYTES, NAME
+    global U_POINTS, U_LOC, U_ISC, U_SM1, U_BYTES, WAVE_LDS, LDS_BYTES, NAME, GLB_L
     assert len(shape) == ne and all(1 <= n <= 8 for n in shape)
     NE, D = ne, 5 + 2 * ne
     TRI = D * (D + 1) // 2
@@ -53,7 +54,17 @@ def configure(ne, shape):
     pad = [n + (n & 1) for n in shape]
     PT_OFF = [16 * sum(pad[:i]) for i in range(ne)]                    # its block in the uniform area: [ln c (pad)][y (pad)]
     PT_YOFF = [8 * pad[i] for i in range(ne)]
-    LDS_L = [(i, 0) for i in range(1, D)] + [(i, 1) for i in range(2, 5)]
+    if ne == 3:
+        LDS_L = [(i, 0) for i in range(1, D)] + [(i, 1) for i in range(2, 5)]
+        GLB_L = []
+    else:
+        # Ne = 4: 135 doubles of state per chain against 128 registers + 35 LDS slots per lane at two wavefronts per SIMD: a THIRD tier,
+        # a scratch area in device memory (L2-resident: 21 KB per resident wavefront), holds the last rows of L — four elements per
+        # column, loaded G_AHEAD columns ahead of their use and stored back as the sweep produces them
+        GLB_L = [(i, kc) for kc in range(D) for i in range(max(kc + 1, GLB_FIRST_ROW), D)]          # column by column: the order of use
+        # ... and of the rows above them the LATE columns' elements go to LDS (columns 4..6: by then the sweep has returned the registers
+        # of w_0..w_3 and u_0..u_3; column 0 is where every register is taken)
+        LDS_L = [(i, kc) for kc, first in ((4, 5), (5, 6), (6, 7)) for i in range(first, GLB_FIRST_ROW)]
     SLOT_MEAN, SLOT_D, SLOT_L = 0, D, 2 * D
     NSLOTS = 2 * D + len(LDS_L)
     U_POINTS, U_LOC = 0, 16 * sum(pad)
@@ -125,6 +136,19 @@ class Main(object):
     def l_slot(self, i, kcol):
         return SLOT_L + LDS_L.index((i, kcol))
 
+    def g_addr(self, key):
+        """(SGPR base pair, immediate) of scratch slot GLB_L.index(key): bases sit every 16 slots, in the middle of their 8 KB"""
+        gidx = GLB_L.index(key)
+        return self.s_wsb[gidx // 16], (gidx % 16 - 8) * 512
+
+    def g_load(self, dst, key):
+        base, imm = self.g_addr(key)
+        self.k.gload(dst, self.v_lane8, base, imm)
+
+    def g_store(self, key, src):
+        base, imm = self.g_addr(key)
+        self.k.gstore(self.v_lane8, src, base, imm)
+
     # ------------------------------------------------------------------------------------------------------------ prologue
     def ptr(self, name):
         r = self.k.sd()
@@ -146,6 +170,7 @@ class Main(object):
         self.s_wave, self.s_block, self.s_quant = k.s1(), k.s1(), k.s1()      # wave in the workgroup; the task: block, quantum
         self.s_nch8, self.s_rows, self.s_rstride, self.s_mom = k.sd(), k.sd(), k.sd(), k.sd()
         self.s_gamma, self.s_acc, self.s_queue = k.sd(), k.sd(), k.sd()
+        self.s_wsb = [k.sd() for _ in range((len(GLB_L) + 15) // 16)]
         g.stage_tables(s_consts)
         k.free(s_consts)
         self.v_lane, self.v_lane8, self.v_lds, self.v_ulds, self.v_cid = k.v1(), k.v1(), k.v1(), k.v1(), k.v1()
@@ -163,6 +188,22 @@ class Main(object):
         k.sop("s_add_u32", tmp, tmp, Lit(NSLOTS * 512))
         k.mov32(self.v_ulds, tmp)
         k.s_load(self.s_queue, g.kernarg, self.ARG_OFF["queue"])
+        if GLB_L:
+            # this wavefront's scratch: scratch + (workgroup * 4 + wave) * slots * 512 bytes; base j = slot 16 j + 8
+            per_wave = len(GLB_L) * 512
+            t2 = k.sd()
+            k.s_load(self.s_wsb[0], g.kernarg, self.ARG_OFF["scratch"])
+            k.sop("s_lshl_b32", tmp, g.wg_id, 2)
+            k.sop("s_add_u32", tmp, tmp, self.s_wave)
+            k.sop("s_mul_hi_u32", t2.hi(), tmp, Lit(per_wave))
+            k.sop("s_mul_i32", t2.lo(), tmp, Lit(per_wave))
+            k.sop("s_add_u32", t2.lo(), t2.lo(), Lit(8 * 512))
+            k.sop("s_addc_u32", t2.hi(), t2.hi(), 0)
+            self.add64(self.s_wsb[0], self.s_wsb[0], t2)
+            for j in range(1, len(self.s_wsb)):
+                k.sop("s_add_u32", self.s_wsb[j].lo(), self.s_wsb[j - 1].lo(), Lit(16 * 512))
+                k.sop("s_addc_u32", self.s_wsb[j].hi(), self.s_wsb[j - 1].hi(), 0)
+            k.free(t2)
         k.free(vt, tmp)
         # the chain state's registers
         self.th = [k.vd() for _ in range(D)]
@@ -171,7 +212,7 @@ class Main(object):
         self.Lreg = {}
         for i in range(1, D):
             for kc in range(i):
-                if (i, kc) not in LDS_L:
+                if (i, kc) not in LDS_L and (i, kc) not in GLB_L:
                     self.Lreg[(i, kc)] = k.vd()
         self.loga, self.nacc, self.sc, self.logu = k.vd(), k.vd(), k.vd(), k.vd()
         k.s_waitcnt_all()
@@ -510,8 +551,17 @@ class Main(object):
                 slot = SLOT_D + key
             elif key in self.Lreg:
                 reg = self.Lreg[key]
+            elif key in GLB_L:
+                slot = ("glb", key)
             else:
                 slot = self.l_slot(*key)
+
+            def put(s_, t_):
+                if isinstance(s_, tuple):
+                    self.g_store(s_[1], t_)
+                else:
+                    self.lds_store(s_, t_)
+
             if load:
                 if reg is not None:
                     k.gload(reg, self.v_lane8, cur)
@@ -524,17 +574,20 @@ class Main(object):
                     k.gstore(self.v_lane8, reg, cur)
                 else:
                     t = k.vd()
-                    self.lds_load(t, slot)
+                    if isinstance(slot, tuple):
+                        self.g_load(t, slot[1])
+                    else:
+                        self.lds_load(t, slot)
                     k.gstore(self.v_lane8, t, cur)
                     k.free(t)
             self.add64(cur, cur, self.s_nch8)
             if load and len(temps) == 12:
                 for t, s in temps:
-                    self.lds_store(s, t)
+                    put(s, t)
                     k.free(t)
                 temps = []
         for t, s in temps:
-            self.lds_store(s, t)
+            put(s, t)
             k.free(t)
 
     # ------------------------------------------------------------------------------------------------------------ draws
@@ -543,8 +596,8 @@ class Main(object):
         (word j of block b is normal 4 b + j) and log u (the last word of the last block).  The parts of the first rounds that do
         not depend on the lane run on the scalar unit; the three blocks advance round by round side by side."""
         k, c = self.k, self.c
-        k.comment("---- draws of iteration t: 3 Philox4x32-7 blocks -> 11 normals and log u ----")
-        NB, R = 3, 7
+        NB, R = (D + 3) // 4, 7
+        k.comment("---- draws of iteration t: %d Philox4x32-7 blocks -> %d normals and log u ----" % (NB, D))
         s = [k.s1() for _ in range(8)]
         p1lo, p1hi, n0u, p0ulo, p0uhi, ka, kb, tx = s
 
@@ -637,6 +690,20 @@ class Main(object):
         k.label(l_gdone, drain=False)
         k.free(tmp, cur)
 
+    def g_fetch_column(self, kc):
+        """issue the loads of column kc's scratch-tier elements (self.gq: element -> register pair)"""
+        for i in range(kc + 1, D):
+            if (i, kc) in GLB_L:
+                self.gq[(i, kc)] = self.k.vd()
+                self.g_load(self.gq[(i, kc)], (i, kc))
+
+    def sweep_prefetch(self):
+        """top of the loop, ahead of the draws: the scratch-tier elements of the sweep's first columns (a device-memory latency that the
+        draws cover)"""
+        self.gq = {}
+        for kc in range(G_AHEAD if GLB_L else 0):
+            self.g_fetch_column(kc)
+
     def sweep(self):
         """the adaptation of iteration t - 1 (hier_advance_body: mean, loga, PHF_LDL_COLUMN column by column) fused with
         y = L sqrt(d) z of iteration t's proposal; v_gs = gamma (0.0 where the C code does not adapt: an exact no-op).
@@ -648,13 +715,7 @@ class Main(object):
         k.add(omg, 1.0, Neg(gs))
         # w = theta - mean; mean <- g theta + (1 - g) mean
         w = [k.vd() for _ in range(D)]
-        mt = [k.vd() for _ in range(D)]
-        for i in range(D):
-            self.lds_load(mt[i], SLOT_MEAN + i)
         dq = {}
-        for kc in range(2):                                  # the first diagonals: in flight while the mean is updated
-            dq[kc] = k.vd()
-            self.lds_load(dq[kc], SLOT_D + kc)
         lq = {}
 
         def fetch_column(kc):
@@ -663,13 +724,44 @@ class Main(object):
                     lq[(i, kc)] = k.vd()
                     self.lds_load(lq[(i, kc)], self.l_slot(i, kc))
 
-        fetch_column(0)
-        for i in range(D):
-            k.sub(w[i], self.th[i], mt[i])
-            k.mul(mt[i], omg, mt[i])
-            k.fma(mt[i], gs, self.th[i], mt[i])
-            self.lds_store(SLOT_MEAN + i, mt[i])
-        k.free(mt)
+        def mean_update(rows, mt):
+            for j, i in enumerate(rows):
+                k.sub(w[i], self.th[i], mt[j])
+                k.mul(mt[j], omg, mt[j])
+                k.fma(mt[j], gs, self.th[i], mt[j])
+                self.lds_store(SLOT_MEAN + i, mt[j])
+
+        if not GLB_L:
+            mt = [k.vd() for _ in range(D)]
+            for i in range(D):
+                self.lds_load(mt[i], SLOT_MEAN + i)
+            for kc in range(2):                              # the first diagonals: in flight while the mean is updated
+                dq[kc] = k.vd()
+                self.lds_load(dq[kc], SLOT_D + kc)
+            fetch_column(0)
+            mean_update(range(D), mt)
+            k.free(mt)
+        else:
+            # (register budget: the mean goes through five doubles at a time, the next group's reads in flight behind the current one's arithmetic)
+            groups = [list(range(i0, min(i0 + 5, D))) for i0 in range(0, D, 5)]
+            mts = []
+            for gi, rows in enumerate(groups[:2]):
+                mts.append([k.vd() for _ in rows])
+                for j, i in enumerate(rows):
+                    self.lds_load(mts[gi][j], SLOT_MEAN + i)
+            for gi, rows in enumerate(groups):
+                mean_update(rows, mts[gi])
+                k.free(mts[gi])
+                if gi + 2 < len(groups):
+                    nxt = groups[gi + 2]
+                    mts.append([k.vd() for _ in nxt])
+                    for j, i in enumerate(nxt):
+                        self.lds_load(mts[gi + 2][j], SLOT_MEAN + i)
+                if gi == len(groups) - 2:
+                    for kc in range(2):
+                        dq[kc] = k.vd()
+                        self.lds_load(dq[kc], SLOT_D + kc)
+                    fetch_column(0)
         # loga <- loga + g ((accepted ? 1 : 0) - 1/4)
         a01 = k.vd()
         k.mov32(a01.lo(), 0)
@@ -692,6 +784,13 @@ class Main(object):
             k.free(dq.pop(kc))
             return h
 
+        def source(i, kc):
+            if (i, kc) in LDS_L:
+                return lq[(i, kc)]
+            if (i, kc) in GLB_L:
+                return self.gq[(i, kc)]
+            return self.Lreg[(i, kc)]
+
         hd = head(0)
         for kc in range(D):
             if kc + 2 < D:
@@ -699,9 +798,11 @@ class Main(object):
                 self.lds_load(dq[kc + 2], SLOT_D + kc + 2)
             if kc + 1 < D:
                 fetch_column(kc + 1)
+            if GLB_L and kc + G_AHEAD < D:
+                self.g_fetch_column(kc + G_AHEAD)
             dk, ap, dn = hd["dk"], hd["ap"], hd["dn"]
             inv, beta, sq = k.vd(), k.vd(), k.vd()
-            lik = {i: (lq[(i, kc)] if (i, kc) in LDS_L else self.Lreg[(i, kc)]) for i in range(kc + 1, D)}
+            lik = {i: source(i, kc) for i in range(kc + 1, D)}
             with k.parallel() as par:
                 par.stream()                                 # 1 / dn (or 0), beta, the next alpha
                 M.rcp(m, [inv], [dn])
@@ -724,15 +825,24 @@ class Main(object):
                 for i in range(kc + 1, D):
                     if (i, kc) in LDS_L:
                         self.lds_store(self.l_slot(i, kc), lik[i])
+                    elif (i, kc) in GLB_L:
+                        self.g_store((i, kc), lik[i])
                     k.fma(y[i], lik[i], self.zn[kc], 0.0 if kc == 0 else y[i])
                     if (i, kc) in LDS_L:
                         k.free(lq.pop((i, kc)))
+                    elif (i, kc) in GLB_L:
+                        k.free(self.gq.pop((i, kc)))
                 k.add(y[kc], 0.0 if kc == 0 else y[kc], self.zn[kc])
                 if kc + 1 < D:
                     par.stream()                             # the head of the next column (alpha and w_{k+1} are final)
                     hd = head(kc + 1)
             k.free(beta)
-        k.free(pos, omg, alpha, w, self.zn)
+            if GLB_L:                                        # column kc is done with w_k and u_k: their registers take later columns' prefetches
+                k.free(w[kc], self.zn[kc])
+        if GLB_L:
+            k.free(pos, omg, alpha)
+        else:
+            k.free(pos, omg, alpha, w, self.zn)
         # the scale of the next proposal: e^(loga / 2)
         h = k.vd()
         k.mul(h, self.loga, 0.5)
@@ -1089,6 +1199,7 @@ class Main(object):
         l_loop, l_exit = k.new_label("loop"), k.new_label("exit")
         k.label(l_loop)
         self.load_gamma()
+        self.sweep_prefetch()
         self.draws()
         k.count_marker("draws")
         self.sweep()
@@ -1138,12 +1249,14 @@ class Main(object):
         self.info["sgpr_high_water"] = k.s.high
         self.info["lds_bytes_per_workgroup"] = LDS_BYTES
         self.info["lds_slots_per_wavefront"] = NSLOTS
+        self.info["scratch_slots_per_wavefront"] = len(GLB_L)
         return lines_meta, self.info
 
 
 # the kernels of the code object: (experiments, points per experiment).  The Crumb set's 154 pairs with three experiments are 147 x (4, 4, 4),
 # 6 x (2, 2, 2) and 1 x (5, 5, 4)
-HIER_KERNELS = [(3, (4, 4, 4)), (3, (2, 2, 2)), (3, (5, 5, 4))]
+# ... and the 41 with four are 32 x (4, 4, 4, 1), 5 x (4, 4, 4, 2), 2 x (4, 4, 4, 3), (2, 2, 2, 1), (5, 5, 5, 1)
+HIER_KERNELS = [(3, (4, 4, 4)), (3, (2, 2, 2)), (3, (5, 5, 4)), (4, (4, 4, 4, 1)), (4, (4, 4, 4, 2)), (4, (4, 4, 4, 3))]
 
 
 def main_kernel(ne=3, shape=(4, 4, 4)):
@@ -1166,10 +1279,11 @@ def main_kernels():
 def header_extra(kernels):
     info = kernels[0][5]
     text = "#define PHF_ISA_HIER3_LDS_BYTES %d\n#define PHF_ISA_HIER3_VGPRS %d\n\n" % (info["lds_bytes_per_workgroup"], info["vgpr_high_water"])
-    text += ("/* the hierarchical iteration's kernels: experiments, PHF_HIER_SHAPE code of the point shape (phf_hier_points.points_per_expt), name */\n"
+    text += ("/* the hierarchical iteration's kernels: experiments, PHF_HIER_SHAPE code of the point shape (phf_hier_points.points_per_expt),\n"
+             " * scratch_slots (doubles per lane of device-memory scratch a resident wavefront keeps part of its chains' state in), name */\n"
              "#define PHF_ISA_HIER_NUM_KERNELS %d\n"
-             "static const struct { int n_expts; int shape_code; const char* name; } phf_isa_hier_kernels[PHF_ISA_HIER_NUM_KERNELS] = {\n" % len(kernels))
-    for ne, shape, code, name, _, _ in kernels:
+             "static const struct { int n_expts; int shape_code; int scratch_slots; const char* name; } phf_isa_hier_kernels[PHF_ISA_HIER_NUM_KERNELS] = {\n" % len(kernels))
+    for ne, shape, code, name, _, kinfo in kernels:
         assert code is not None
-        text += "    {%d, %d, \"%s\"}, /* %s */\n" % (ne, code, name, " + ".join(str(n) for n in shape))
+        text += "    {%d, %d, %d, \"%s\"}, /* %s */\n" % (ne, code, kinfo["scratch_slots_per_wavefront"], name, " + ".join(str(n) for n in shape))
     return text + "};\n\n"

@@ -538,6 +538,10 @@ class Kernel(object):
     def count_marker(self, name):
         """instruction counts (self.counts) are snapshotted under `name` when the final pass reaches this point"""
         self._rec({"kind": "marker", "name": name})
+        # registers in use at most since the previous marker, and now (generation time: that is when they are allocated)
+        self.phase_vgprs = getattr(self, "phase_vgprs", [])
+        self.phase_vgprs.append((name, self.max_v_in_use + self.v.lo, self.v.in_use() + self.v.lo))
+        self.max_v_in_use = self.v.in_use()
 
     def finalize(self):
         """program order is final: insert s_waitcnt / s_nop and produce the text"""
