@@ -185,10 +185,14 @@ class HierarchicalBatch(object):
         """experiments: the pairs' experiments when they are not Crumb pairs (s3h: the generated set)"""
         from pyhillfit_amd import hierarchical as H
         self.torch, self.dev = torch, dev
+        # PHF_BENCH_HIER_FUSED=0: every group a launch of its own on its own stream (what rounds 1-5 measured); default: the groups the
+        # gfx950 code object has kernels for — Ne = 3 and the 4 + 4 + 4 + {1, 2, 3} shapes of Ne = 4 — in ONE persistent grid
+        # (phf_hierarchical_advance_fused), the rest beside it on streams of their own
+        self.use_fused = os.environ.get("PHF_BENCH_HIER_FUSED", "1") != "0"
         groups = {}
         for p, (d_, c_) in enumerate(names):
             ex = dr.load_crumb_data(d_, c_)[2] if experiments is None else experiments[p]
-            groups.setdefault(H.group_key(ex), []).append((p, ex))
+            groups.setdefault(H.group_key(ex, H.ISA_SHAPES if self.use_fused else None), []).append((p, ex))
         shapes, scales, locs = H.prior_params()
         self.samplers = []
         for (ne, _), members in sorted(groups.items(), reverse=True):
@@ -215,7 +219,17 @@ class HierarchicalBatch(object):
         if set(groups) == {(3, 4)}:                        # every pair has three experiments of four points (s3h): one launch of the assembly kernel
             self.kernel_name = "phf_hier3_advance (hand-allocated gfx950 build of the Ne = 3 iteration, work queue)"
         H.hint_side_by_side(self.samplers)                 # the groups run side by side: one lane per chain once they fill the chip together
-        self.streams = [torch.cuda.Stream(device=dev) for _ in self.samplers]
+        # launch units: the fused set (one launch, one stream), then every other sampler (a launch and a stream each)
+        in_fused = [h for h in self.samplers if self.use_fused and (h.n_expts, h.points.packed.points_per_expt) in H.ISA_SHAPES]
+        self.fused = H.FusedSamplers(in_fused) if len(in_fused) > 1 else None
+        if self.fused is None:
+            in_fused = []
+        self.fused_index = [self.samplers.index(h) for h in in_fused]
+        self.single_index = [j for j in range(len(self.samplers)) if j not in self.fused_index]
+        if self.fused is not None:
+            self.kernel_name = ("phf_hier_fused_advance (one persistent grid, a body per (Ne, point shape): %d of the %d launch groups) + hier_advance_kernel<Ne> "
+                                "for the other groups on streams of their own" % (len(in_fused), len(self.samplers)))
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(len(self.single_index) + (1 if self.fused is not None else 0))]
 
     def enable_moments(self):
         [h.enable_moments(after_iteration=0) for h in self.samplers]
@@ -235,10 +249,17 @@ class HierarchicalBatch(object):
         # drives its segments.  The caller joins once at the end (self.join()).
         torch = self.torch
         cur = torch.cuda.current_stream(self.dev)
-        for h, o, st in zip(self.samplers, out, self.streams):
+        streams = list(self.streams)
+        for j in self.single_index:                       # the hipcc groups first: their lone wavefronts take whole SIMDs, the persistent grid what is left
+            st = streams.pop(0)
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                h.advance(I, out=o)
+                self.samplers[j].advance(I, out=out[j])
+        if self.fused is not None:
+            st = streams.pop(0)
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self.fused.advance(I, out=[out[j] for j in self.fused_index])
         if join:
             self.join()
 
@@ -264,6 +285,8 @@ class HierarchicalBatch(object):
         return max(b.elapsed_time(e) for b, e in zip(self.ev_start, self.ev_end))
 
     def acceptance_summary(self):
+        if self.fused is not None:
+            self.fused.check_queue()
         return self.torch.cat([h.acceptance().mean(dim=1) for h in self.samplers])
 
 

@@ -269,6 +269,25 @@ int phf_hierarchical_advance_queued(const phf_hier_points* pts, const phf_proble
  * 4 + 4 + 4 + 1 / 2 / 3 points).  Reads only n_expts, points_per_expt, num_problems and chains_per_problem; no device call.  < 0: error. */
 int64_t phf_hierarchical_queue_words(const phf_hier_points* pts, const phf_problems* prob);
 
+/* EVERY launch group of a run through ONE persistent grid (ABI 7; phf_hier_fused_advance of the gfx950 code object: a body per (n_expts, point
+ * shape), a wavefront that finishes a task of one group pulls the next task whatever group it belongs to).  Separate launches side by side —
+ * one stream per group, what python/PyHillFit.py's pool amounts to (:997-1003) — leave a chip's workgroup slots to whichever persistent grid
+ * got them first; one queue does not.  groups: 1..6 of them, each with a (n_expts, points_per_expt) the code object has a kernel for
+ * (PHF_ERR_UNSUPPORTED otherwise: launch such groups one by one), no two alike; the same thinning in every cfg; t_begin a multiple of it.
+ * Every chain's numbers are those of phf_hierarchical_advance, bit for bit.  queue: device int32 [phf_hierarchical_fused_queue_words()],
+ * zeroed by the caller when allocated; word 1 + (the groups' blocks) is the sticky fault flag. */
+typedef struct phf_hier_group {
+  const phf_hier_points* pts;
+  const phf_problems* prob;
+  const phf_mh_config* cfg;      /* seed, thinning, adapt_start, gamma of THIS group (adapt_start = 100 dim differs with n_expts) */
+  double* state;                 /* device [phf_hierarchical_state_size(n_expts)][Q C] */
+  double* rows;                  /* device [rows][Q][dim + 1][C] or NULL */
+  double* moments;               /* device [2 (dim + 1)][Q C] or NULL */
+} phf_hier_group;
+int64_t phf_hierarchical_fused_queue_words(int32_t n_groups, const phf_hier_group* groups);
+int phf_hierarchical_advance_fused(int32_t n_groups, const phf_hier_group* groups, const phf_hier_prior* prior, int64_t t_begin, int64_t t_end,
+                                   int64_t moments_after, int32_t quantum, int32_t* queue, void* stream);
+
 /* Which kernel runs groups with Ne = 3..6, PROCESS-WIDE (ABI 4; A/B timing and the bit-identity tests): lanes 1 | 2 = one | two lanes
  * per chain, wps 1 | 2 = the register build of the two-lane kernel (512 | 256 registers); 0 = not forced: the launch's own
  * phf_problems.kernel_hint, else the launch size, decides.  The environment variables PHF_HIER_LANES / PHF_HIER_WPS give the initial
@@ -282,6 +301,7 @@ int phf_hierarchical_set_kernel_policy(int lanes, int wps);
 #define PHF_HIER_KERNEL_WAVE 3         /* hier_wave_advance_kernel: one wavefront per chain (Ne > 8) */
 #define PHF_HIER_KERNEL_GFX950_ISA 4   /* phf_hier3_advance: the hand-allocated gfx950 build (Ne = 3, four points per experiment) */
 #define PHF_HIER_KERNEL_GFX950_ISA_QUEUED 5   /* ... as a work queue (phf_hierarchical_advance_queued) */
+#define PHF_HIER_KERNEL_GFX950_ISA_FUSED 6    /* ... every group of a run in one persistent grid (phf_hierarchical_advance_fused, ABI 7) */
 int phf_hierarchical_last_kernel(void);
 
 /* log_target_distribution (python/PyHillFit.py:173-193) at M parameter vectors: theta device [dim][M]. */

@@ -11,7 +11,7 @@ ABI_VERSION = 7
 # every symbol include/pyhillfit_amd.h declares
 EXPORTS = ["phf_version", "phf_last_error", "phf_simd_count", "phf_single_level_state_size", "phf_single_level_init",
            "phf_single_level_advance", "phf_single_level_advance_queued", "phf_single_level_queue_status", "phf_single_level_last_kernel", "phf_single_level_log_target",
-           "phf_debug_math", "phf_debug_isa", "phf_philox_rounds", "phf_debug_philox", "phf_debug_philox_rounds", "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance", "phf_hierarchical_advance_queued", "phf_hierarchical_queue_words",
+           "phf_debug_math", "phf_debug_isa", "phf_philox_rounds", "phf_debug_philox", "phf_debug_philox_rounds", "phf_hierarchical_state_size", "phf_hierarchical_init", "phf_hierarchical_advance", "phf_hierarchical_advance_queued", "phf_hierarchical_queue_words", "phf_hierarchical_advance_fused", "phf_hierarchical_fused_queue_words",
            "phf_hierarchical_set_kernel_policy", "phf_hierarchical_last_kernel", "phf_hierarchical_log_target", "phf_predictive_scratch_bytes", "phf_predictive_accumulate"]
 
 

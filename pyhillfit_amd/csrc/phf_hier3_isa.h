@@ -22,6 +22,9 @@ int phf_hier_isa_scratch_slots(int n_expts, int shape_code);
 // a->total_waves for a plain launch (a->queue == NULL), the chip's wavefront slots for a queued one
 int phf_hier_isa_advance(int which, phf_hier3_isa_args* a, int grid_waves, hipStream_t stream);
 
+// launch phf_hier_fused_advance (every body in one persistent grid): `a` complete except `consts`
+int phf_hier_isa_fused_advance(phf_hier_fused_args* a, int grid_waves, hipStream_t stream);
+
 // the same for phf_sl3_advance: the single-level model-2 iteration (no moments), plain or queued
 bool phf_sl3_isa_available();
 int phf_sl3_isa_advance(phf_sl3_isa_args* a, int grid_waves, hipStream_t stream);

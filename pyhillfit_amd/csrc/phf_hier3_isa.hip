@@ -45,6 +45,7 @@ struct DeviceModule {
   char msg[256] = "";
   hipModule_t module = nullptr;
   hipFunction_t advance[PHF_ISA_HIER_NUM_KERNELS] = {};      // phf_isa_hier_kernels[]: one per (experiments, point shape)
+  hipFunction_t fused = nullptr;                               // phf_hier_fused_advance: every body in one persistent grid
   hipFunction_t sl_advance = nullptr;
   hipFunction_t unit[kNumUnits] = {};
   void* consts = nullptr;                      // tables + scalar constants, device memory, lives as long as the process
@@ -102,6 +103,8 @@ void load_module(DeviceModule* m) {
     e = hipModuleGetFunction(&m->advance[i], m->module, phf_isa_hier_kernels[i].name);
     if (e != hipSuccess) { m->advance[i] = nullptr; (void)hipGetLastError(); }   // a units-only code object (generator bring-up)
   }
+  e = hipModuleGetFunction(&m->fused, m->module, "phf_hier_fused_advance");
+  if (e != hipSuccess) { m->fused = nullptr; (void)hipGetLastError(); }
   e = hipModuleGetFunction(&m->sl_advance, m->module, "phf_sl3_advance");
   if (e != hipSuccess) { m->sl_advance = nullptr; (void)hipGetLastError(); }
   const std::vector<unsigned char> blob = build_blob();
@@ -160,6 +163,14 @@ int phf_hier_isa_advance(int which, phf_hier3_isa_args* a, int grid_waves, hipSt
   a->consts = m->consts;
   const unsigned blocks = (unsigned)((grid_waves + 3) / 4);
   return launch(m->advance[which], blocks, a, sizeof(*a), stream, "phf_hierarchical_advance (gfx950 assembly)");
+}
+
+int phf_hier_isa_fused_advance(phf_hier_fused_args* a, int grid_waves, hipStream_t stream) {
+  DeviceModule* m = nullptr;
+  if (int rc = get_module(&m)) return rc;
+  if (!m->fused) return phf_fail(PHF_ERR_UNSUPPORTED, "gfx950 code object holds no phf_hier_fused_advance");
+  a->consts = m->consts;
+  return launch(m->fused, (unsigned)((grid_waves + 3) / 4), a, sizeof(*a), stream, "phf_hierarchical_advance_fused (gfx950 assembly)");
 }
 
 bool phf_sl3_isa_available() {

@@ -996,17 +996,11 @@ int64_t hier_queue_words(int n_expts, int shape_code, int64_t total) {
   return words;
 }
 
-int launch_isa(const HierArgs& a, hipStream_t stream, bool* launched) {
-  *launched = false;
+// the argument block of one launch group for the gfx950 kernels (generated/phf_hier3_isa_layout.h): everything but the queue-level fields
+void fill_isa_args(const HierArgs& a, phf_hier3_isa_args* gp) {
+  phf_hier3_isa_args& g = *gp;
   const int64_t bpp = a.blocks_per_problem;
   const int64_t total = bpp * a.prob.num_problems;
-  if (a.cfg.adapt_start < 0 || a.t_end >= 0xffffffffLL || total > 0x7fffffffLL) return PHF_OK;   // hipcc kernels
-  // a kernel that keeps part of the state in device-memory scratch needs the caller's word that the workspace holds it (kernel_hint bit 6)
-  const int scratch_slots = phf_hier_isa_scratch_slots(a.pts.n_expts, a.pts.points_per_expt);
-  if (scratch_slots > 0 && (!a.queue || !(a.prob.kernel_hint & 64u))) return PHF_OK;
-  const int which = phf_hier_isa_find(a.pts.n_expts, a.pts.points_per_expt);
-  if (which < 0) return PHF_OK;
-  phf_hier3_isa_args g{};
   g.state = a.state; g.rows = a.rows; g.moments = a.moments; g.gamma = a.cfg.gamma;
   g.ln_conc = a.pts.ln_conc; g.response = a.pts.response; g.pair_index = a.prob.pair_index; g.problem_id = a.prob.problem_id;
   g.launch_order = a.prob.launch_order; g.chain_offset = a.prob.chain_offset;
@@ -1022,6 +1016,20 @@ int launch_isa(const HierArgs& a, hipStream_t stream, bool* launched) {
   g.until_save0 = a.cfg.thinning - (int32_t)(a.t_begin % a.cfg.thinning);
   for (int i = 0; i < 5; ++i) { g.prior_loc[i] = a.prior.loc[i]; g.prior_inv_scale[i] = a.prior.inv_scale[i]; g.prior_shape_m1[i] = a.prior.shape_m1[i]; }
   g.three_twelve[0] = 3.0; g.three_twelve[1] = 12.0;
+}
+
+int launch_isa(const HierArgs& a, hipStream_t stream, bool* launched) {
+  *launched = false;
+  const int64_t bpp = a.blocks_per_problem;
+  const int64_t total = bpp * a.prob.num_problems;
+  if (a.cfg.adapt_start < 0 || a.t_end >= 0xffffffffLL || total > 0x7fffffffLL) return PHF_OK;   // hipcc kernels
+  // a kernel that keeps part of the state in device-memory scratch needs the caller's word that the workspace holds it (kernel_hint bit 6)
+  const int scratch_slots = phf_hier_isa_scratch_slots(a.pts.n_expts, a.pts.points_per_expt);
+  if (scratch_slots > 0 && (!a.queue || !(a.prob.kernel_hint & 64u))) return PHF_OK;
+  const int which = phf_hier_isa_find(a.pts.n_expts, a.pts.points_per_expt);
+  if (which < 0) return PHF_OK;
+  phf_hier3_isa_args g{};
+  fill_isa_args(a, &g);
   // Work queue (phf_hierarchical_advance_queued): the launch is cut into quanta, the grid is only as large as the chip holds (two
   // wavefronts per SIMD) and its wavefronts pull (quantum, block) tasks, so that the last round of a launch is a round of short tasks:
   // 147 pairs x 1 024 chains are 2 352 wavefronts on 2 048 slots — 1.15 rounds that cost two without the queue.  Worth it only when
@@ -1257,6 +1265,101 @@ int64_t phf_hierarchical_queue_words(const phf_hier_points* pts, const phf_probl
     return phf_fail(PHF_ERR_INVALID_ARGUMENT, "phf_hierarchical_queue_words: incomplete phf_hier_points / phf_problems");
   const int64_t total = (int64_t)((prob->chains_per_problem + kBlock - 1) / kBlock) * prob->num_problems;
   return hier_queue_words(pts->n_expts, pts->points_per_expt, total);
+}
+
+// ---- every launch group of a run through ONE persistent grid (phf_hier_fused_advance: a body per (experiments, point shape)) ----
+static int fused_plan(int32_t n_groups, const phf_hier_group* groups, int* body_of, int64_t* blocks_of, int64_t* total, bool* scratch) {
+  if (n_groups < 1 || n_groups > PHF_ISA_FUSED_BODIES || !groups)
+    return phf_fail(PHF_ERR_INVALID_ARGUMENT, "fused hierarchical launch: 1..PHF_ISA_FUSED_BODIES groups");
+  *total = 0; *scratch = false;
+  bool taken[PHF_ISA_FUSED_BODIES] = {};
+  for (int i = 0; i < n_groups; ++i) {
+    const phf_hier_group& g = groups[i];
+    if (!g.pts || !g.prob || g.prob->num_problems <= 0 || g.prob->chains_per_problem <= 0)
+      return phf_fail(PHF_ERR_INVALID_ARGUMENT, "fused hierarchical launch: incomplete group");
+    int b = -1;
+    for (int j = 0; j < PHF_ISA_FUSED_BODIES; ++j)
+      if (phf_isa_hier_kernels[j].n_expts == g.pts->n_expts && phf_isa_hier_kernels[j].shape_code == g.pts->points_per_expt) b = j;
+    if (b < 0) return phf_fail(PHF_ERR_UNSUPPORTED, "fused hierarchical launch: no gfx950 kernel for a group's (n_expts, points_per_expt)");
+    if (taken[b]) return phf_fail(PHF_ERR_UNSUPPORTED, "fused hierarchical launch: two groups of one (n_expts, points_per_expt)");
+    taken[b] = true;
+    body_of[i] = b;
+    blocks_of[i] = (int64_t)((g.prob->chains_per_problem + kBlock - 1) / kBlock) * g.prob->num_problems;
+    *total += blocks_of[i];
+    if (phf_isa_hier_kernels[b].scratch_slots > 0) *scratch = true;
+  }
+  if (*total > 0x3fffffffLL) return phf_fail(PHF_ERR_UNSUPPORTED, "too many chains for one launch");
+  return PHF_OK;
+}
+
+int64_t phf_hierarchical_fused_queue_words(int32_t n_groups, const phf_hier_group* groups) {
+  int body_of[PHF_ISA_FUSED_BODIES]; int64_t blocks_of[PHF_ISA_FUSED_BODIES]; int64_t total; bool scratch;
+  if (int rc = fused_plan(n_groups, groups, body_of, blocks_of, &total, &scratch)) return rc;
+  int64_t words = 2 + total;
+  if (scratch) {
+    const int64_t slots = 2LL * phf_simd_count();
+    int max_slots = 0;
+    for (int j = 0; j < PHF_ISA_FUSED_BODIES; ++j) max_slots = phf_isa_hier_kernels[j].scratch_slots > max_slots ? phf_isa_hier_kernels[j].scratch_slots : max_slots;
+    words += 128 + ((total < slots ? total : slots) + 3) * max_slots * 128;
+  }
+  return words;
+}
+
+int phf_hierarchical_advance_fused(int32_t n_groups, const phf_hier_group* groups, const phf_hier_prior* prior, int64_t t_begin, int64_t t_end,
+                                   int64_t moments_after, int32_t quantum_in, int32_t* queue, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int body_of[PHF_ISA_FUSED_BODIES]; int64_t blocks_of[PHF_ISA_FUSED_BODIES]; int64_t total; bool scratch;
+  if (int rc = fused_plan(n_groups, groups, body_of, blocks_of, &total, &scratch)) return rc;
+  if (!prior || !queue || quantum_in < 0) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "fused hierarchical launch: prior, queue workspace, quantum >= 0");
+  if (t_begin < 0 || t_end < t_begin || t_end >= 0xffffffffLL) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "bad iteration range");
+  if (t_end == t_begin) return PHF_OK;
+  if (!hier_isa_enabled()) return phf_fail(PHF_ERR_UNSUPPORTED, "fused hierarchical launch: PHF_HIER_ISA=0");
+  const int thinning = groups[0].cfg ? groups[0].cfg->thinning : 0;
+  if (thinning <= 0) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "thinning must be positive");
+  if (t_begin % thinning) return phf_fail(PHF_ERR_UNSUPPORTED, "fused hierarchical launch: t_begin must be a multiple of the thinning");
+  if (int rc = phf_require_device_memory(queue, "queue workspace")) return rc;
+  static thread_local phf_hier_fused_args fa;
+  fa = phf_hier_fused_args{};
+  for (int i = 0; i < n_groups; ++i) {
+    const phf_hier_group& g = groups[i];
+    if (!g.cfg || !g.state) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "fused hierarchical launch: a group without config / state");
+    if (int rc = check(g.pts, g.prob, prior)) return rc;
+    if (g.cfg->thinning != thinning) return phf_fail(PHF_ERR_UNSUPPORTED, "fused hierarchical launch: the groups' thinning differs");
+    if (g.cfg->adapt_start < 0) return phf_fail(PHF_ERR_UNSUPPORTED, "fused hierarchical launch: negative adapt_start");
+    if (t_end > g.cfg->adapt_start && !g.cfg->gamma) return phf_fail(PHF_ERR_INVALID_ARGUMENT, "gamma table required once adapting");
+    if (int rc = phf_require_device_memory(g.state, "state")) return rc;
+    if (int rc = phf_require_device_memory(g.moments, "moments")) return rc;
+    HierArgs a{};
+    a.pts = *g.pts; a.prob = *g.prob; a.prior = *prior; a.cfg = *g.cfg; a.t_begin = t_begin; a.t_end = t_end; a.state = g.state; a.rows = g.rows;
+    a.moments = g.moments; a.moments_after = moments_after;
+    a.blocks_per_problem = (g.prob->chains_per_problem + kBlock - 1) / kBlock;
+    fill_isa_args(a, &fa.body[body_of[i]]);
+  }
+  // bounds[b]: first block of body b's group, bodies in table order; a body without a group gets an empty range
+  int64_t run = 0;
+  for (int b = 0; b < 8; ++b) {
+    fa.bounds[b] = (uint32_t)run;
+    for (int i = 0; i < n_groups; ++i) if (body_of[i] == b) run += blocks_of[i];
+  }
+  const int64_t slots = 2LL * phf_simd_count();
+  int64_t quantum = quantum_in;
+  if (quantum <= 0) {
+    quantum = (t_end - t_begin) * total / (16 * slots);
+    if (quantum < 100) quantum = 100;
+  }
+  quantum -= quantum % thinning;
+  if (quantum < thinning) quantum = thinning;
+  const int64_t nquanta = (t_end - t_begin + quantum - 1) / quantum;
+  if (nquanta * total >= (1LL << 31)) return phf_fail(PHF_ERR_UNSUPPORTED, "fused hierarchical launch: too many tasks");
+  if (hipMemsetAsync(queue, 0, (size_t)(1 + total) * sizeof(int32_t), stream) != hipSuccess)
+    return phf_check_launch("phf_hierarchical_advance_fused (memset)");
+  fa.queue = queue; fa.scratch = scratch ? hier_queue_scratch(queue, total) : nullptr;
+  fa.t_begin = (uint32_t)t_begin; fa.t_end = (uint32_t)t_end;
+  fa.quantum = (uint32_t)quantum; fa.num_tasks = (uint32_t)(nquanta * total); fa.blocks_magic = phf_isa_magic((uint32_t)total);
+  fa.rows_per_quantum = (uint32_t)(quantum / thinning); fa.total_blocks = (int32_t)total;
+  const int64_t grid_waves = total < slots ? total : slots;
+  g_last_kernel = PHF_HIER_KERNEL_GFX950_ISA_FUSED;
+  return phf_hier_isa_fused_advance(&fa, (int)grid_waves, stream);
 }
 
 int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,

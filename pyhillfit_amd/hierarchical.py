@@ -330,6 +330,79 @@ class HierarchicalSampler(object):
         return mean, (s2 - s1 * mean) / max(n - 1, 1), n
 
 
+class HierGroup(C.Structure):
+    """phf_hier_group (include/pyhillfit_amd.h, ABI 7)"""
+    _fields_ = [("pts", C.POINTER(HierPoints)), ("prob", C.POINTER(_lib.Problems)), ("cfg", C.POINTER(_lib.MhConfig)),
+                ("state", C.c_void_p), ("rows", C.c_void_p), ("moments", C.c_void_p)]
+
+
+class FusedSamplers(object):
+    """Several HierarchicalSampler's — the launch groups of one run, each with a (Ne, point shape) the gfx950 code object has a kernel for,
+    no two alike — advanced by ONE launch (phf_hierarchical_advance_fused): one persistent grid pulls every group's blocks from one work
+    queue.  Every chain's numbers are those of the samplers' own advance(), bit for bit; the samplers keep their state, moments and
+    iteration counters, so fused and separate launches can follow each other."""
+
+    def __init__(self, samplers):
+        self.samplers = list(samplers)
+        if not self.samplers:
+            raise ValueError("no samplers")
+        s0 = self.samplers[0]
+        self.lib, self.device = s0.lib, s0.device
+        _bind(self.lib)
+        self.lib.phf_hierarchical_fused_queue_words.argtypes = [C.c_int32, C.POINTER(HierGroup)]
+        self.lib.phf_hierarchical_fused_queue_words.restype = C.c_int64
+        self.lib.phf_hierarchical_advance_fused.argtypes = [C.c_int32, C.POINTER(HierGroup), C.POINTER(HierPrior), C.c_int64, C.c_int64, C.c_int64,
+                                                            C.c_int32, C.c_void_p, C.c_void_p]
+        kinds = [(s.n_expts, s.points.packed.points_per_expt) for s in self.samplers]
+        if len(set(kinds)) != len(kinds) or any(kd not in ISA_SHAPES for kd in kinds):
+            raise ValueError("fused launch: every sampler needs a (Ne, point shape) of its own that the gfx950 code object has a kernel for; got %s" % (kinds,))
+        if any(s.device != self.device or s.thinning != s0.thinning or s.seed != s0.seed for s in self.samplers):
+            raise ValueError("fused launch: one device, one thinning, one seed")
+        self.nblocks = sum(s.nblocks for s in self.samplers)
+        words = int(self.lib.phf_hierarchical_fused_queue_words(len(self.samplers), self._groups([None] * len(self.samplers), [None] * len(self.samplers))[0]))
+        if words < 0:
+            raise _lib.PhfError(self.lib.phf_last_error().decode())
+        self.queue = torch.zeros(words, dtype=torch.int32, device=self.device)
+        self.quantum = 0
+
+    def _groups(self, cfgs, rows):
+        arr = (HierGroup * len(self.samplers))()
+        for g, s, cfg, r in zip(arr, self.samplers, cfgs, rows):
+            g.pts = C.pointer(s.points.struct); g.prob = C.pointer(s.prob)
+            g.cfg = C.pointer(cfg) if cfg is not None else None
+            g.state = s.state.data_ptr(); g.rows = None if r is None else r.data_ptr()
+            g.moments = None if s.moments is None else s.moments.data_ptr()
+        return arr, cfgs
+
+    def advance(self, n_iterations, out=None, save=True):
+        """out: one tensor per sampler (as HierarchicalSampler.advance's), or None"""
+        t0 = self.samplers[0].t
+        if any(s.t != t0 for s in self.samplers):
+            raise ValueError("fused launch: the samplers stand at different iterations")
+        if len({s.moments_after for s in self.samplers if s.moments is not None}) > 1:
+            raise ValueError("fused launch: one moments_after")
+        t_end = t0 + int(n_iterations)
+        cfgs = [s._config(t_end) for s in self.samplers]
+        rows = [None] * len(self.samplers)
+        if save:
+            for j, s in enumerate(self.samplers):
+                shape = (s.rows_between(t0, t_end), s.Q, s.d + 1, s.C)
+                rows[j] = torch.empty(shape, dtype=torch.float64, device=self.device) if out is None else out[j]
+                if tuple(rows[j].shape) != shape or not rows[j].is_contiguous():
+                    raise ValueError("out[%d] must be contiguous with shape %s" % (j, shape))
+        arr, keep = self._groups(cfgs, rows)
+        after = max([s.moments_after for s in self.samplers if s.moments is not None] or [0])
+        _lib.check(self.lib.phf_hierarchical_advance_fused(len(self.samplers), arr, C.byref(self.samplers[0].prior), t0, t_end, after,
+                                                           int(self.quantum), _ptr(self.queue), _stream_ptr(self.device)),
+                   "phf_hierarchical_advance_fused")
+        for s in self.samplers:
+            s.t = t_end
+        return rows
+
+    def check_queue(self):
+        raise_if_drained(self.queue[:2 + self.nblocks], "fused hierarchical")
+
+
 # ---- start point: bestfit.hierarchical_first_iteration (torch-free, so that it can run in the worker processes) --------
 first_iteration = bestfit.hierarchical_first_iteration
 

@@ -95,6 +95,28 @@ def test_argument_validation_without_gpu(lib):
     assert lib.phf_hierarchical_advance_queued(C.byref(hp), C.byref(prob), C.byref(pr), C.byref(cfg), 0, 10, 1, None, None, 0, 0, None, None) == -1
     assert b"queue" in lib.phf_last_error()
     assert lib.phf_debug_isa(99, 1, 1, 1, None) == -1 and lib.phf_debug_isa(0, 0, None, None, None) == 0
+    # ABI 7: workspace sizes (no device call), the fused launch's checks
+    lib.phf_hierarchical_queue_words.restype = C.c_int64
+    prob.kernel_hint = 0
+    hp.points_per_expt = 4
+    blocks = prob.num_problems * -(-prob.chains_per_problem // 64)
+    assert lib.phf_hierarchical_queue_words(C.byref(hp), C.byref(prob)) == 2 + blocks           # Ne = 3: no scratch tier
+    assert lib.phf_hierarchical_queue_words(None, C.byref(prob)) == -1
+    grp = (H.HierGroup * 2)()
+    lib.phf_hierarchical_fused_queue_words.argtypes = [C.c_int32, C.POINTER(H.HierGroup)]
+    lib.phf_hierarchical_fused_queue_words.restype = C.c_int64
+    lib.phf_hierarchical_advance_fused.argtypes = [C.c_int32, C.POINTER(H.HierGroup), C.POINTER(H.HierPrior), C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                                   C.c_void_p, C.c_void_p]
+    for g in grp:
+        g.pts = C.pointer(hp); g.prob = C.pointer(prob); g.cfg = C.pointer(cfg); g.state = 1
+    assert lib.phf_hierarchical_fused_queue_words(1, grp) == 2 + blocks
+    assert lib.phf_hierarchical_fused_queue_words(2, grp) == -3 and b"two groups of one" in lib.phf_last_error()
+    assert lib.phf_hierarchical_fused_queue_words(0, grp) == -1 and lib.phf_hierarchical_fused_queue_words(9, grp) == -1
+    hp.points_per_expt = 7 | (1 << 4)                          # 7 + 7 + 1 points: no gfx950 kernel for that shape
+    assert lib.phf_hierarchical_fused_queue_words(1, grp) == -3 and b"no gfx950 kernel" in lib.phf_last_error()
+    hp.points_per_expt = 4
+    assert lib.phf_hierarchical_advance_fused(1, grp, C.byref(pr), 0, 10, 0, 0, None, None) == -1      # no workspace
+    assert lib.phf_hierarchical_advance_fused(1, grp, C.byref(pr), 3, 10, 0, 0, 1, None) == -3 and b"multiple of the thinning" in lib.phf_last_error()
 
 
 def test_drained_queue_raises_on_the_host():

@@ -224,6 +224,48 @@ def test_isa_four_experiments_work_queue_at_full_width(gpu):
         assert bool(same.all()), (name, int((~same).sum()))
 
 
+def test_fused_launch_of_six_groups_bit_identical_to_separate_launches(gpu, oracle_pair):
+    """phf_hierarchical_advance_fused: the six kinds of launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4: 4 + 4 + 4 + 1 / 2 / 3) in ONE
+    persistent grid pulling from one queue — rows, state and moments of every group against its own launches of the hipcc kernel, bit for bit;
+    quanta of 50 iterations (a block's quanta chain through its state, tasks of all groups interleave), a ragged last wavefront, a subset of
+    the groups (bodies without a group), moments, and a fused launch continued by separate ones"""
+    import torch
+    from pyhillfit_amd import hierarchical as H
+    groups = [(UNIFORM4, THETA0), (OTHER_SHAPES["2 + 2 + 2"], THETA0), (OTHER_SHAPES["5 + 5 + 4"], THETA0),
+              (NE4["4 + 4 + 4 + 1"], THETA0_4), (NE4["4 + 4 + 4 + 2"], THETA0_4), (NE4["4 + 4 + 4 + 3"], THETA0_4)]
+    C, thin, adapt, cuts = 200, 5, 140, (135, 10, 355)
+
+    def make(isa, which):
+        out = []
+        for j in which:
+            names, th0 = groups[j]
+            s, _ = _setup(gpu, names, oracle_pair, C, thin, adapt, 777, isa)
+            s.problem_ids = torch.tensor([100 * j + q for q in range(3)], dtype=torch.int32, device=gpu)
+            s.prob.problem_id = s.problem_ids.data_ptr()
+            s.init(np.array(th0), cov_scale=0.01)
+            s.enable_moments(after_iteration=adapt + 10)
+            out.append(s)
+        return out
+
+    for which in (range(6), (1, 4)):
+        ref = make(False, which)
+        want = [torch.cat([s.advance(k) for k in cuts]) for s in ref]
+        assert H.last_kernel() == 1
+        fus = make(True, which)
+        f = H.FusedSamplers(fus)
+        f.quantum = 50
+        parts = [f.advance(k) for k in cuts[:2]]
+        assert H.last_kernel() == 6, H.last_kernel()
+        last = [s.advance(cuts[2]) for s in fus]                       # ... continued by the samplers' own launches
+        torch.cuda.synchronize()
+        f.check_queue()
+        for j, (s, r) in enumerate(zip(fus, ref)):
+            got = torch.cat([parts[0][j], parts[1][j], last[j]])
+            for name, a, b in (("rows", got, want[j]), ("state", s.state, r.state), ("moments", s.moments, r.moments)):
+                same = a.view(torch.int64) == b.view(torch.int64)
+                assert bool(same.all()), (list(which), j, name, int((~same).sum()))
+
+
 def test_isa_advance_bit_identical_to_the_twin(gpu, oracle_pair):
     from oracle import c_oracle as co
     from pyhillfit_amd import hierarchical as H

@@ -341,6 +341,9 @@ def generate(with_main=True):
             if name != "phf_hier3_advance":
                 info["%s" % name] = {"vgpr_high_water": kinfo["vgpr_high_water"], "lds_bytes_per_workgroup": kinfo["lds_bytes_per_workgroup"],
                                      "count_iteration": kinfo["count_iteration"]}
+        fused, finfo = G.fused_kernel()
+        kernels.append(fused)
+        info["phf_hier_fused_advance"] = finfo
         import gen_sl_isa_main as GS
         sl, sl_info = GS.main_kernel()
         kernels.append(sl)

@@ -137,17 +137,18 @@ class Main(object):
         return SLOT_L + LDS_L.index((i, kcol))
 
     def g_addr(self, key):
-        """(SGPR base pair, immediate) of scratch slot GLB_L.index(key): bases sit every 16 slots, in the middle of their 8 KB"""
+        """(VGPR offset, immediate) of scratch slot GLB_L.index(key) against the one SGPR base (slot 8): the lane's offset + 8 KB per group of
+        16 slots in a VGPR of its own (scalar registers are the scarcer kind here), the slot within the group in the +-4 KB immediate"""
         gidx = GLB_L.index(key)
-        return self.s_wsb[gidx // 16], (gidx % 16 - 8) * 512
+        return self.v_goff[gidx // 16], (gidx % 16 - 8) * 512
 
     def g_load(self, dst, key):
-        base, imm = self.g_addr(key)
-        self.k.gload(dst, self.v_lane8, base, imm)
+        voff, imm = self.g_addr(key)
+        self.k.gload(dst, voff, self.s_wsb, imm)
 
     def g_store(self, key, src):
-        base, imm = self.g_addr(key)
-        self.k.gstore(self.v_lane8, src, base, imm)
+        voff, imm = self.g_addr(key)
+        self.k.gstore(voff, src, self.s_wsb, imm)
 
     # ------------------------------------------------------------------------------------------------------------ prologue
     def ptr(self, name):
@@ -157,6 +158,10 @@ class Main(object):
 
     def prologue_once(self):
         """what a wavefront does once: constants, the workgroup's tables, its own LDS areas, the registers that live as long as it does"""
+        self.prologue_common()
+        self.alloc_state()
+
+    def prologue_common(self):
         k, g = self.k, self.g
         k.comment("---- once per wavefront: constants, tables -> LDS, LDS bases ----")
         assert self.ARG_OFF["total_waves"] == self.ARG_OFF["num_problems"] + 12 and self.ARG_OFF["chains"] == self.ARG_OFF["adapt_start"] + 12
@@ -170,7 +175,7 @@ class Main(object):
         self.s_wave, self.s_block, self.s_quant = k.s1(), k.s1(), k.s1()      # wave in the workgroup; the task: block, quantum
         self.s_nch8, self.s_rows, self.s_rstride, self.s_mom = k.sd(), k.sd(), k.sd(), k.sd()
         self.s_gamma, self.s_acc, self.s_queue = k.sd(), k.sd(), k.sd()
-        self.s_wsb = [k.sd() for _ in range((len(GLB_L) + 15) // 16)]
+        self.s_wsb = k.sd() if GLB_L else None
         g.stage_tables(s_consts)
         k.free(s_consts)
         self.v_lane, self.v_lane8, self.v_lds, self.v_ulds, self.v_cid = k.v1(), k.v1(), k.v1(), k.v1(), k.v1()
@@ -192,20 +197,20 @@ class Main(object):
             # this wavefront's scratch: scratch + (workgroup * 4 + wave) * slots * 512 bytes; base j = slot 16 j + 8
             per_wave = len(GLB_L) * 512
             t2 = k.sd()
-            k.s_load(self.s_wsb[0], g.kernarg, self.ARG_OFF["scratch"])
+            k.s_load(self.s_wsb, g.kernarg, self.ARG_OFF["scratch"])
             k.sop("s_lshl_b32", tmp, g.wg_id, 2)
             k.sop("s_add_u32", tmp, tmp, self.s_wave)
             k.sop("s_mul_hi_u32", t2.hi(), tmp, Lit(per_wave))
             k.sop("s_mul_i32", t2.lo(), tmp, Lit(per_wave))
             k.sop("s_add_u32", t2.lo(), t2.lo(), Lit(8 * 512))
             k.sop("s_addc_u32", t2.hi(), t2.hi(), 0)
-            self.add64(self.s_wsb[0], self.s_wsb[0], t2)
-            for j in range(1, len(self.s_wsb)):
-                k.sop("s_add_u32", self.s_wsb[j].lo(), self.s_wsb[j - 1].lo(), Lit(16 * 512))
-                k.sop("s_addc_u32", self.s_wsb[j].hi(), self.s_wsb[j - 1].hi(), 0)
+            self.add64(self.s_wsb, self.s_wsb, t2)
             k.free(t2)
         k.free(vt, tmp)
-        # the chain state's registers
+
+    def alloc_state(self):
+        """the chain state's registers"""
+        k = self.k
         self.th = [k.vd() for _ in range(D)]
         self.lt = k.vd()
         self.y = [k.vd() for _ in range(D)]
@@ -215,6 +220,10 @@ class Main(object):
                 if (i, kc) not in LDS_L and (i, kc) not in GLB_L:
                     self.Lreg[(i, kc)] = k.vd()
         self.loga, self.nacc, self.sc, self.logu = k.vd(), k.vd(), k.vd(), k.vd()
+        self.v_goff = [self.v_lane8]
+        for j in range(1, (len(GLB_L) + 15) // 16):
+            self.v_goff.append(k.v1())
+            k.vop("v_add_u32_e32", self.v_goff[j], Lit(8192 * j), self.v_lane8)
         k.s_waitcnt_all()
 
     def next_task(self):
@@ -498,13 +507,15 @@ class Main(object):
         k = self.k
         t2 = k.sd()
         st = None
-        k.sop("s_cmp_eq_u64", None, self.s_queue, 0)
-        k.branch("s_cbranch_scc1", self.l_end)
+        fused = not getattr(self, "emit_end", True)          # the fused kernel: always queued, its task code further away than s_branch reaches
+        if not fused:
+            k.sop("s_cmp_eq_u64", None, self.s_queue, 0)
+            k.branch("s_cbranch_scc1", self.l_end)
         k.sop("s_mov_b64", EXEC, -1)
         k.s_waitcnt_all()
         k.raw_rec("buffer_wbl2 sc1")
         k.raw_rec("s_waitcnt vmcnt(0)")
-        k.sop("s_lshl_b32", t2.lo(), self.s_block, 2)
+        k.sop("s_lshl_b32", t2.lo(), getattr(self, "s_qblock", self.s_block), 2)
         k.sop("s_mov_b32", t2.hi(), 0)
         self.add64(t2, t2, self.s_queue)
         v = k.v1()
@@ -516,7 +527,12 @@ class Main(object):
         k.sop("s_and_saveexec_b64", save, VCC)
         k.emit("global_store_dword", [], [self.v_zero, v, t2], "vmem", suffix="offset:4 sc1", mem="vm")
         k.sop("s_mov_b64", EXEC, save)
-        k.free(t2, v, tmp, save)
+        k.free(v, tmp, save)
+        if fused:
+            k.long_jump(self.l_task, t2)
+            k.free(t2)
+            return
+        k.free(t2)
         k.branch("s_branch", self.l_task)
         k.label(self.l_end)
         k.endpgm()
@@ -1195,6 +1211,13 @@ class Main(object):
         k, c = self.k, self.c
         self.prologue_once()
         self.next_task()
+        self.emit_loop()
+        lines_meta = k.finish(LDS_BYTES, ARG_BYTES)
+        return lines_meta, self.collect_info()
+
+    def emit_loop(self):
+        """the block's iterations (draws -> sweep -> save -> [leave] -> propose -> target -> accept), then the state back and the hand-over"""
+        k, c = self.k, self.c
         k.count_marker("prologue")
         l_loop, l_exit = k.new_label("loop"), k.new_label("exit")
         k.label(l_loop)
@@ -1232,7 +1255,9 @@ class Main(object):
         k.branch("s_branch", l_loop)
         k.label(l_exit)
         self.task_done()
-        lines_meta = k.finish(LDS_BYTES, ARG_BYTES)
+
+    def collect_info(self):
+        k = self.k
         snaps = k.snapshots
         order = ["prologue", "draws", "sweep", "save", "target", "accept"]
         prev = snaps["prologue"]
@@ -1250,7 +1275,165 @@ class Main(object):
         self.info["lds_bytes_per_workgroup"] = LDS_BYTES
         self.info["lds_slots_per_wavefront"] = NSLOTS
         self.info["scratch_slots_per_wavefront"] = len(GLB_L)
-        return lines_meta, self.info
+        return self.info
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# ONE kernel with a body per (experiments, shape): a persistent grid pulls the blocks of EVERY launch group of a hierarchical run from one
+# work queue.  Separate kernels cannot share a chip well — each persistent grid takes every workgroup slot it finds and keeps it until its
+# own queue is empty (profiles/r05/c4_ne4_assembly_vs_hipcc.txt) — one queue can: a wavefront that finishes a task of one group takes the
+# next task whatever group it belongs to.  Kernel arguments: a header (queue-level values) + one phf_hier3_isa_args block per body.
+FUSED_HDR = {"consts": 0, "queue": 8, "scratch": 16, "t_begin": 24, "t_end": 28, "quantum": 32, "num_tasks": 36, "blocks_magic": 40,
+             "rows_per_quantum": 44, "total_blocks": 48, "bounds": 64}
+FUSED_HDR_BYTES, FUSED_MAX_BODIES = 96, 8
+
+
+class FusedMain(Main):
+    def __init__(self, kinds):
+        global WAVE_LDS
+        assert len(kinds) <= FUSED_MAX_BODIES
+        self.kinds = list(kinds)
+        wave_lds, slots = [], set()
+        for ne, shape in self.kinds:
+            configure(ne, shape)
+            wave_lds.append(WAVE_LDS)
+            slots.add(NSLOTS)
+        assert len(slots) == 1, "the bodies share the wavefront's LDS base arithmetic"
+        with_scratch = [kd for kd in self.kinds if kd[0] == 4]
+        configure(*(with_scratch[0] if with_scratch else self.kinds[0]))      # the prologue's scratch bases: sized for the bodies that have a scratch tier
+        WAVE_LDS = max(wave_lds)
+        self.lds_bytes = WAVE_BASE + 4 * WAVE_LDS
+        assert 2 * self.lds_bytes <= 160 * 1024
+        self.g = Gen("phf_hier_fused_advance", NSLOTS)
+        self.k, self.m, self.c = self.g.k, self.g.m, self.g.c
+        self.info = {}
+        self.ARG_OFF = self.offsets(0)
+        self.emit_end = False
+
+    def offsets(self, body):
+        off = {name: FUSED_HDR_BYTES + body * ARG_BYTES + o for name, o in ARG_OFF.items()}
+        off.update({name: FUSED_HDR[name] for name in ("consts", "queue", "scratch")})
+        return off
+
+    def next_task_fused(self):
+        """pull task n from queue[0]: quantum n / blocks of block n % blocks (all groups' blocks numbered through, group after group);
+        wait for that block's previous quantum; then to the body of the block's group (bounds[b] = first block of body b's group)"""
+        k, g = self.k, self.g
+        H = FUSED_HDR
+        k.comment("---- next task (any group's) ----")
+        self.l_task, self.l_end = k.new_label("task"), k.new_label("end")
+        self.s_qblock = self.s_wave                          # (the wavefront's number in its workgroup is spent after the prologue)
+        k.label(self.l_task)
+        k.sop("s_mov_b64", EXEC, -1)
+        q4 = k.sx(4)
+        k.s_load(q4, g.kernarg, H["quantum"])                # quantum num_tasks blocks_magic rows_per_quantum
+        a_quant, a_ntasks, a_bmagic, a_rpq = (q4.sub(i, 1) for i in range(4))
+        tb = k.sd()
+        k.s_load(tb, g.kernarg, H["t_begin"])                # t_begin t_end
+        tot = k.s1()
+        k.s_load(tot, g.kernarg, H["total_blocks"])
+        tmp, task = k.s1(), k.s1()
+        vt, one, save = k.v1(), k.v1(), k.sd()
+        k.mov32(one, 1)
+        k.emit("v_cmp_eq_u32_e32", [VCC], [0, self.v_lane], "valu", count="valu_int")
+        k.sop("s_and_saveexec_b64", save, VCC)
+        k.emit("global_atomic_add", [vt], [self.v_zero, one, self.s_queue], "vmem", suffix="sc0", mem="vm")
+        k.sop("s_mov_b64", EXEC, save)
+        k.readfirstlane(task, vt)
+        k.sop("s_cmp_ge_u32", None, task, a_ntasks)
+        k.branch("s_cbranch_scc1", self.l_end)
+        self.udiv(self.s_quant, self.s_qblock, task, tot, a_bmagic, tmp)
+        cur, polls = k.sd(), k.s1()
+        l_poll, l_ready, l_giveup = k.new_label("poll"), k.new_label("ready"), k.new_label("giveup")
+        k.sop("s_lshl_b32", cur.lo(), self.s_qblock, 2)
+        k.sop("s_mov_b32", cur.hi(), 0)
+        self.add64(cur, cur, self.s_queue)
+        k.sop("s_mov_b32", polls, 0)
+        k.sop("s_cmp_eq_u32", None, self.s_quant, 0)
+        k.branch("s_cbranch_scc1", l_ready)
+        k.label(l_poll)
+        k.emit("global_load_dword", [vt], [self.v_zero, cur], "vmem", suffix="offset:4 sc1", mem="vm")
+        k.readfirstlane(tmp, vt)
+        k.sop("s_cmp_ge_i32", None, tmp, self.s_quant)
+        k.branch("s_cbranch_scc1", l_ready)
+        k.raw_rec("s_sleep 16")
+        k.sop("s_add_u32", polls, polls, 1)
+        k.sop("s_cmp_lt_u32", None, polls, Lit(1 << 22))
+        k.branch("s_cbranch_scc1", l_poll)
+        k.label(l_giveup)                                    # cannot happen in a correct run: poison the counter, raise the sticky fault word
+        k.sop("s_lshl_b32", cur.lo(), tot, 2)
+        k.sop("s_mov_b32", cur.hi(), 0)
+        self.add64(cur, cur, self.s_queue)
+        k.mov32(one, 1)
+        k.emit("global_store_dword", [], [self.v_zero, one, cur], "vmem", suffix="offset:4 sc1", mem="vm")
+        k.mov32(one, Lit(0x40000000))
+        k.emit("global_store_dword", [], [self.v_zero, one, self.s_queue], "vmem", suffix="sc1", mem="vm")
+        k.branch("s_branch", self.l_end)
+        k.label(l_ready)
+        k.raw_rec("buffer_inv sc1")
+        k.free(cur, polls, vt, one, save)
+        k.sop("s_mul_i32", tmp, self.s_quant, a_quant)        # this quantum's iterations: (t_begin + quantum * Q, min(that + Q, t_end)]
+        k.sop("s_add_u32", self.s_first, tb.lo(), tmp)
+        k.sop("s_add_u32", self.s_tend, self.s_first, a_quant)
+        k.sop("s_min_u32", self.s_tend, self.s_tend, tb.hi())
+        k.sop("s_add_u32", self.s_first, self.s_first, 1)
+        k.sop("s_mul_i32", task, self.s_quant, a_rpq)         # rows saved by this block's earlier quanta
+        k.sop("s_mov_b32", self.s_t, self.s_first)
+        k.free(q4, tb, tot)
+        n = len(self.kinds)
+        bq = [k.sx(4) for _ in range((n + 3) // 4)]          # (two aligned quads: eight contiguous scalar registers are not to be had here)
+        for j, q in enumerate(bq):
+            k.s_load(q, g.kernarg, H["bounds"] + 16 * j)
+
+        class _B(object):
+            @staticmethod
+            def sub(b, _n):
+                return bq[b // 4].sub(b % 4, 1)
+        b8 = _B()
+        self.l_body = [k.new_label("body%d" % b) for b in range(n)]
+        picks = [k.new_label("pick%d" % b) for b in range(n)]
+        for b in range(n - 1, 0, -1):
+            k.sop("s_cmp_ge_u32", None, self.s_qblock, b8.sub(b, 1))
+            k.branch("s_cbranch_scc1", picks[b])
+        jt = k.sd()
+        for b in range(n):
+            if b:
+                k.label(picks[b])
+            k.sop("s_sub_u32", self.s_block, self.s_qblock, b8.sub(b, 1))
+            k.long_jump(self.l_body[b], jt)
+        k.free(bq, jt)
+        k.label(self.l_end)                                  # (here, within reach of the task code's branches; the bodies come back by long jumps)
+        k.endpgm()
+        return tmp, task
+
+    def build(self):
+        k = self.k
+        self.prologue_common()
+        tmp, task = self.next_task_fused()
+        snap = [(set(pl.free), pl) for pl in (k.v, k.s)]
+        for b, (ne, shape) in enumerate(self.kinds):
+            configure(ne, shape)
+            for free, pl in snap:
+                pl.free = set(free)
+            self.ARG_OFF = self.offsets(b)
+            k.comment("======== body %d: %d experiments, %s points ========" % (b, ne, " + ".join(str(x) for x in shape)))
+            k.label(self.l_body[b])
+            self.alloc_state()
+            w4 = k.sx(4)
+            k.s_load(w4, self.g.kernarg, self.ARG_OFF["num_problems"])     # num_problems bpp bpp_magic total_waves
+            self.block_setup(w4, tmp, task)
+            self.emit_loop()
+        configure(3, (4, 4, 4))
+        lines_meta = k.finish(self.lds_bytes, FUSED_HDR_BYTES + len(self.kinds) * ARG_BYTES)
+        return lines_meta, {"vgpr_high_water": k.v.high, "sgpr_high_water": k.s.high, "lds_bytes_per_workgroup": self.lds_bytes,
+                            "bodies": len(self.kinds)}
+
+
+def fused_kernel():
+    try:
+        return FusedMain(HIER_KERNELS).build()
+    finally:
+        configure(3, (4, 4, 4))
 
 
 # the kernels of the code object: (experiments, points per experiment).  The Crumb set's 154 pairs with three experiments are 147 x (4, 4, 4),
@@ -1286,4 +1469,18 @@ def header_extra(kernels):
     for ne, shape, code, name, _, kinfo in kernels:
         assert code is not None
         text += "    {%d, %d, %d, \"%s\"}, /* %s */\n" % (ne, code, kinfo["scratch_slots_per_wavefront"], name, " + ".join(str(n) for n in shape))
-    return text + "};\n\n"
+    text += "};\n\n"
+    n = len(kernels)
+    text += ("/* phf_hier_fused_advance: ONE persistent grid for every launch group of a run — a header + one argument block per body; body b is\n"
+             " * phf_isa_hier_kernels[b]'s iteration, bounds[b] the first block of its group in the run's numbering (blocks of a body without a\n"
+             " * group: bounds[b] = bounds[b + 1]; beyond the last body: total_blocks) */\n"
+             "#define PHF_ISA_FUSED_BODIES %d\n"
+             "typedef struct phf_hier_fused_args {\n"
+             "  const void* consts;\n  int32_t* queue;\n  double* scratch;\n  uint32_t t_begin, t_end;\n"
+             "  uint32_t quantum, num_tasks, blocks_magic, rows_per_quantum;\n  int32_t total_blocks;\n  int32_t pad[3];\n  uint32_t bounds[8];\n"
+             "  phf_hier3_isa_args body[PHF_ISA_FUSED_BODIES];\n} phf_hier_fused_args;\n" % n)
+    for name in ("consts", "queue", "scratch", "t_begin", "t_end", "quantum", "num_tasks", "blocks_magic", "rows_per_quantum", "total_blocks", "bounds"):
+        text += "_Static_assert(__builtin_offsetof(phf_hier_fused_args, %s) == %d, \"layout of %s\");\n" % (name, FUSED_HDR[name], name)
+    text += ("_Static_assert(__builtin_offsetof(phf_hier_fused_args, body) == %d && sizeof(phf_hier_fused_args) == %d, \"layout of the bodies' blocks\");\n\n"
+             % (FUSED_HDR_BYTES, FUSED_HDR_BYTES + n * ARG_BYTES))
+    return text

@@ -529,6 +529,12 @@ class Kernel(object):
         assert self._streams is None
         self._rec({"kind": "branch", "opc": opc, "target": target})
 
+    def long_jump(self, target, tmp):
+        """an unconditional jump beyond s_branch's +-128 KB: s_getpc_b64 + the label's distance + s_setpc_b64 through the SGPR pair `tmp`"""
+        assert self._streams is None and tmp.file == "s" and tmp.n == 2
+        self.labels += 1
+        self._rec({"kind": "longjump", "target": target, "tmp": tmp, "here": ".%s_pc_%d" % (self.name, self.labels)})
+
     def barrier(self):
         self._rec({"kind": "barrier"})
 
@@ -559,6 +565,16 @@ class Kernel(object):
             elif kd == "branch":
                 self.drain()
                 self.raw("%s %s" % (r["opc"], r["target"]))
+                self._hist_push({"kind": "salu", "vw": set(), "sw": set()})
+                self.counts["branch"] = self.counts.get("branch", 0) + 1
+            elif kd == "longjump":
+                self.drain()
+                t = r["tmp"]
+                self.raw("s_getpc_b64 %s" % fmt(t))
+                self.lines.append(r["here"] + ":")
+                self.raw("s_add_u32 %s, %s, (%s-%s)&0xffffffff" % (fmt(t.lo()), fmt(t.lo()), r["target"], r["here"]))
+                self.raw("s_addc_u32 %s, %s, (%s-%s)>>32" % (fmt(t.hi()), fmt(t.hi()), r["target"], r["here"]))
+                self.raw("s_setpc_b64 %s" % fmt(t))
                 self._hist_push({"kind": "salu", "vw": set(), "sw": set()})
                 self.counts["branch"] = self.counts.get("branch", 0) + 1
             elif kd == "barrier":
