@@ -57,6 +57,9 @@ def build_parser():
     new.add_argument("--write-workers", type=int, default=None, help="processes formatting the chain text files (default: this rank's host cores - 1, at most 16; 0 = write in the main process)")
     new.add_argument("--save-all-chains", action='store_true', default=False, help="also write every chain to a .npy next to the chain file")
     new.add_argument("--segment", type=int, default=20000, help="MH iterations per kernel launch")
+    new.add_argument("--fused-launch", choices=["auto", "on", "off"], default="auto",
+                     help="--hierarchical: the launch groups the gfx950 code object has kernels for (Ne = 3; Ne = 4 with 4 + 4 + 4 + 1 / 2 / 3 points) through "
+                          "ONE persistent grid per segment instead of a launch each (auto: when the run's chains give every SIMD a wavefront); same numbers")
     new.add_argument("--output-root", type=str, default="output", help="root of the output tree (reference: ./output)")
     new.add_argument("--drugs", type=str, default=None, help="comma-separated drug names instead of -a / the menu")
     new.add_argument("--channels", type=str, default=None, help="comma-separated channel names instead of -a / the menu")

@@ -69,7 +69,8 @@ def shape_code(sizes):
 # (experiments, shape code) of the point shapes the hand-allocated gfx950 code object has a kernel for (tools/gen_hier_isa_main.py:
 # HIER_KERNELS — the library looks the launch's shape up in its own table and runs the hipcc kernels for any other)
 ISA_SHAPES = {(3, shape_code((4, 4, 4))), (3, shape_code((2, 2, 2))), (3, shape_code((5, 5, 4))),
-              (4, shape_code((4, 4, 4, 1))), (4, shape_code((4, 4, 4, 2))), (4, shape_code((4, 4, 4, 3)))}
+              (4, shape_code((4, 4, 4, 1))), (4, shape_code((4, 4, 4, 2))), (4, shape_code((4, 4, 4, 3))),
+              (4, shape_code((2, 2, 2, 1))), (4, shape_code((5, 5, 5, 1)))}
 
 
 # ... and the shapes whose pairs get a launch group of their own.  The Ne = 4 kernels are measured and NOT grouped by default: alone they
@@ -419,7 +420,7 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     t_begin = time.time()
     shapes, scales, locs = prior_params()
     prior = make_prior(shapes, scales, locs)
-    groups = {}
+    groups, loaded = {}, []
     all_pairs = [(a, b) for a in dr.drugs for b in dr.channels]
     for drug, channel in pairs:
         try:
@@ -435,7 +436,14 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         if ne > MAX_EXPTS:
             print("{} + {}: {} experiments exceed the {} supported by the hierarchical kernels --- skipping".format(drug, channel, ne, MAX_EXPTS))
             continue
-        groups.setdefault(group_key(experiments), []).append((drug, channel, experiments, all_pairs.index((drug, channel)), fitted_all))
+        loaded.append((drug, channel, experiments, all_pairs.index((drug, channel)), fitted_all))
+    # one persistent grid for the groups the gfx950 code object has kernels for (FusedSamplers) — when the run's chains give every SIMD a
+    # one-lane wavefront (below that the groups run the two-lane kernels, whose wall time is the latency of one wavefront-iteration)
+    mode = getattr(args, "fused_launch", "auto")
+    one_lane = -(-args.num_chains // 64) * len(loaded) >= simd_count()
+    use_fused = mode == "on" or (mode == "auto" and one_lane)
+    for item in loaded:
+        groups.setdefault(group_key(item[2], ISA_SHAPES if use_fused else None), []).append(item)
     summaries = []
     total_iterations, thinning = args.iterations, args.thinning
     saved_iterations = total_iterations // thinning + 1                # :469
@@ -478,6 +486,15 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         runs.append(dict(ne=ne, members=members, theta0=theta0, s=s, kept=kept, buf=buf, seg=seg, r=1, curves=curves, files=files,
                          stream=torch.cuda.Stream(device=device)))
     hint_side_by_side(r["s"] for r in runs)
+    fused_runs = [r for r in runs if use_fused and (r["s"].n_expts, r["s"].points.packed.points_per_expt) in ISA_SHAPES]
+    fused = None
+    if len(fused_runs) > 1:
+        fused = FusedSamplers([r["s"] for r in fused_runs])
+        for r in fused_runs:
+            r["s"].set_kernel_hint(lanes=1)                                # (their own launches, if any, stay on the kernels the fused grid runs)
+            r["stream"] = fused_runs[0]["stream"]
+    else:
+        fused_runs = []
     torch.cuda.synchronize(device)
     start = time.time()
     done = 0
@@ -495,11 +512,17 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
     while done < total_iterations:
         k = min(runs[0]["seg"], total_iterations - done) if runs else total_iterations
         queued = []
+        fused_rows = {}
+        if fused is not None:                  # the fused groups' segment: one launch, on their common stream
+            nrs = [r["s"].rows_between(r["s"].t, r["s"].t + k) for r in fused_runs]
+            with torch.cuda.stream(fused_runs[0]["stream"]):
+                out = fused.advance(k, out=[r["buf"][:nr] for r, nr in zip(fused_runs, nrs)])
+            fused_rows = {id(r): (o, nr) for r, o, nr in zip(fused_runs, out, nrs)}
         for run in runs:                       # queue this segment of every group (asynchronous, one stream each) ...
             s = run["s"]
-            nr = s.rows_between(s.t, s.t + k)
+            nr = fused_rows[id(run)][1] if id(run) in fused_rows else s.rows_between(s.t, s.t + k)
             with torch.cuda.stream(run["stream"]):
-                rows = s.advance(k, out=run["buf"][:nr])
+                rows = fused_rows[id(run)][0] if id(run) in fused_rows else s.advance(k, out=run["buf"][:nr])
                 first = max(0, burn - run["r"])                        # saved rows before `burn` are the burn-in (:84-86 of the CDF script)
                 if run["curves"] is not None and first < nr:
                     run["curves"].accumulate(rows[first:], cdf_chains(args, args.num_chains))
@@ -515,6 +538,8 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
         done += k
     hand_over(in_flight)
     torch.cuda.synchronize(device)
+    if fused is not None:
+        fused.check_queue()
     elapsed = time.time() - start
     total_chains = sum(len(r_["members"]) for r_ in runs) * args.num_chains
     for run in runs:

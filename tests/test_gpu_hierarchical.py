@@ -278,6 +278,40 @@ def test_hierarchical_cli_and_statistics(gpu, tmp_path):
         assert np.array_equal(chain[0, :-1], np.array(sm["first_iteration"])) and np.array_equal(chain[1:], rows)
 
 
+def test_hierarchical_cli_fused_launch_chain_files_equal_the_twin(gpu, tmp_path):
+    """python PyHillFit.py --hierarchical --fused-launch on: nine pairs of five launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4:
+    4 + 4 + 4 + 1, 4 + 4 + 4 + 3), three segments through ONE persistent grid per segment, chain-0 rows copied out behind every segment: chain 0
+    of every pair through the text file == the CPU twin, bit for bit"""
+    from oracle import c_oracle as co
+    from pyhillfit_amd import PyHillFit
+    from pyhillfit_amd import doseresponse as dr
+    from pyhillfit_amd import hierarchical as H
+    from pyhillfit_amd.sampler import gamma_table
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    csv = str(tmp_path / "crumb_data.csv")
+    dr.table.to_csv(csv)
+    out = str(tmp_path / "output")
+    T = 3000
+    summ = PyHillFit.main(["--data-file", csv, "-m", "2", "--hierarchical", "-i", str(T), "-t", "5", "--drugs", "Amiodarone,Rufinamide,Verapamil",
+                           "--channels", "hERG,Nav1.5-peak,Kv4.3", "--num-chains", "192", "--output-root", out, "--num-APs", "50",
+                           "--segment", "1000", "--fused-launch", "on"])
+    assert len(summ) == 9 and H.last_kernel() == 6
+    shapes, scales, locs = H.prior_params()
+    all_pairs = [(a, b) for a in dr.drugs for b in dr.channels]
+    kinds = set()
+    for sm in summ:
+        ne, drug, c = sm["num_expts"], sm["drug"], sm["channel"]
+        _, _, ex = dr.load_crumb_data(drug, c)
+        kinds.add(H.group_key(ex, H.ISA_SHAPES))
+        f = os.path.join(out, "crumb_data", "hierarchical", drug, c, "%d_expts" % ne, "chain", "crumb_data_%s_%s_hierarchical_chain.txt" % (drug, c))
+        chain = np.loadtxt(f)
+        pk = co.PackedHierPair(ex, shapes, scales, locs)
+        st = pk.init_state(np.array(sm["first_iteration"]), 0.01)
+        rows = pk.advance(st, 0, T, 5, 100 * (5 + 2 * ne), gamma_table(T), seed=25, chain_id=0, problem_id=all_pairs.index((drug, c)))
+        assert np.array_equal(chain[0, :-1], np.array(sm["first_iteration"])) and np.array_equal(chain[1:], rows), (drug, c)
+    assert len(kinds) == 5, kinds
+
+
 def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):
     """pairs with more than 8 experiments (the reference's synthetic set: Ne = 50, dim 105, 200 points) run one wavefront per
     chain (state in LDS, lanes = experiments / factor rows): same bits as the twin across a launch cut, and the moments it

@@ -147,7 +147,8 @@ def test_isa_other_point_shapes_bit_identical_to_the_hipcc_kernel_and_the_twin(s
 
 NE4 = {"4 + 4 + 4 + 1": [("Amiodarone", "Nav1.5-peak"), ("Amitriptyline", "KvLQT1/mink"), ("Azithromycin", "KvLQT1/mink")],
        "4 + 4 + 4 + 2": [("Bepridil", "Nav1.5-peak"), ("Dofetilide", "Cav1.2"), ("Propafenone", "hERG")],
-       "4 + 4 + 4 + 3": [("Amiodarone", "Kv4.3"), ("Saquinavir", "hERG"), ("Amiodarone", "Kv4.3")]}
+       "4 + 4 + 4 + 3": [("Amiodarone", "Kv4.3"), ("Saquinavir", "hERG"), ("Amiodarone", "Kv4.3")],
+       "2 + 2 + 2 + 1": [("Rufinamide", "KvLQT1/mink")] * 3, "5 + 5 + 5 + 1": [("Verapamil", "Cav1.2")] * 3}
 THETA0_4 = [np.concatenate([t[:4], np.tile(t[4:6], 4), t[-1:]]) for t in THETA0]
 
 
@@ -224,15 +225,17 @@ def test_isa_four_experiments_work_queue_at_full_width(gpu):
         assert bool(same.all()), (name, int((~same).sum()))
 
 
-def test_fused_launch_of_six_groups_bit_identical_to_separate_launches(gpu, oracle_pair):
-    """phf_hierarchical_advance_fused: the six kinds of launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4: 4 + 4 + 4 + 1 / 2 / 3) in ONE
+def test_fused_launch_of_eight_groups_bit_identical_to_separate_launches(gpu, oracle_pair):
+    """phf_hierarchical_advance_fused: the eight kinds of launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4: 4 + 4 + 4 + 1 / 2 / 3, 2 + 2 + 2 + 1,
+    5 + 5 + 5 + 1: every Crumb pair with three or four experiments) in ONE
     persistent grid pulling from one queue — rows, state and moments of every group against its own launches of the hipcc kernel, bit for bit;
     quanta of 50 iterations (a block's quanta chain through its state, tasks of all groups interleave), a ragged last wavefront, a subset of
     the groups (bodies without a group), moments, and a fused launch continued by separate ones"""
     import torch
     from pyhillfit_amd import hierarchical as H
     groups = [(UNIFORM4, THETA0), (OTHER_SHAPES["2 + 2 + 2"], THETA0), (OTHER_SHAPES["5 + 5 + 4"], THETA0),
-              (NE4["4 + 4 + 4 + 1"], THETA0_4), (NE4["4 + 4 + 4 + 2"], THETA0_4), (NE4["4 + 4 + 4 + 3"], THETA0_4)]
+              (NE4["4 + 4 + 4 + 1"], THETA0_4), (NE4["4 + 4 + 4 + 2"], THETA0_4), (NE4["4 + 4 + 4 + 3"], THETA0_4),
+              (NE4["2 + 2 + 2 + 1"], THETA0_4), (NE4["5 + 5 + 5 + 1"], THETA0_4)]
     C, thin, adapt, cuts = 200, 5, 140, (135, 10, 355)
 
     def make(isa, which):
@@ -247,7 +250,7 @@ def test_fused_launch_of_six_groups_bit_identical_to_separate_launches(gpu, orac
             out.append(s)
         return out
 
-    for which in (range(6), (1, 4)):
+    for which in (range(8), (1, 4, 7)):
         ref = make(False, which)
         want = [torch.cat([s.advance(k) for k in cuts]) for s in ref]
         assert H.last_kernel() == 1

@@ -1439,7 +1439,8 @@ def fused_kernel():
 # the kernels of the code object: (experiments, points per experiment).  The Crumb set's 154 pairs with three experiments are 147 x (4, 4, 4),
 # 6 x (2, 2, 2) and 1 x (5, 5, 4)
 # ... and the 41 with four are 32 x (4, 4, 4, 1), 5 x (4, 4, 4, 2), 2 x (4, 4, 4, 3), (2, 2, 2, 1), (5, 5, 5, 1)
-HIER_KERNELS = [(3, (4, 4, 4)), (3, (2, 2, 2)), (3, (5, 5, 4)), (4, (4, 4, 4, 1)), (4, (4, 4, 4, 2)), (4, (4, 4, 4, 3))]
+HIER_KERNELS = [(3, (4, 4, 4)), (3, (2, 2, 2)), (3, (5, 5, 4)), (4, (4, 4, 4, 1)), (4, (4, 4, 4, 2)), (4, (4, 4, 4, 3)),
+                (4, (2, 2, 2, 1)), (4, (5, 5, 5, 1))]
 
 
 def main_kernel(ne=3, shape=(4, 4, 4)):
