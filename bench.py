@@ -188,11 +188,13 @@ class HierarchicalBatch(object):
         # PHF_BENCH_HIER_FUSED=0: every group a launch of its own on its own stream (what rounds 1-5 measured); default: the groups the
         # gfx950 code object has kernels for — Ne = 3 and the 4 + 4 + 4 + {1, 2, 3} shapes of Ne = 4 — in ONE persistent grid
         # (phf_hierarchical_advance_fused), the rest beside it on streams of their own
-        self.use_fused = os.environ.get("PHF_BENCH_HIER_FUSED", "1") != "0"
+        mode = os.environ.get("PHF_BENCH_HIER_FUSED", "1")   # "3": only the Ne = 3 groups in the fused grid (A/B)
+        self.use_fused = mode != "0"
+        shapes = None if not self.use_fused else ({k for k in H.ISA_SHAPES if k[0] == 3} if mode == "3" else H.ISA_SHAPES)
         groups = {}
         for p, (d_, c_) in enumerate(names):
             ex = dr.load_crumb_data(d_, c_)[2] if experiments is None else experiments[p]
-            groups.setdefault(H.group_key(ex, H.ISA_SHAPES if self.use_fused else None), []).append((p, ex))
+            groups.setdefault(H.group_key(ex, shapes), []).append((p, ex))
         shapes, scales, locs = H.prior_params()
         self.samplers = []
         for (ne, _), members in sorted(groups.items(), reverse=True):
