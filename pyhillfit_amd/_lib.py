@@ -81,6 +81,9 @@ def load():
     return lib
 
 
+PHF_ERR_UNSUPPORTED = -3          # include/pyhillfit_amd.h
+
+
 def check(rc, what=""):
     if rc != 0:
         raise PhfError("%s failed (%d): %s" % (what or "pyhillfit_amd call", rc, load().phf_last_error().decode()))

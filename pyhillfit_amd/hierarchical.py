@@ -393,9 +393,13 @@ class FusedSamplers(object):
                     raise ValueError("out[%d] must be contiguous with shape %s" % (j, shape))
         arr, keep = self._groups(cfgs, rows)
         after = max([s.moments_after for s in self.samplers if s.moments is not None] or [0])
-        _lib.check(self.lib.phf_hierarchical_advance_fused(len(self.samplers), arr, C.byref(self.samplers[0].prior), t0, t_end, after,
-                                                           int(self.quantum), _ptr(self.queue), _stream_ptr(self.device)),
-                   "phf_hierarchical_advance_fused")
+        rc = self.lib.phf_hierarchical_advance_fused(len(self.samplers), arr, C.byref(self.samplers[0].prior), t0, t_end, after,
+                                                     int(self.quantum), _ptr(self.queue), _stream_ptr(self.device))
+        if rc == _lib.PHF_ERR_UNSUPPORTED:
+            # what the one grid does not take (a launch that starts between two saved rows, PHF_HIER_ISA=0 ...): the samplers' own launches,
+            # one after the other on this stream — the same numbers
+            return [s.advance(n_iterations, out=r, save=save) for s, r in zip(self.samplers, rows)]
+        _lib.check(rc, "phf_hierarchical_advance_fused")
         for s in self.samplers:
             s.t = t_end
         return rows
