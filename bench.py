@@ -20,6 +20,9 @@ With N > 1 BOTH are measured in the same run, one timed region each: `value` is 
 `strong_value` (or `weak_value`) the other.  With N = 1 the c3 run also times short regions of c2, c4, c5 and of the kernels the command
 lines and the thermodynamic-integration path launch — c5 with the on-device <log L> and moments (`c5_moments`), c3 with model 1
 (`c3_model1`) — (`other_workloads`).
+c4 (and a hierarchical strong-scaling share) launches the groups the gfx950 code object has kernels for — every pair with three or four
+experiments — as ONE persistent grid per step (phf_hierarchical_advance_fused), Ne = 5 / 6 beside it on streams of their own;
+PHF_BENCH_HIER_FUSED=0 gives every group a launch and a stream of its own (the arrangement before ABI 7), =3 fuses the Ne = 3 groups only.
 RCCL is used outside the timed regions only: rank 0 reads and packs the data and broadcasts it, the per-problem
 acceptance summaries are gathered to rank 0.  Timing: barrier + synchronize on both sides, MAX over ranks.
 Rank 0 prints ONE JSON line."""

@@ -1,6 +1,8 @@
 // phf_hier3_isa.hip — host side of the hand-allocated gfx950 code object (generated/phf_hier3_gfx950.s, emitted by
 // tools/gen_hier_isa.py and assembled by pyhillfit_amd/build.py): the code object travels INSIDE libpyhillfit_amd.so (.incbin), is
-// loaded once per device with hipModuleLoadData, and its kernels are launched with hipModuleLaunchKernel on the caller's stream.
+// loaded once per device with hipModuleLoadData, and its kernels — the hierarchical iteration per (experiments, point shape):
+// generated/phf_hier3_isa_layout.h phf_isa_hier_kernels[]; phf_hier_fused_advance, one persistent grid with a body per entry of that
+// table; phf_sl3_advance; the unit kernels — are launched with hipModuleLaunchKernel on the caller's stream.
 // The constants blob the kernels read — the exp2 / log / erfc / normal tables of phf_math.h followed by the scalar constants of
 // generated/phf_hier3_isa_layout.h — is built here from the SAME arrays the hipcc kernels and the host twin compile.
 #include <hip/hip_runtime.h>

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Emit the hand-allocated gfx950 code object source of the hierarchical sampler's Ne = 3 (4 + 4 + 4 points) one-lane iteration.
+"""Emit the hand-allocated gfx950 code object source: the hierarchical sampler's one-lane iteration per (experiments, point shape) — Ne = 3 and
+Ne = 4, every shape of the Crumb set — and ONE persistent grid with a body per shape (tools/gen_hier_isa_main.py); the single-level model-2
+iteration (tools/gen_sl_isa_main.py); unit kernels of every elementary function.  What follows describes the first of them, Ne = 3 with
+4 + 4 + 4 points; the others differ in the target phase (emitted per shape) and, for Ne = 4, in a third state tier (device-memory scratch).
 
     python tools/gen_hier_isa.py            writes pyhillfit_amd/csrc/generated/phf_hier3_gfx950.s and phf_hier3_isa_layout.h
     python tools/gen_hier_isa.py --check    exits 1 if the committed files differ from what this script emits (tests/test_isa_generator.py)

@@ -1,5 +1,8 @@
-"""phf_hier3_advance: the hierarchical sampler's iteration for Ne = 3, four points per experiment, one lane per chain, in gfx950
-assembly with every register placed by hand (see tools/gen_hier_isa.py for the why and the overall layout).
+"""The hierarchical sampler's iteration, one lane per chain, in gfx950 assembly with every register placed by hand (see tools/gen_hier_isa.py
+for the why and the overall layout) — one kernel per (number of experiments, points per experiment): configure(ne, shape) sets the layout,
+Main emits the kernel.  Ne = 3 (any shape of up to 8 points per experiment): phf_hier3_advance (4 + 4 + 4), phf_hier3_advance_s<shape>.
+Ne = 4: phf_hier4_advance_s<shape>, with a third state tier in device-memory scratch.  FusedMain: phf_hier_fused_advance, ONE persistent grid
+with a body per kernel of HIER_KERNELS, one work queue for every launch group of a run.
 
 Each phase below names the C it restates (pyhillfit_amd/csrc/phf_hierarchical.hip: hier_advance_body, PHF_LDL_COLUMN;
 pyhillfit_amd/csrc/phf_hier_model.h: phf_hier_log_target_n / phf_hier_target_half / phf_hier_draws_k) — same fp64 operations, same
@@ -1385,21 +1388,17 @@ class FusedMain(Main):
         for j, q in enumerate(bq):
             k.s_load(q, g.kernarg, H["bounds"] + 16 * j)
 
-        class _B(object):
-            @staticmethod
-            def sub(b, _n):
-                return bq[b // 4].sub(b % 4, 1)
-        b8 = _B()
+        bound = [bq[b // 4].sub(b % 4, 1) for b in range(n)]
         self.l_body = [k.new_label("body%d" % b) for b in range(n)]
         picks = [k.new_label("pick%d" % b) for b in range(n)]
         for b in range(n - 1, 0, -1):
-            k.sop("s_cmp_ge_u32", None, self.s_qblock, b8.sub(b, 1))
+            k.sop("s_cmp_ge_u32", None, self.s_qblock, bound[b])
             k.branch("s_cbranch_scc1", picks[b])
         jt = k.sd()
         for b in range(n):
             if b:
                 k.label(picks[b])
-            k.sop("s_sub_u32", self.s_block, self.s_qblock, b8.sub(b, 1))
+            k.sop("s_sub_u32", self.s_block, self.s_qblock, bound[b])
             k.long_jump(self.l_body[b], jt)
         k.free(bq, jt)
         k.label(self.l_end)                                  # (here, within reach of the task code's branches; the bodies come back by long jumps)
