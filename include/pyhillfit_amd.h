@@ -272,7 +272,7 @@ int64_t phf_hierarchical_queue_words(const phf_hier_points* pts, const phf_probl
 /* EVERY launch group of a run through ONE persistent grid (ABI 7; phf_hier_fused_advance of the gfx950 code object: a body per (n_expts, point
  * shape), a wavefront that finishes a task of one group pulls the next task whatever group it belongs to).  Separate launches side by side —
  * one stream per group, what python/PyHillFit.py's pool amounts to (:997-1003) — leave a chip's workgroup slots to whichever persistent grid
- * got them first; one queue does not.  groups: 1..6 of them, each with a (n_expts, points_per_expt) the code object has a kernel for
+ * got them first; one queue does not.  groups: 1..8 of them, each with a (n_expts, points_per_expt) the code object has a kernel for
  * (PHF_ERR_UNSUPPORTED otherwise: launch such groups one by one), no two alike; the same thinning in every cfg; t_begin a multiple of it.
  * Every chain's numbers are those of phf_hierarchical_advance, bit for bit.  queue: device int32 [phf_hierarchical_fused_queue_words()],
  * zeroed by the caller when allocated; word 1 + (the groups' blocks) is the sticky fault flag. */
