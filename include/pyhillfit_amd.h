@@ -205,12 +205,14 @@ typedef struct phf_hier_points {
   int32_t points_per_expt;    /* ABI 6 (was `reserved`): the point SHAPE of every pair of this set, the caller's statement about its data (like
                                  n_expts; expt_start must say the same): per | last << 4 — EVERY experiment of EVERY pair has `per` points
                                  (1..15), except that the last one has `last` (1..15) if those bits are not 0; so n > 0 alone = n points in
-                                 every experiment; 0 = the pairs differ, the shape has no such code, or unknown.  (PHF_HIER_SHAPE of
+                                 every experiment; or (ABI 7) bit 30 + a nibble per experiment, experiment 0 in the lowest (up to 7 experiments of
+                                 1..15 points: 4 + 4 + 4 + 1 + 1 = 0x40011444); 0 = the pairs differ, the shape has no such code, or unknown.  (PHF_HIER_SHAPE of
                                  pyhillfit_amd/csrc/phf_hier_model.h.)  Launches that get one lane per chain run the hand-allocated gfx950
                                  build of the iteration (two wavefronts per SIMD: same numbers) where the library has one for (n_expts,
                                  shape): n_expts == 3 with 4 + 4 + 4 points (147 of the Crumb set's 210 pairs), 2 + 2 + 2 (6), 5 + 5 + 4 (1);
-                                 ABI 7: n_expts == 4 with 4 + 4 + 4 + 1 (32), + 2 (5), + 3 (2) — through phf_hierarchical_advance_queued with a
-                                 workspace of phf_hierarchical_queue_words() words and kernel_hint bit 6. */
+                                 ABI 7: every n_expts == 4 shape of the Crumb set (4 + 4 + 4 + 1 (32 pairs), + 2 (5), + 3 (2), 2 + 2 + 2 + 1, 5 + 5 + 5 + 1) and
+                                 every n_expts == 5 one (4 + 4 + 4 + 1 + 1 (5), 4 + 4 + 4 + 2 + 1 (5), 4 + 4 + 4 + 4 + 4, 5 + 5 + 4 + 2 + 2) — through
+                                 phf_hierarchical_advance_queued / _fused with a workspace of phf_hierarchical_queue_words() words and kernel_hint bit 6. */
   const double* ln_conc;      /* device [P][stride] */
   const double* response;     /* device [P][stride] */
   const int32_t* expt_start;  /* device [P][Ne+1]  first point of each experiment; [Ne] = number of points */
@@ -272,7 +274,7 @@ int64_t phf_hierarchical_queue_words(const phf_hier_points* pts, const phf_probl
 /* EVERY launch group of a run through ONE persistent grid (ABI 7; phf_hier_fused_advance of the gfx950 code object: a body per (n_expts, point
  * shape), a wavefront that finishes a task of one group pulls the next task whatever group it belongs to).  Separate launches side by side —
  * one stream per group, what python/PyHillFit.py's pool amounts to (:997-1003) — leave a chip's workgroup slots to whichever persistent grid
- * got them first; one queue does not.  groups: 1..8 of them, each with a (n_expts, points_per_expt) the code object has a kernel for
+ * got them first; one queue does not.  groups: 1..12 of them, each with a (n_expts, points_per_expt) the code object has a kernel for
  * (PHF_ERR_UNSUPPORTED otherwise: launch such groups one by one), no two alike; the same thinning in every cfg; t_begin a multiple of it.
  * Every chain's numbers are those of phf_hierarchical_advance, bit for bit.  queue: device int32 [phf_hierarchical_fused_queue_words()],
  * zeroed by the caller when allocated; word 1 + (the groups' blocks) is the sticky fault flag. */

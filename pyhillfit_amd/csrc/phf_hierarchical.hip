@@ -924,11 +924,21 @@ int check(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_p
       return phf_fail(PHF_ERR_INVALID_ARGUMENT, "kernel_hint: bits 0-1 and 2-3 hold 0, 1 or 2; bit 4 = not the gfx950 assembly build; bit 6 = the queue workspace "
                                                 "holds phf_hierarchical_queue_words() words; the other bits must be 0");
   }
-  if (pts->points_per_expt != 0) {                          // a PHF_HIER_SHAPE code: `per` points in every experiment, `last` in the last one if that differs
-    const int per = pts->points_per_expt & 15, last = pts->points_per_expt >> 4;
-    if (pts->points_per_expt < 0 || per == 0 || last > 15 || (pts->n_expts - 1) * per + (last ? last : per) > pts->stride)
-      return phf_fail(PHF_ERR_INVALID_ARGUMENT, "phf_hier_points.points_per_expt: 0 (unknown / no such code) or per | last << 4: the points of EVERY experiment "
-                                                "(and of the last one if it differs) of EVERY pair");
+  if (pts->points_per_expt != 0) {                          // a shape code: per | last << 4, or (bit 30) a nibble per experiment
+    const int code = pts->points_per_expt;
+    bool ok = code > 0;
+    int n_pts = 0;
+    if (ok && (code & (1 << 30))) {
+      ok = pts->n_expts <= 7 && (pts->n_expts == 7 || ((code & ~(1 << 30)) >> (4 * pts->n_expts)) == 0);
+      for (int i = 0; ok && i < pts->n_expts; ++i) { const int n = (code >> (4 * i)) & 15; ok = n > 0; n_pts += n; }
+    } else if (ok) {
+      const int per = code & 15, last = code >> 4;
+      ok = per > 0 && last <= 15;
+      n_pts = (pts->n_expts - 1) * per + (last ? last : per);
+    }
+    if (!ok || n_pts > pts->stride)
+      return phf_fail(PHF_ERR_INVALID_ARGUMENT, "phf_hier_points.points_per_expt: 0 (unknown / no such code), per | last << 4 (the points of EVERY experiment, and of the "
+                                                "last one if it differs), or bit 30 + a nibble per experiment — of EVERY pair");
   }
   return PHF_OK;
 }
@@ -1337,7 +1347,7 @@ int phf_hierarchical_advance_fused(int32_t n_groups, const phf_hier_group* group
   }
   // bounds[b]: first block of body b's group, bodies in table order; a body without a group gets an empty range
   int64_t run = 0;
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < 16; ++b) {
     fa.bounds[b] = (uint32_t)run;
     for (int i = 0; i < n_groups; ++i) if (body_of[i] == b) run += blocks_of[i];
   }

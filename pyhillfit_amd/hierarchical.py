@@ -58,19 +58,23 @@ def make_prior(shapes=None, scales=None, locs=None):
 
 def shape_code(sizes):
     """PHF_HIER_SHAPE(per, last) of a pair's point shape (pyhillfit_amd/csrc/phf_hier_model.h; phf_hier_points.points_per_expt): `per` points in
-    every experiment but the last, `last` there (coded only if it differs); 0 for a shape that code cannot express"""
+    every experiment but the last, `last` there (coded only if it differs) — or, where the shape is not of that form, bit 30 + a nibble per
+    experiment (up to 7 experiments of 1..15 points); 0 for a shape neither expresses"""
     sizes = [int(n) for n in sizes]
     per, last = sizes[0], sizes[-1]
-    if len(sizes) < 2 or any(n != per for n in sizes[:-1]) or not (0 < per < 16 and 0 < last < 16):
-        return 0
-    return per if last == per else per | (last << 4)
+    if len(sizes) >= 2 and all(n == per for n in sizes[:-1]) and 0 < per < 16 and 0 < last < 16:
+        return per if last == per else per | (last << 4)
+    if 2 <= len(sizes) <= 7 and all(0 < n < 16 for n in sizes):      # the list form: bit 30 + a nibble per experiment
+        return (1 << 30) | sum(n << (4 * i) for i, n in enumerate(sizes))
+    return 0
 
 
 # (experiments, shape code) of the point shapes the hand-allocated gfx950 code object has a kernel for (tools/gen_hier_isa_main.py:
 # HIER_KERNELS — the library looks the launch's shape up in its own table and runs the hipcc kernels for any other)
 ISA_SHAPES = {(3, shape_code((4, 4, 4))), (3, shape_code((2, 2, 2))), (3, shape_code((5, 5, 4))),
               (4, shape_code((4, 4, 4, 1))), (4, shape_code((4, 4, 4, 2))), (4, shape_code((4, 4, 4, 3))),
-              (4, shape_code((2, 2, 2, 1))), (4, shape_code((5, 5, 5, 1)))}
+              (4, shape_code((2, 2, 2, 1))), (4, shape_code((5, 5, 5, 1))),
+              (5, shape_code((4, 4, 4, 1, 1))), (5, shape_code((4, 4, 4, 2, 1))), (5, shape_code((4, 4, 4, 4, 4))), (5, shape_code((5, 5, 4, 2, 2)))}
 
 
 # ... and the shapes whose pairs get a launch group of their own.  The Ne = 4 kernels are measured and NOT grouped by default: alone they
@@ -231,13 +235,20 @@ class HierarchicalSampler(object):
         # than the chip holds wavefronts; ignored by every other launch); quantum 0 = the library's choice
         # (ABI 7: the library says how many words — 2 + blocks, plus the device-memory scratch of the Ne = 4 assembly kernels — and
         # kernel_hint bit 6 states that the workspace has them; the sticky fault word is word 1 + blocks)
-        words = int(self.lib.phf_hierarchical_queue_words(C.byref(self.points.struct), C.byref(self.prob)))
-        if words < 0:
-            raise _lib.PhfError(self.lib.phf_last_error().decode())
+        # — allocated at the sampler's first launch of its own: as a member of a FusedSamplers it never needs one)
         self.nblocks = self.Q * (-(-self.C // 64))
-        self.queue = torch.zeros(words, dtype=torch.int32, device=dev)
+        self._queue = None
         self.prob.kernel_hint |= 64
         self.quantum = 0
+
+    @property
+    def queue(self):
+        if self._queue is None:
+            words = int(self.lib.phf_hierarchical_queue_words(C.byref(self.points.struct), C.byref(self.prob)))
+            if words < 0:
+                raise _lib.PhfError(self.lib.phf_last_error().decode())
+            self._queue = torch.zeros(words, dtype=torch.int32, device=self.device)
+        return self._queue
 
     def set_kernel_hint(self, lanes=0, wps=0, isa=None):
         """which kernel THIS sampler's launches should get (phf_problems.kernel_hint: lanes per chain 1 | 2, register build of the two-lane
@@ -300,7 +311,8 @@ class HierarchicalSampler(object):
         """The gfx950 assembly build's queued launches raise the workspace's sticky fault word (its last int32) when a wavefront gives
         up waiting for its block's previous quantum: the launch drains and leaves stale chains behind a PHF_OK.  Read wherever the host
         hands results on (acceptance, posterior_moments, state_dict, the end of a run) — PhfError instead of such results."""
-        raise_if_drained(self.queue[:2 + self.nblocks], "hierarchical")
+        if self._queue is not None:
+            raise_if_drained(self._queue[:2 + self.nblocks], "hierarchical")
 
     def acceptance(self):
         self.check_queue()

@@ -279,8 +279,8 @@ def test_hierarchical_cli_and_statistics(gpu, tmp_path):
 
 
 def test_hierarchical_cli_fused_launch_chain_files_equal_the_twin(gpu, tmp_path):
-    """python PyHillFit.py --hierarchical --fused-launch on: nine pairs of five launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4:
-    4 + 4 + 4 + 1, 4 + 4 + 4 + 3), three segments through ONE persistent grid per segment, chain-0 rows copied out behind every segment: chain 0
+    """python PyHillFit.py --hierarchical --fused-launch on: fifteen pairs of seven launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4:
+    4 + 4 + 4 + 1, 4 + 4 + 4 + 3; Ne = 5: 4 + 4 + 4 + 1 + 1, 5 + 5 + 4 + 2 + 2), three segments through ONE persistent grid per segment, chain-0 rows copied out behind every segment: chain 0
     of every pair through the text file == the CPU twin, bit for bit"""
     from oracle import c_oracle as co
     from pyhillfit_amd import PyHillFit
@@ -292,10 +292,10 @@ def test_hierarchical_cli_fused_launch_chain_files_equal_the_twin(gpu, tmp_path)
     dr.table.to_csv(csv)
     out = str(tmp_path / "output")
     T = 3000
-    summ = PyHillFit.main(["--data-file", csv, "-m", "2", "--hierarchical", "-i", str(T), "-t", "5", "--drugs", "Amiodarone,Rufinamide,Verapamil",
+    summ = PyHillFit.main(["--data-file", csv, "-m", "2", "--hierarchical", "-i", str(T), "-t", "5", "--drugs", "Amiodarone,Rufinamide,Verapamil,Mibefradil,Dofetilide",
                            "--channels", "hERG,Nav1.5-peak,Kv4.3", "--num-chains", "192", "--output-root", out, "--num-APs", "50",
                            "--segment", "1000", "--fused-launch", "on"])
-    assert len(summ) == 9 and H.last_kernel() == 6
+    assert len(summ) == 15 and H.last_kernel() == 6
     shapes, scales, locs = H.prior_params()
     all_pairs = [(a, b) for a in dr.drugs for b in dr.channels]
     kinds = set()
@@ -309,7 +309,7 @@ def test_hierarchical_cli_fused_launch_chain_files_equal_the_twin(gpu, tmp_path)
         st = pk.init_state(np.array(sm["first_iteration"]), 0.01)
         rows = pk.advance(st, 0, T, 5, 100 * (5 + 2 * ne), gamma_table(T), seed=25, chain_id=0, problem_id=all_pairs.index((drug, c)))
         assert np.array_equal(chain[0, :-1], np.array(sm["first_iteration"])) and np.array_equal(chain[1:], rows), (drug, c)
-    assert len(kinds) == 5, kinds
+    assert len(kinds) == 7, kinds
 
 
 def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):

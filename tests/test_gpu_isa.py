@@ -150,9 +150,13 @@ NE4 = {"4 + 4 + 4 + 1": [("Amiodarone", "Nav1.5-peak"), ("Amitriptyline", "KvLQT
        "4 + 4 + 4 + 3": [("Amiodarone", "Kv4.3"), ("Saquinavir", "hERG"), ("Amiodarone", "Kv4.3")],
        "2 + 2 + 2 + 1": [("Rufinamide", "KvLQT1/mink")] * 3, "5 + 5 + 5 + 1": [("Verapamil", "Cav1.2")] * 3}
 THETA0_4 = [np.concatenate([t[:4], np.tile(t[4:6], 4), t[-1:]]) for t in THETA0]
+NE5 = {"4 + 4 + 4 + 1 + 1": [("Lopinavir", "KvLQT1/mink"), ("Mibefradil", "KvLQT1/mink"), ("Mibefradil", "Kv4.3")],
+       "4 + 4 + 4 + 2 + 1": [("Azithromycin", "Cav1.2"), ("Lidocaine", "Cav1.2"), ("Quinine", "Kv4.3")],
+       "4 + 4 + 4 + 4 + 4": [("Moxifloxacin", "KvLQT1/mink")] * 3, "5 + 5 + 4 + 2 + 2": [("Dofetilide", "hERG")] * 3}
+THETA0_5 = [np.concatenate([t[:4], np.tile(t[4:6], 5), t[-1:]]) for t in THETA0]
 
 
-@pytest.mark.parametrize("shape", sorted(NE4))
+@pytest.mark.parametrize("shape", ["4 + 4 + 4 + 1", "4 + 4 + 4 + 2", "4 + 4 + 4 + 3"])         # (the shapes with a kernel of their own)
 def test_isa_four_experiments_bit_identical_to_the_hipcc_kernel_and_the_twin(shape, gpu, oracle_pair):
     """phf_hier4_advance_*: the Ne = 4 iteration (13 parameters, 135 doubles of state per chain) at two wavefronts per SIMD — 27 elements
     of L in registers, 9 + mean + d in LDS, rows 9..12 of L in a device-memory scratch tier inside the queue workspace (ABI 7:
@@ -225,9 +229,9 @@ def test_isa_four_experiments_work_queue_at_full_width(gpu):
         assert bool(same.all()), (name, int((~same).sum()))
 
 
-def test_fused_launch_of_eight_groups_bit_identical_to_separate_launches(gpu, oracle_pair):
-    """phf_hierarchical_advance_fused: the eight kinds of launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4: 4 + 4 + 4 + 1 / 2 / 3, 2 + 2 + 2 + 1,
-    5 + 5 + 5 + 1: every Crumb pair with three or four experiments) in ONE
+def test_fused_launch_of_twelve_groups_bit_identical_to_separate_launches(gpu, oracle_pair):
+    """phf_hierarchical_advance_fused: the twelve kinds of launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4: 4 + 4 + 4 + 1 / 2 / 3, 2 + 2 + 2 + 1,
+    5 + 5 + 5 + 1; Ne = 5: 4 + 4 + 4 + 1 + 1, 4 + 4 + 4 + 2 + 1, 4 + 4 + 4 + 4 + 4, 5 + 5 + 4 + 2 + 2: every Crumb pair with three, four or five experiments) in ONE
     persistent grid pulling from one queue — rows, state and moments of every group against its own launches of the hipcc kernel, bit for bit;
     quanta of 50 iterations (a block's quanta chain through its state, tasks of all groups interleave), a ragged last wavefront, a subset of
     the groups (bodies without a group), moments, and a fused launch continued by separate ones"""
@@ -235,7 +239,7 @@ def test_fused_launch_of_eight_groups_bit_identical_to_separate_launches(gpu, or
     from pyhillfit_amd import hierarchical as H
     groups = [(UNIFORM4, THETA0), (OTHER_SHAPES["2 + 2 + 2"], THETA0), (OTHER_SHAPES["5 + 5 + 4"], THETA0),
               (NE4["4 + 4 + 4 + 1"], THETA0_4), (NE4["4 + 4 + 4 + 2"], THETA0_4), (NE4["4 + 4 + 4 + 3"], THETA0_4),
-              (NE4["2 + 2 + 2 + 1"], THETA0_4), (NE4["5 + 5 + 5 + 1"], THETA0_4)]
+              (NE4["2 + 2 + 2 + 1"], THETA0_4), (NE4["5 + 5 + 5 + 1"], THETA0_4)] + [(NE5[k_], THETA0_5) for k_ in sorted(NE5)]
     C, thin, adapt, cuts = 200, 5, 140, (135, 10, 355)
 
     def make(isa, which):
@@ -250,7 +254,7 @@ def test_fused_launch_of_eight_groups_bit_identical_to_separate_launches(gpu, or
             out.append(s)
         return out
 
-    for which in (range(8), (1, 4, 7)):
+    for which in (range(12), (1, 4, 9)):
         ref = make(False, which)
         want = [torch.cat([s.advance(k) for k in cuts]) for s in ref]
         assert H.last_kernel() == 1

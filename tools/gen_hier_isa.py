@@ -340,7 +340,8 @@ def generate(with_main=True):
         mains = G.main_kernels()
         info = dict(mains[0][5])
         for ne, shape, code, name, built, kinfo in mains:
-            kernels.append(built)
+            if built is not None:
+                kernels.append(built)
             if name != "phf_hier3_advance":
                 info["%s" % name] = {"vgpr_high_water": kinfo["vgpr_high_water"], "lds_bytes_per_workgroup": kinfo["lds_bytes_per_workgroup"],
                                      "count_iteration": kinfo["count_iteration"]}

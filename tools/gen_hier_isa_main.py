@@ -24,18 +24,21 @@ from gen_hier_isa import ARG_BYTES, ARG_OFF, Gen
 # per iteration, measured as 20 % of the wavefront's cycles in s_waitcnt.)
 WAVE_BASE = 8064                                    # behind the workgroup's tables (M.TABLE_BYTES, padded)
 GLB_FIRST_ROW, G_AHEAD = 9, 3                       # Ne = 4: rows 9..12 of L live in the scratch tier, fetched three columns ahead
+TIERS = {4: (9, 3), 5: (4, 2), 6: (2, 1)}                      # Ne -> (first row of L in the scratch tier, columns fetched ahead); Ne = 5: all but rows 1..3
 
 RESIDENT = ["L2E64", "NLN2HI64", "NLN2LO64", "KE0", "KE1", "K100", "KL0", "KL1", "KL2", "LN2HI", "LN2LO", "LN10", "ISQRT2",
             "M746", "P710", "P40", "P6", "QUARTER", "LOGADD", "MBITS"]
 
 
 def shape_code(shape):
-    """PHF_HIER_SHAPE(per, last) of a point shape (phf_hier_model.h; phf_hier_points.points_per_expt): every experiment `per` points,
-    the last one `last` if that differs; None for a shape that code cannot express"""
+    """the code of a point shape (phf_hier_points.points_per_expt): PHF_HIER_SHAPE(per, last) of phf_hier_model.h — every experiment `per`
+    points, the last one `last` if that differs — where the shape has that form, else the list form; None for a shape neither expresses"""
     per, last = shape[0], shape[-1]
-    if any(n != per for n in shape[:-1]) or not (0 < per < 16 and 0 < last < 16):
-        return None
-    return per if last == per else per | (last << 4)
+    if all(n == per for n in shape[:-1]) and 0 < per < 16 and 0 < last < 16:
+        return per if last == per else per | (last << 4)
+    if len(shape) <= 7 and all(0 < n < 16 for n in shape):         # the list form (ABI 7): bit 30 + a nibble per experiment
+        return (1 << 30) | sum(n << (4 * i) for i, n in enumerate(shape))
+    return None
 
 
 def kernel_name(ne, shape):
@@ -47,7 +50,7 @@ def kernel_name(ne, shape):
 def configure(ne, shape):
     """the module's layout constants for a kernel of `ne` experiments with shape[i] points in experiment i"""
     global NE, D, TRI, S_TH, S_LT, S_MEAN, S_TRI, S_LOGA, S_NACC, SHAPE, N_PTS, PT_START, PT_OFF, PT_YOFF, LDS_L, SLOT_MEAN, SLOT_D, SLOT_L, NSLOTS
-    global U_POINTS, U_LOC, U_ISC, U_SM1, U_BYTES, WAVE_LDS, LDS_BYTES, NAME, GLB_L
+    global U_POINTS, U_LOC, U_ISC, U_SM1, U_BYTES, WAVE_LDS, LDS_BYTES, NAME, GLB_L, GLB_FIRST_ROW, G_AHEAD
     assert len(shape) == ne and all(1 <= n <= 8 for n in shape)
     NE, D = ne, 5 + 2 * ne
     TRI = D * (D + 1) // 2
@@ -60,7 +63,18 @@ def configure(ne, shape):
     if ne == 3:
         LDS_L = [(i, 0) for i in range(1, D)] + [(i, 1) for i in range(2, 5)]
         GLB_L = []
+    elif ne == 5:
+        # Ne = 5: 171 doubles of state per chain.  theta, the proposal, w and u alone are 60 doubles during the sweep: L lives in the scratch
+        # tier but for rows 1..3 (one element in a register, five in the LDS slots the mean and d leave), streamed column by column
+        GLB_FIRST_ROW, G_AHEAD = TIERS[5]
+        GLB_L = [(i, kc) for kc in range(D) for i in range(max(kc + 1, GLB_FIRST_ROW), D)]
+        LDS_L = [(2, 0), (3, 0), (2, 1), (3, 1), (3, 2)]
+    elif ne == 6:
+        GLB_FIRST_ROW, G_AHEAD = TIERS[6]                    # Ne = 6: 208 doubles; the mean and d fill 34 of the 35 LDS slots, L[1][0] the last
+        GLB_L = [(i, kc) for kc in range(D) for i in range(max(kc + 1, GLB_FIRST_ROW), D)]
+        LDS_L = [(1, 0)]
     else:
+        GLB_FIRST_ROW, G_AHEAD = TIERS[4]
         # Ne = 4: 135 doubles of state per chain against 128 registers + 35 LDS slots per lane at two wavefronts per SIMD: a THIRD tier,
         # a scratch area in device memory (L2-resident: 21 KB per resident wavefront), holds the last rows of L — four elements per
         # column, loaded G_AHEAD columns ahead of their use and stored back as the sweep produces them
@@ -972,7 +986,9 @@ class Main(object):
         k.add(wb1, beta, -1.0)
         # half 0: ln alpha, ln Hill_1..3, ln beta, ln(alpha - loc0)
         part0, part1 = k.vd(), k.vd()
-        assert NE in (3, 4), "the halves' shares of the first batch of logarithms: half 0 = alpha, Hill_i, beta, alpha - loc0"
+        # (the 9 + Ne logarithms in phf_hier_target_half's order — alpha | Hill_i | beta | x_k - loc_k | s | sigma [| pad] — half 0 takes the first
+        # (10 + Ne) / 2: up to alpha - loc0 for Ne = 3, 4, up to beta for Ne = 5, 6)
+        assert NE in (3, 4, 5, 6)
         lg0 = [k.vd() for _ in range(NE + 1)]
         args0 = [alpha] + hill
         for j in range(0, NE + 1, 2):
@@ -982,18 +998,30 @@ class Main(object):
             k.fma(part0, wb1, lg0[1 + i], part0)
         k.free(wnb, wb1)
         t2 = [k.vd(), k.vd()]
-        M.log_fast(m, t2, [beta, xl[0]])
-        k.fma(part0, three, t2[0], part0)
-        k.fma(part0, sm1[0], t2[1], part0)
-        # half 1: ln(beta - loc1), ln(mu - loc2), ln(s - loc3), ln(sigma - loc4), ln s, ln sigma
-        t4 = [k.vd() for _ in range(2)]
-        M.log_fast(m, t2, [xl[1], xl[2]])
-        M.log_fast(m, t4, [xl[3], xl[4]])
-        for j, r in enumerate(t2 + t4):
-            k.fma(part1, sm1[1 + j], r, 0.0 if j == 0 else part1)
-        M.log_fast(m, t2, [s_, sigma])
-        k.fma(part1, Neg(three), t2[0], part1)
-        k.fma(part1, Neg(twelve), t2[1], part1)
+        if NE <= 4:
+            M.log_fast(m, t2, [beta, xl[0]])
+            k.fma(part0, three, t2[0], part0)
+            k.fma(part0, sm1[0], t2[1], part0)
+            # half 1: ln(beta - loc1), ln(mu - loc2), ln(s - loc3), ln(sigma - loc4), ln s, ln sigma
+            t4 = [k.vd() for _ in range(2)]
+            M.log_fast(m, t2, [xl[1], xl[2]])
+            M.log_fast(m, t4, [xl[3], xl[4]])
+            for j, r in enumerate(t2 + t4):
+                k.fma(part1, sm1[1 + j], r, 0.0 if j == 0 else part1)
+            M.log_fast(m, t2, [s_, sigma])
+            k.fma(part1, Neg(three), t2[0], part1)
+            k.fma(part1, Neg(twelve), t2[1], part1)
+        else:
+            M.log_fast(m, t2[:1], [beta])
+            k.fma(part0, three, t2[0], part0)
+            # half 1: ln(x_k - loc_k) for all five, ln s, ln sigma
+            t4 = []
+            args1 = list(xl) + [s_, sigma]
+            wts1 = list(sm1) + [Neg(three), Neg(twelve)]
+            for j in range(0, 7, 2):
+                M.log_fast(m, t2[:len(args1[j:j + 2])], args1[j:j + 2])
+                for jj in range(len(args1[j:j + 2])):
+                    k.fma(part1, wts1[j + jj], t2[jj], 0.0 if j + jj == 0 else part1)
         if (9 + NE) % 2:                                     # the pad of half 1: fma(0, ln 1, part) with ln 1 = +0 exactly
             k.add(part1, part1, 0.0)
         k.free(t4, xl, f_sm1, three, twelve)
@@ -1288,7 +1316,7 @@ class Main(object):
 # next task whatever group it belongs to.  Kernel arguments: a header (queue-level values) + one phf_hier3_isa_args block per body.
 FUSED_HDR = {"consts": 0, "queue": 8, "scratch": 16, "t_begin": 24, "t_end": 28, "quantum": 32, "num_tasks": 36, "blocks_magic": 40,
              "rows_per_quantum": 44, "total_blocks": 48, "bounds": 64}
-FUSED_HDR_BYTES, FUSED_MAX_BODIES = 96, 8
+FUSED_HDR_BYTES, FUSED_MAX_BODIES = 128, 16
 
 
 class FusedMain(Main):
@@ -1302,8 +1330,12 @@ class FusedMain(Main):
             wave_lds.append(WAVE_LDS)
             slots.add(NSLOTS)
         assert len(slots) == 1, "the bodies share the wavefront's LDS base arithmetic"
-        with_scratch = [kd for kd in self.kinds if kd[0] == 4]
-        configure(*(with_scratch[0] if with_scratch else self.kinds[0]))      # the prologue's scratch bases: sized for the bodies that have a scratch tier
+        biggest = None
+        for ne, shape in self.kinds:                                           # the prologue's scratch base: a wavefront's area holds the largest tier
+            configure(ne, shape)
+            if biggest is None or len(GLB_L) > biggest[0]:
+                biggest = (len(GLB_L), (ne, shape))
+        configure(*biggest[1])
         WAVE_LDS = max(wave_lds)
         self.lds_bytes = WAVE_BASE + 4 * WAVE_LDS
         assert 2 * self.lds_bytes <= 160 * 1024
@@ -1438,8 +1470,9 @@ def fused_kernel():
 # the kernels of the code object: (experiments, points per experiment).  The Crumb set's 154 pairs with three experiments are 147 x (4, 4, 4),
 # 6 x (2, 2, 2) and 1 x (5, 5, 4)
 # ... and the 41 with four are 32 x (4, 4, 4, 1), 5 x (4, 4, 4, 2), 2 x (4, 4, 4, 3), (2, 2, 2, 1), (5, 5, 5, 1)
+# ... the 12 with five: 5 x (4, 4, 4, 1, 1), 5 x (4, 4, 4, 2, 1), (4, 4, 4, 4, 4), (5, 5, 4, 2, 2)
 HIER_KERNELS = [(3, (4, 4, 4)), (3, (2, 2, 2)), (3, (5, 5, 4)), (4, (4, 4, 4, 1)), (4, (4, 4, 4, 2)), (4, (4, 4, 4, 3)),
-                (4, (2, 2, 2, 1)), (4, (5, 5, 5, 1))]
+                (4, (2, 2, 2, 1)), (4, (5, 5, 5, 1)), (5, (4, 4, 4, 1, 1)), (5, (4, 4, 4, 2, 1)), (5, (4, 4, 4, 4, 4)), (5, (5, 5, 4, 2, 2))]
 
 
 def main_kernel(ne=3, shape=(4, 4, 4)):
@@ -1450,12 +1483,18 @@ def main_kernel(ne=3, shape=(4, 4, 4)):
         configure(3, (4, 4, 4))
 
 
+# ... of which these also exist as kernels of their own (a launch group on its own: phf_hierarchical_advance_queued; s3h; the A/B and PMC runs);
+# the others are bodies of the fused kernel only — a group of such a shape launched by itself runs the hipcc kernel (the same numbers)
+STANDALONE = HIER_KERNELS[:6]
+
+
 def main_kernels():
-    """[(n_expts, shape, shape code, kernel name, (lines, meta), info)]"""
+    """[(n_expts, shape, shape code, kernel name, (lines, meta) or None, info)]: every body of the fused kernel, with the kernel of its own
+    where it has one"""
     out = []
     for ne, shape in HIER_KERNELS:
         built, info = main_kernel(ne, shape)
-        out.append((ne, shape, shape_code(shape), kernel_name(ne, shape), built, dict(info)))
+        out.append((ne, shape, shape_code(shape), kernel_name(ne, shape), built if (ne, shape) in STANDALONE else None, dict(info)))
     return out
 
 
@@ -1477,7 +1516,7 @@ def header_extra(kernels):
              "#define PHF_ISA_FUSED_BODIES %d\n"
              "typedef struct phf_hier_fused_args {\n"
              "  const void* consts;\n  int32_t* queue;\n  double* scratch;\n  uint32_t t_begin, t_end;\n"
-             "  uint32_t quantum, num_tasks, blocks_magic, rows_per_quantum;\n  int32_t total_blocks;\n  int32_t pad[3];\n  uint32_t bounds[8];\n"
+             "  uint32_t quantum, num_tasks, blocks_magic, rows_per_quantum;\n  int32_t total_blocks;\n  int32_t pad[3];\n  uint32_t bounds[16];\n"
              "  phf_hier3_isa_args body[PHF_ISA_FUSED_BODIES];\n} phf_hier_fused_args;\n" % n)
     for name in ("consts", "queue", "scratch", "t_begin", "t_end", "quantum", "num_tasks", "blocks_magic", "rows_per_quantum", "total_blocks", "bounds"):
         text += "_Static_assert(__builtin_offsetof(phf_hier_fused_args, %s) == %d, \"layout of %s\");\n" % (name, FUSED_HDR[name], name)
