@@ -104,7 +104,14 @@ def tri_index(i, k):
 
 
 class Main(object):
+    # how a block's state becomes visible to the wavefront that runs its next quantum (possibly on another XCD, whose L2 is not coherent with
+    # this one's).  False: the sequence hipcc emits for an agent-scope release — buffer_wbl2 writes EVERY dirty line of this XCD's L2 back,
+    # the scratch tier's among them: 52 of a C4 step's 61 GB of HBM traffic were those.  True: the state's stores and the moments' atomics are
+    # system-scope (written through / performed at the memory side), nothing else needs to leave the L2
+    WRITE_THROUGH_RELEASE = True
+
     def __init__(self):
+        self.write_through_release = self.WRITE_THROUGH_RELEASE
         self.g = Gen(NAME, NSLOTS)
         self.k = self.g.k
         self.m = self.g.m
@@ -530,8 +537,9 @@ class Main(object):
             k.branch("s_cbranch_scc1", self.l_end)
         k.sop("s_mov_b64", EXEC, -1)
         k.s_waitcnt_all()
-        k.raw_rec("buffer_wbl2 sc1")
-        k.raw_rec("s_waitcnt vmcnt(0)")
+        if not getattr(self, "write_through_release", False):
+            k.raw_rec("buffer_wbl2 sc1")
+            k.raw_rec("s_waitcnt vmcnt(0)")
         k.sop("s_lshl_b32", t2.lo(), getattr(self, "s_qblock", self.s_block), 2)
         k.sop("s_mov_b32", t2.hi(), 0)
         self.add64(t2, t2, self.s_queue)
@@ -603,15 +611,16 @@ class Main(object):
                     k.gload(t, self.v_lane8, cur)
                     temps.append((t, slot))
             else:
+                scope = "sc0 sc1" if getattr(self, "write_through_release", False) else ""
                 if reg is not None:
-                    k.gstore(self.v_lane8, reg, cur)
+                    k.gstore(self.v_lane8, reg, cur, scope=scope)
                 else:
                     t = k.vd()
                     if isinstance(slot, tuple):
                         self.g_load(t, slot[1])
                     else:
                         self.lds_load(t, slot)
-                    k.gstore(self.v_lane8, t, cur)
+                    k.gstore(self.v_lane8, t, cur, scope=scope)
                     k.free(t)
             self.add64(cur, cur, self.s_nch8)
             if load and len(temps) == 12:
@@ -921,7 +930,7 @@ class Main(object):
                 t = sq[r % 4]
                 k.mul(t, src, src)
                 src = t
-            k.gatomic_add_f64(self.v_lane8, src, cur)
+            k.gatomic_add_f64(self.v_lane8, src, cur, scope="sc1" if getattr(self, "write_through_release", False) else "")
             self.add64(cur, cur, self.s_nch8)
         k.free(sq, cur)
         k.label(l_skip)
@@ -1344,6 +1353,7 @@ class FusedMain(Main):
         self.info = {}
         self.ARG_OFF = self.offsets(0)
         self.emit_end = False
+        self.write_through_release = self.WRITE_THROUGH_RELEASE
 
     def offsets(self, body):
         off = {name: FUSED_HDR_BYTES + body * ARG_BYTES + o for name, o in ARG_OFF.items()}

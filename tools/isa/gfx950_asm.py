@@ -490,13 +490,15 @@ class Kernel(object):
         self.emit(opc, [d], [voff, sbase], "vmem", suffix="offset:%d" % offset if offset else "", mem="vm")
         return d
 
-    def gstore(self, voff, data, sbase, offset=0):
+    def gstore(self, voff, data, sbase, offset=0, scope=""):
+        """scope: "" (wavefront: the line may stay dirty in L2) or "sc0 sc1" (system: written through to memory)"""
         opc = {2: "global_store_dwordx2", 4: "global_store_dwordx4", 1: "global_store_dword"}[data.n]
         assert -4096 <= offset < 4096
-        self.emit(opc, [], [voff, data, sbase], "vmem", suffix="offset:%d" % offset if offset else "", mem="vm")
+        self.emit(opc, [], [voff, data, sbase], "vmem", suffix=" ".join(x for x in ("offset:%d" % offset if offset else "", scope) if x), mem="vm")
 
-    def gatomic_add_f64(self, voff, data, sbase, offset=0):
-        self.emit("global_atomic_add_f64", [], [voff, data, sbase], "vmem", suffix="offset:%d" % offset if offset else "", mem="vm")
+    def gatomic_add_f64(self, voff, data, sbase, offset=0, scope=""):
+        """scope: "" (agent: performed in this XCD's L2) or "sc1" (system: performed at the memory side)"""
+        self.emit("global_atomic_add_f64", [], [voff, data, sbase], "vmem", suffix=" ".join(x for x in ("offset:%d" % offset if offset else "", scope) if x), mem="vm")
 
     # ---- scalar ----
     def sop(self, opc, d, *srcs):
