@@ -23,7 +23,7 @@ from gen_hier_isa import ARG_BYTES, ARG_OFF, Gen
 # share lgkmcnt with the LDS and return out of order, so every table look-up behind one waits for it: ~11 exposed scalar-memory latencies
 # per iteration, measured as 20 % of the wavefront's cycles in s_waitcnt.)
 WAVE_BASE = 8064                                    # behind the workgroup's tables (M.TABLE_BYTES, padded)
-GLB_FIRST_ROW, G_AHEAD = 9, 3                       # Ne = 4: rows 9..12 of L live in the scratch tier, fetched three columns ahead
+GLB_FIRST_ROW, G_AHEAD, G_PRE = 9, 3, 3              # Ne = 4: rows 9..12 of L live in the scratch tier, fetched three columns ahead
 TIERS = {4: (9, 3), 5: (4, 2), 6: (2, 1)}                      # Ne -> (first row of L in the scratch tier, columns fetched ahead); Ne = 5: all but rows 1..3
 
 RESIDENT = ["L2E64", "NLN2HI64", "NLN2LO64", "KE0", "KE1", "K100", "KL0", "KL1", "KL2", "LN2HI", "LN2LO", "LN10", "ISQRT2",
@@ -743,7 +743,8 @@ class Main(object):
         """top of the loop, ahead of the draws: the scratch-tier elements of the sweep's first columns (a device-memory latency that the
         draws cover)"""
         self.gq = {}
-        for kc in range(G_AHEAD if GLB_L else 0):
+        self.g_fetched = min(G_AHEAD, G_PRE) if GLB_L else 0        # (the draws leave room for G_PRE columns; the rest of the lead is taken at the sweep's start)
+        for kc in range(self.g_fetched):
             self.g_fetch_column(kc)
 
     def sweep(self):
@@ -840,8 +841,9 @@ class Main(object):
                 self.lds_load(dq[kc + 2], SLOT_D + kc + 2)
             if kc + 1 < D:
                 fetch_column(kc + 1)
-            if GLB_L and kc + G_AHEAD < D:
-                self.g_fetch_column(kc + G_AHEAD)
+            while GLB_L and self.g_fetched <= kc + G_AHEAD and self.g_fetched < D:
+                self.g_fetch_column(self.g_fetched)
+                self.g_fetched += 1
             dk, ap, dn = hd["dk"], hd["ap"], hd["dn"]
             inv, beta, sq = k.vd(), k.vd(), k.vd()
             lik = {i: source(i, kc) for i in range(kc + 1, D)}
