@@ -53,6 +53,27 @@ def test_generator_places_other_point_shapes_within_the_same_budget(ne, shape):
     assert "scratch_" not in "\n".join(lines)
 
 
+def test_kernel_table_is_the_same_in_generator_header_and_host_package():
+    """the (experiments, point shape) kernels exist in three places — the generator's list, the generated header's table (what the library
+    looks a launch's shape up in) and pyhillfit_amd.hierarchical.ISA_SHAPES (what the host groups pairs by): one set of shape codes"""
+    import re
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    sys.path.insert(0, os.path.join(REPO, "tools", "isa"))
+    import gen_hier_isa_main as G
+    from pyhillfit_amd import hierarchical as H
+    gen = {(ne, G.shape_code(shape)) for ne, shape in G.HIER_KERNELS}
+    assert len(gen) == len(G.HIER_KERNELS) and None not in {c for _, c in gen}
+    for ne, shape in G.HIER_KERNELS:
+        assert G.shape_code(shape) == H.shape_code(shape), shape
+    with open(os.path.join(REPO, "pyhillfit_amd", "csrc", "generated", "phf_hier3_isa_layout.h")) as f:
+        hdr = f.read()
+    table = {(int(a), int(b)) for a, b in re.findall(r"^\s*\{(\d+), (\d+), \d+, \"phf_hier", hdr, flags=re.M)}
+    assert table == gen == H.ISA_SHAPES
+    assert ("#define PHF_ISA_FUSED_BODIES %d" % len(gen)) in hdr
+    assert H.shape_code((4, 4, 4)) == 4 and H.shape_code((4, 4, 4, 1)) == 0x14 and H.shape_code((4, 4, 4, 1, 1)) == 0x40011444
+    assert H.shape_code((17, 1)) == 0 and H.shape_code((1,)) == 0 and H.shape_code((3, 2, 1, 1, 1, 1, 1, 1)) == 0
+
+
 def test_builder_inserts_waits_and_hazard_nops():
     """tools/isa/gfx950_asm.py: the s_waitcnt / s_nop insertion the generated code relies on (the assembler inserts none)"""
     sys.path.insert(0, os.path.join(REPO, "tools", "isa"))
