@@ -1,5 +1,5 @@
-"""Diagnostic: the parts of a fused C4 step (210 pairs x 1 024 chains, 2 000 iterations) on their own: the fused launch of all six assembly
-groups, of the Ne = 3 groups only, of the Ne = 4 groups only, the hipcc rest (Ne = 5, 6 and two odd Ne = 4 pairs) on its streams, and all of it.
+"""Diagnostic: the parts of a fused C4 step (210 pairs x 1 024 chains, 2 000 iterations) on their own: the fused launch of every assembly
+group, of the Ne = 3 / Ne = 4 / Ne = 5 groups only, the hipcc rest (Ne = 6) on its stream, and all of it.
 -> profiles/r05/c4_fused_launch.txt"""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,8 +41,9 @@ def run(label, keep):
     del b; torch.cuda.empty_cache()
 
 
-run("fused: all six assembly groups", lambda h, f: f)
+run("fused: every assembly group (Ne = 3, 4, 5: twelve bodies)", lambda h, f: f)
 run("fused: the three Ne = 3 groups", lambda h, f: f and h.n_expts == 3)
-run("fused: the three Ne = 4 groups", lambda h, f: f and h.n_expts == 4)
-run("hipcc rest: Ne = 6, 5 and the two odd Ne = 4 pairs, a stream each", lambda h, f: not f)
+run("fused: the five Ne = 4 groups", lambda h, f: f and h.n_expts == 4)
+run("fused: the four Ne = 5 groups", lambda h, f: f and h.n_expts == 5)
+run("hipcc rest: Ne = 6", lambda h, f: not f)
 run("everything (a C4 step)", lambda h, f: True)
