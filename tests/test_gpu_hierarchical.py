@@ -312,6 +312,31 @@ def test_hierarchical_cli_fused_launch_chain_files_equal_the_twin(gpu, tmp_path)
     assert len(kinds) == 7, kinds
 
 
+def test_hierarchical_cli_all_pairs_fused_launch_on_equals_off(gpu, tmp_path):
+    """all 210 Crumb pairs (every launch group: twelve shapes in the fused grid, Ne = 6 beside it) through the command line with --fused-launch on
+    and off: the same chain files byte for byte, the same pooled posterior summaries"""
+    import filecmp
+    from pyhillfit_amd import PyHillFit
+    from pyhillfit_amd import doseresponse as dr
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    csv = str(tmp_path / "crumb_data.csv")
+    dr.table.to_csv(csv)
+    res = {}
+    for mode in ("on", "off"):
+        out = str(tmp_path / ("output_" + mode))
+        res[mode] = (out, PyHillFit.main(["--data-file", csv, "-m", "2", "--hierarchical", "-a", "-i", "4000", "-t", "5", "--num-chains", "128",
+                                          "--output-root", out, "--num-APs", "20", "--segment", "2000", "--fused-launch", mode]))
+    on, off = res["on"][1], res["off"][1]
+    assert len(on) == len(off) == 210
+    off = {(b["drug"], b["channel"]): b for b in off}                     # (the groups, and so the summaries' order, differ between the two modes)
+    for a in on:
+        b = off[(a["drug"], a["channel"])]
+        assert a["pooled_mean"] == b["pooled_mean"] and a["pooled_sd"] == b["pooled_sd"] and a["acceptance"] == b["acceptance"], (a["drug"], a["channel"])
+        rel = os.path.join("crumb_data", "hierarchical", a["drug"], a["channel"], "%d_expts" % a["num_expts"], "chain",
+                           "crumb_data_%s_%s_hierarchical_chain.txt" % (a["drug"], a["channel"]))
+        assert filecmp.cmp(os.path.join(res["on"][0], rel), os.path.join(res["off"][0], rel), shallow=False), rel
+
+
 def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):
     """pairs with more than 8 experiments (the reference's synthetic set: Ne = 50, dim 105, 200 points) run one wavefront per
     chain (state in LDS, lanes = experiments / factor rows): same bits as the twin across a launch cut, and the moments it
