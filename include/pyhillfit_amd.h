@@ -211,7 +211,8 @@ typedef struct phf_hier_points {
                                  build of the iteration (two wavefronts per SIMD: same numbers) where the library has one for (n_expts,
                                  shape): n_expts == 3 with 4 + 4 + 4 points (147 of the Crumb set's 210 pairs), 2 + 2 + 2 (6), 5 + 5 + 4 (1);
                                  ABI 7: every n_expts == 4 shape of the Crumb set (4 + 4 + 4 + 1 (32 pairs), + 2 (5), + 3 (2), 2 + 2 + 2 + 1, 5 + 5 + 5 + 1) and
-                                 every n_expts == 5 one (4 + 4 + 4 + 1 + 1 (5), 4 + 4 + 4 + 2 + 1 (5), 4 + 4 + 4 + 4 + 4, 5 + 5 + 4 + 2 + 2) — through
+                                 every n_expts == 5 and 6 one (4 + 4 + 4 + 1 + 1 (5), 4 + 4 + 4 + 2 + 1 (5), 4 + 4 + 4 + 4 + 4, 5 + 5 + 4 + 2 + 2; 4 + 4 + 4 + 1 + 1 + 1 (2),
+                                 4 + 4 + 4 + 4 + 2 + 1: the last two, like 2 + 2 + 2 + 1, 5 + 5 + 5 + 1 and the n_expts == 5 ones, in the fused kernel only) — through
                                  phf_hierarchical_advance_queued / _fused with a workspace of phf_hierarchical_queue_words() words and kernel_hint bit 6. */
   const double* ln_conc;      /* device [P][stride] */
   const double* response;     /* device [P][stride] */
@@ -274,7 +275,7 @@ int64_t phf_hierarchical_queue_words(const phf_hier_points* pts, const phf_probl
 /* EVERY launch group of a run through ONE persistent grid (ABI 7; phf_hier_fused_advance of the gfx950 code object: a body per (n_expts, point
  * shape), a wavefront that finishes a task of one group pulls the next task whatever group it belongs to).  Separate launches side by side —
  * one stream per group, what python/PyHillFit.py's pool amounts to (:997-1003) — leave a chip's workgroup slots to whichever persistent grid
- * got them first; one queue does not.  groups: 1..12 of them, each with a (n_expts, points_per_expt) the code object has a kernel for
+ * got them first; one queue does not.  groups: 1..14 of them, each with a (n_expts, points_per_expt) the code object has a kernel for
  * (PHF_ERR_UNSUPPORTED otherwise: launch such groups one by one), no two alike; the same thinning in every cfg; t_begin a multiple of it.
  * Every chain's numbers are those of phf_hierarchical_advance, bit for bit.  queue: device int32 [phf_hierarchical_fused_queue_words()],
  * zeroed by the caller when allocated; word 1 + (the groups' blocks) is the sticky fault flag. */

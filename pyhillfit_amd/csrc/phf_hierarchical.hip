@@ -9,6 +9,8 @@
 // traffic at all.  HBM sees the state once per launch and the thinned samples.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include <atomic>
 #include <cstdlib>
 
@@ -1343,8 +1345,12 @@ int phf_hierarchical_advance_fused(int32_t n_groups, const phf_hier_group* group
     a.pts = *g.pts; a.prob = *g.prob; a.prior = *prior; a.cfg = *g.cfg; a.t_begin = t_begin; a.t_end = t_end; a.state = g.state; a.rows = g.rows;
     a.moments = g.moments; a.moments_after = moments_after;
     a.blocks_per_problem = (g.prob->chains_per_problem + kBlock - 1) / kBlock;
-    fill_isa_args(a, &fa.body[body_of[i]]);
+    phf_hier3_isa_args full{};
+    fill_isa_args(a, &full);
+    static_assert(sizeof(phf_hier_body_args) <= sizeof(phf_hier3_isa_args), "a body's block is the head of phf_hier3_isa_args");
+    std::memcpy(&fa.body[body_of[i]], &full, sizeof(phf_hier_body_args));
   }
+  for (int i = 0; i < 5; ++i) { fa.prior_loc[i] = prior->loc[i]; fa.prior_inv_scale[i] = prior->inv_scale[i]; fa.prior_shape_m1[i] = prior->shape_m1[i]; }
   // bounds[b]: first block of body b's group, bodies in table order; a body without a group gets an empty range
   int64_t run = 0;
   for (int b = 0; b < 16; ++b) {

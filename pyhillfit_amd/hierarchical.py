@@ -74,7 +74,8 @@ def shape_code(sizes):
 ISA_SHAPES = {(3, shape_code((4, 4, 4))), (3, shape_code((2, 2, 2))), (3, shape_code((5, 5, 4))),
               (4, shape_code((4, 4, 4, 1))), (4, shape_code((4, 4, 4, 2))), (4, shape_code((4, 4, 4, 3))),
               (4, shape_code((2, 2, 2, 1))), (4, shape_code((5, 5, 5, 1))),
-              (5, shape_code((4, 4, 4, 1, 1))), (5, shape_code((4, 4, 4, 2, 1))), (5, shape_code((4, 4, 4, 4, 4))), (5, shape_code((5, 5, 4, 2, 2)))}
+              (5, shape_code((4, 4, 4, 1, 1))), (5, shape_code((4, 4, 4, 2, 1))), (5, shape_code((4, 4, 4, 4, 4))), (5, shape_code((5, 5, 4, 2, 2))),
+              (6, shape_code((4, 4, 4, 1, 1, 1))), (6, shape_code((4, 4, 4, 4, 2, 1)))}
 
 
 # ... and the shapes whose pairs get a launch group of their own.  The Ne = 4 kernels are measured and NOT grouped by default: alone they

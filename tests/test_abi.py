@@ -111,7 +111,7 @@ def test_argument_validation_without_gpu(lib):
         g.pts = C.pointer(hp); g.prob = C.pointer(prob); g.cfg = C.pointer(cfg); g.state = 1
     assert lib.phf_hierarchical_fused_queue_words(1, grp) == 2 + blocks
     assert lib.phf_hierarchical_fused_queue_words(2, grp) == -3 and b"two groups of one" in lib.phf_last_error()
-    assert lib.phf_hierarchical_fused_queue_words(0, grp) == -1 and lib.phf_hierarchical_fused_queue_words(13, grp) == -1      # 1..12 groups
+    assert lib.phf_hierarchical_fused_queue_words(0, grp) == -1 and lib.phf_hierarchical_fused_queue_words(15, grp) == -1      # 1..14 groups
     hp.points_per_expt = (1 << 30) | 0x124                     # the list form: 4 + 2 + 1 points — a valid code, no gfx950 kernel for that shape
     assert lib.phf_hierarchical_fused_queue_words(1, grp) == -3 and b"no gfx950 kernel" in lib.phf_last_error()
     for bad in ((1 << 30) | 0x1124, (1 << 30) | 0x104):        # a nibble beyond the third experiment; an experiment without points

@@ -154,6 +154,8 @@ NE5 = {"4 + 4 + 4 + 1 + 1": [("Lopinavir", "KvLQT1/mink"), ("Mibefradil", "KvLQT
        "4 + 4 + 4 + 2 + 1": [("Azithromycin", "Cav1.2"), ("Lidocaine", "Cav1.2"), ("Quinine", "Kv4.3")],
        "4 + 4 + 4 + 4 + 4": [("Moxifloxacin", "KvLQT1/mink")] * 3, "5 + 5 + 4 + 2 + 2": [("Dofetilide", "hERG")] * 3}
 THETA0_5 = [np.concatenate([t[:4], np.tile(t[4:6], 5), t[-1:]]) for t in THETA0]
+NE6 = {"4 + 4 + 4 + 1 + 1 + 1": [("Chloroquine", "Kv4.3"), ("Cibenzoline", "Kv4.3"), ("Chloroquine", "Kv4.3")], "4 + 4 + 4 + 4 + 2 + 1": [("Amitriptyline", "Kv4.3")] * 3}
+THETA0_6 = [np.concatenate([t[:4], np.tile(t[4:6], 6), t[-1:]]) for t in THETA0]
 
 
 @pytest.mark.parametrize("shape", ["4 + 4 + 4 + 1", "4 + 4 + 4 + 2", "4 + 4 + 4 + 3"])         # (the shapes with a kernel of their own)
@@ -229,9 +231,9 @@ def test_isa_four_experiments_work_queue_at_full_width(gpu):
         assert bool(same.all()), (name, int((~same).sum()))
 
 
-def test_fused_launch_of_twelve_groups_bit_identical_to_separate_launches(gpu, oracle_pair):
-    """phf_hierarchical_advance_fused: the twelve kinds of launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4: 4 + 4 + 4 + 1 / 2 / 3, 2 + 2 + 2 + 1,
-    5 + 5 + 5 + 1; Ne = 5: 4 + 4 + 4 + 1 + 1, 4 + 4 + 4 + 2 + 1, 4 + 4 + 4 + 4 + 4, 5 + 5 + 4 + 2 + 2: every Crumb pair with three, four or five experiments) in ONE
+def test_fused_launch_of_fourteen_groups_bit_identical_to_separate_launches(gpu, oracle_pair):
+    """phf_hierarchical_advance_fused: the fourteen kinds of launch groups (Ne = 3: 4 + 4 + 4, 2 + 2 + 2, 5 + 5 + 4; Ne = 4: 4 + 4 + 4 + 1 / 2 / 3, 2 + 2 + 2 + 1,
+    5 + 5 + 5 + 1; Ne = 5: 4 + 4 + 4 + 1 + 1, 4 + 4 + 4 + 2 + 1, 4 + 4 + 4 + 4 + 4, 5 + 5 + 4 + 2 + 2; Ne = 6: 4 + 4 + 4 + 1 + 1 + 1, 4 + 4 + 4 + 4 + 2 + 1 — every one of the 210 Crumb pairs has one of these fourteen shapes) in ONE
     persistent grid pulling from one queue — rows, state and moments of every group against its own launches of the hipcc kernel, bit for bit;
     quanta of 50 iterations (a block's quanta chain through its state, tasks of all groups interleave), a ragged last wavefront, a subset of
     the groups (bodies without a group), moments, and a fused launch continued by separate ones"""
@@ -239,7 +241,7 @@ def test_fused_launch_of_twelve_groups_bit_identical_to_separate_launches(gpu, o
     from pyhillfit_amd import hierarchical as H
     groups = [(UNIFORM4, THETA0), (OTHER_SHAPES["2 + 2 + 2"], THETA0), (OTHER_SHAPES["5 + 5 + 4"], THETA0),
               (NE4["4 + 4 + 4 + 1"], THETA0_4), (NE4["4 + 4 + 4 + 2"], THETA0_4), (NE4["4 + 4 + 4 + 3"], THETA0_4),
-              (NE4["2 + 2 + 2 + 1"], THETA0_4), (NE4["5 + 5 + 5 + 1"], THETA0_4)] + [(NE5[k_], THETA0_5) for k_ in sorted(NE5)]
+              (NE4["2 + 2 + 2 + 1"], THETA0_4), (NE4["5 + 5 + 5 + 1"], THETA0_4)] + [(NE5[k_], THETA0_5) for k_ in sorted(NE5)] + [(NE6[k_], THETA0_6) for k_ in sorted(NE6)]
     C, thin, adapt, cuts = 200, 5, 140, (135, 10, 355)
 
     def make(isa, which):
@@ -254,7 +256,7 @@ def test_fused_launch_of_twelve_groups_bit_identical_to_separate_launches(gpu, o
             out.append(s)
         return out
 
-    for which in (range(12), (1, 4, 9)):
+    for which in (range(14), (1, 4, 9), (0, 12, 13)):
         ref = make(False, which)
         want = [torch.cat([s.advance(k) for k in cuts]) for s in ref]
         assert H.last_kernel() == 1

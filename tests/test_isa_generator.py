@@ -41,10 +41,12 @@ def test_generated_kernel_fits_two_wavefronts_per_simd_and_assembles(tmp_path):
         assert k in names
 
 
-@pytest.mark.parametrize("ne,shape", [(3, (2, 2, 2)), (3, (5, 5, 4)), (3, (3, 3, 3)), (3, (8, 8, 8)), (3, (7, 5, 1))])
+@pytest.mark.parametrize("ne,shape", [(3, (2, 2, 2)), (3, (5, 5, 4)), (3, (3, 3, 3)), (3, (8, 8, 8)), (3, (7, 5, 1)), (4, (4, 4, 4, 1)), (5, (4, 4, 4, 1, 1)),
+                                      (6, (4, 4, 4, 1, 1, 1))])
 def test_generator_places_other_point_shapes_within_the_same_budget(ne, shape):
     """the target phase is emitted per point shape (a half's pairs, then its odd point; halves side by side where both have a pair): every
-    shape of up to eight points per experiment fits the registers and the LDS of two workgroups per CU — the allocator raises otherwise"""
+    shape of up to eight points per experiment fits the registers and the LDS of two workgroups per CU — the allocator raises otherwise; so do
+    four, five and six experiments with their scratch tiers (six: streamed element by element; generated, measured, not shipped as a body)"""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     sys.path.insert(0, os.path.join(REPO, "tools", "isa"))
     import gen_hier_isa_main as G

@@ -338,7 +338,7 @@ def generate(with_main=True):
     if with_main:
         import gen_hier_isa_main as G
         mains = G.main_kernels()
-        info = dict(mains[0][5])
+        info = dict([kd for kd in mains if kd[3] == "phf_hier3_advance"][0][5])
         for ne, shape, code, name, built, kinfo in mains:
             if built is not None:
                 kernels.append(built)

@@ -50,7 +50,8 @@ def kernel_name(ne, shape):
 def configure(ne, shape):
     """the module's layout constants for a kernel of `ne` experiments with shape[i] points in experiment i"""
     global NE, D, TRI, S_TH, S_LT, S_MEAN, S_TRI, S_LOGA, S_NACC, SHAPE, N_PTS, PT_START, PT_OFF, PT_YOFF, LDS_L, SLOT_MEAN, SLOT_D, SLOT_L, NSLOTS
-    global U_POINTS, U_LOC, U_ISC, U_SM1, U_BYTES, WAVE_LDS, LDS_BYTES, NAME, GLB_L, GLB_FIRST_ROW, G_AHEAD
+    global U_POINTS, U_LOC, U_ISC, U_SM1, U_BYTES, WAVE_LDS, LDS_BYTES, NAME, GLB_L, GLB_FIRST_ROW, G_AHEAD, G_STREAM
+    G_STREAM = 0
     assert len(shape) == ne and all(1 <= n <= 8 for n in shape)
     NE, D = ne, 5 + 2 * ne
     TRI = D * (D + 1) // 2
@@ -70,9 +71,14 @@ def configure(ne, shape):
         GLB_L = [(i, kc) for kc in range(D) for i in range(max(kc + 1, GLB_FIRST_ROW), D)]
         LDS_L = [(2, 0), (3, 0), (2, 1), (3, 1), (3, 2)]
     elif ne == 6:
-        GLB_FIRST_ROW, G_AHEAD = TIERS[6]                    # Ne = 6: 208 doubles; the mean and d fill 34 of the 35 LDS slots, L[1][0] the last
+        # Ne = 6: 208 doubles of state per chain; theta, the proposal, w and u are 68 of them, the mean and d fill 34 of the 35 LDS slots (L[1][0]
+        # the last): rows 2..16 of L go through the scratch tier ELEMENT BY ELEMENT — a window of G_STREAM loads in flight over the tier's
+        # column-major order, an element's two updates (w_i, then L_ik) and its term of y_i once the column's beta is known — because a
+        # whole column in registers (15 doubles, and the next one's on top) does not fit
+        GLB_FIRST_ROW, G_AHEAD = TIERS[6]
         GLB_L = [(i, kc) for kc in range(D) for i in range(max(kc + 1, GLB_FIRST_ROW), D)]
         LDS_L = [(1, 0)]
+        G_STREAM = 16
     else:
         GLB_FIRST_ROW, G_AHEAD = TIERS[4]
         # Ne = 4: 135 doubles of state per chain against 128 registers + 35 LDS slots per lane at two wavefronts per SIMD: a THIRD tier,
@@ -743,9 +749,75 @@ class Main(object):
         """top of the loop, ahead of the draws: the scratch-tier elements of the sweep's first columns (a device-memory latency that the
         draws cover)"""
         self.gq = {}
+        if G_STREAM:
+            self.g_fifo, self.g_next = [], 0
+            self.g_top_up()
+            return
         self.g_fetched = min(G_AHEAD, G_PRE) if GLB_L else 0        # (the draws leave room for G_PRE columns; the rest of the lead is taken at the sweep's start)
         for kc in range(self.g_fetched):
             self.g_fetch_column(kc)
+
+    def g_top_up(self):
+        """the streamed scratch tier: keep G_STREAM loads in flight over GLB_L's order"""
+        while len(self.g_fifo) < G_STREAM and self.g_next < len(GLB_L):
+            r = self.k.vd()
+            self.g_load(r, GLB_L[self.g_next])
+            self.g_fifo.append((GLB_L[self.g_next], r))
+            self.g_next += 1
+
+    def sweep_column_streamed(self, kc, w, y, lq, hd, head, inv, beta, sq, pos, alpha, omg):
+        """column kc of the sweep with the scratch tier streamed (G_STREAM): the same operations per value as the column-at-once form — w_i <- w_i -
+        w_k L_ik with the OLD L_ik, L_ik <- L_ik + beta w_i with the new w_i, y_i += L_ik u_k column after column — only their order ACROSS elements
+        differs: an element of the scratch tier gets all three once beta is known, four elements side by side"""
+        k, m = self.k, self.m
+        dk, ap, dn = hd["dk"], hd["ap"], hd["dn"]
+        near = [i for i in range(kc + 1, D) if (i, kc) not in GLB_L]          # registers / LDS: as in the other form
+        far = [i for i in range(kc + 1, D) if (i, kc) in GLB_L]
+        lik = {i: (lq[(i, kc)] if (i, kc) in LDS_L else self.Lreg[(i, kc)]) for i in near}
+        with k.parallel() as par:
+            par.stream()
+            M.rcp(m, [inv], [dn])
+            par.stream()
+            M.sqrt_nonneg(m, [sq], [dn], [pos])
+            k.mul(self.zn[kc], sq, self.zn[kc])
+            if near:
+                par.stream()
+                for i in near:
+                    k.fma(w[i], Neg(w[kc]), lik[i], w[i])
+        k.cnd64(inv, 0.0, inv, pos)
+        k.mul(beta, ap, inv)
+        k.mul(dk, alpha, dk)
+        k.mul(dk, dk, inv)
+        k.cnd64(alpha, alpha, dk, pos)
+        k.free(dk, ap, dn, inv, sq)
+        for i in near:
+            k.fma(lik[i], beta, w[i], lik[i])
+            if (i, kc) in LDS_L:
+                self.lds_store(self.l_slot(i, kc), lik[i])
+            k.fma(y[i], lik[i], self.zn[kc], 0.0 if kc == 0 else y[i])
+            if (i, kc) in LDS_L:
+                k.free(lq.pop((i, kc)))
+        k.add(y[kc], 0.0 if kc == 0 else y[kc], self.zn[kc])
+        for g0 in range(0, len(far), 4):
+            grp = far[g0:g0 + 4]
+            regs = []
+            for i in grp:
+                key, r = self.g_fifo.pop(0)
+                assert key == (i, kc), (key, i, kc)
+                regs.append(r)
+            for i, r in zip(grp, regs):
+                k.fma(w[i], Neg(w[kc]), r, w[i])
+            for i, r in zip(grp, regs):
+                k.fma(r, beta, w[i], r)
+            for i, r in zip(grp, regs):
+                self.g_store((i, kc), r)
+                k.fma(y[i], r, self.zn[kc], 0.0 if kc == 0 else y[i])
+            k.free(regs)
+            self.g_top_up()
+        k.free(beta)
+        nxt = head(kc + 1) if kc + 1 < D else None
+        k.free(w[kc], self.zn[kc])
+        return nxt
 
     def sweep(self):
         """the adaptation of iteration t - 1 (hier_advance_body: mean, loga, PHF_LDL_COLUMN column by column) fused with
@@ -841,11 +913,14 @@ class Main(object):
                 self.lds_load(dq[kc + 2], SLOT_D + kc + 2)
             if kc + 1 < D:
                 fetch_column(kc + 1)
-            while GLB_L and self.g_fetched <= kc + G_AHEAD and self.g_fetched < D:
+            while GLB_L and not G_STREAM and self.g_fetched <= kc + G_AHEAD and self.g_fetched < D:
                 self.g_fetch_column(self.g_fetched)
                 self.g_fetched += 1
             dk, ap, dn = hd["dk"], hd["ap"], hd["dn"]
             inv, beta, sq = k.vd(), k.vd(), k.vd()
+            if G_STREAM:
+                hd = self.sweep_column_streamed(kc, w, y, lq, hd, head, inv, beta, sq, pos, alpha, omg)
+                continue
             lik = {i: source(i, kc) for i in range(kc + 1, D)}
             with k.parallel() as par:
                 par.stream()                                 # 1 / dn (or 0), beta, the next alpha
@@ -1325,9 +1400,11 @@ class Main(object):
 # work queue.  Separate kernels cannot share a chip well — each persistent grid takes every workgroup slot it finds and keeps it until its
 # own queue is empty (profiles/r05/c4_ne4_assembly_vs_hipcc.txt) — one queue can: a wavefront that finishes a task of one group takes the
 # next task whatever group it belongs to.  Kernel arguments: a header (queue-level values) + one phf_hier3_isa_args block per body.
+BODY_PRIORITY = {3: 0, 4: 2, 5: 3, 6: 3}
 FUSED_HDR = {"consts": 0, "queue": 8, "scratch": 16, "t_begin": 24, "t_end": 28, "quantum": 32, "num_tasks": 36, "blocks_magic": 40,
-             "rows_per_quantum": 44, "total_blocks": 48, "bounds": 64}
-FUSED_HDR_BYTES, FUSED_MAX_BODIES = 128, 16
+             "rows_per_quantum": 44, "total_blocks": 48, "bounds": 64, "prior_loc": 128, "prior_inv_scale": 168, "prior_shape_m1": 208}
+FUSED_HDR_BYTES, FUSED_MAX_BODIES = 256, 16
+FUSED_BODY_BYTES = ARG_OFF["prior_loc"]             # a body's block: phf_hier3_isa_args up to the prior (the prior is the run's: once, in the header)
 
 
 class FusedMain(Main):
@@ -1358,8 +1435,8 @@ class FusedMain(Main):
         self.write_through_release = self.WRITE_THROUGH_RELEASE
 
     def offsets(self, body):
-        off = {name: FUSED_HDR_BYTES + body * ARG_BYTES + o for name, o in ARG_OFF.items()}
-        off.update({name: FUSED_HDR[name] for name in ("consts", "queue", "scratch")})
+        off = {name: FUSED_HDR_BYTES + body * FUSED_BODY_BYTES + o for name, o in ARG_OFF.items() if o < FUSED_BODY_BYTES}
+        off.update({name: FUSED_HDR[name] for name in ("consts", "queue", "scratch", "prior_loc", "prior_inv_scale", "prior_shape_m1")})
         return off
 
     def next_task_fused(self):
@@ -1428,21 +1505,21 @@ class FusedMain(Main):
         k.sop("s_mov_b32", self.s_t, self.s_first)
         k.free(q4, tb, tot)
         n = len(self.kinds)
-        bq = [k.sx(4) for _ in range((n + 3) // 4)]          # (two aligned quads: eight contiguous scalar registers are not to be had here)
-        for j, q in enumerate(bq):
-            k.s_load(q, g.kernarg, H["bounds"] + 16 * j)
-
-        bound = [bq[b // 4].sub(b % 4, 1) for b in range(n)]
+        bq = k.sx(4)                                          # four bounds at a time, from the last bodies' down (scalar registers are scarce here)
         self.l_body = [k.new_label("body%d" % b) for b in range(n)]
         picks = [k.new_label("pick%d" % b) for b in range(n)]
-        for b in range(n - 1, 0, -1):
-            k.sop("s_cmp_ge_u32", None, self.s_qblock, bound[b])
-            k.branch("s_cbranch_scc1", picks[b])
+        for q in range((n - 1) // 4, -1, -1):
+            k.s_load(bq, g.kernarg, H["bounds"] + 16 * q)
+            for b in range(min(4 * q + 3, n - 1), 4 * q - 1, -1):
+                if b == 0:
+                    continue                                  # (falls through to body 0's pick: bounds[0] = 0)
+                k.sop("s_cmp_ge_u32", None, self.s_qblock, bq.sub(b % 4, 1))
+                k.branch("s_cbranch_scc1", picks[b])
         jt = k.sd()
         for b in range(n):
             if b:
-                k.label(picks[b])
-            k.sop("s_sub_u32", self.s_block, self.s_qblock, bound[b])
+                k.label(picks[b])                             # (reached from its quad's compares: bq holds that quad)
+            k.sop("s_sub_u32", self.s_block, self.s_qblock, bq.sub(b % 4, 1))
             k.long_jump(self.l_body[b], jt)
         k.free(bq, jt)
         k.label(self.l_end)                                  # (here, within reach of the task code's branches; the bodies come back by long jumps)
@@ -1461,13 +1538,16 @@ class FusedMain(Main):
             self.ARG_OFF = self.offsets(b)
             k.comment("======== body %d: %d experiments, %s points ========" % (b, ne, " + ".join(str(x) for x in shape)))
             k.label(self.l_body[b])
+            # a block's iterations are a serial chain, and a step cannot end before the longest chain does: the bodies whose iteration takes
+            # longest get the SIMD's instruction arbiter ahead of their partner wavefront (three-experiment blocks are throughput, not chain)
+            k.raw_rec("s_setprio %d" % BODY_PRIORITY.get(ne, 0))
             self.alloc_state()
             w4 = k.sx(4)
             k.s_load(w4, self.g.kernarg, self.ARG_OFF["num_problems"])     # num_problems bpp bpp_magic total_waves
             self.block_setup(w4, tmp, task)
             self.emit_loop()
         configure(3, (4, 4, 4))
-        lines_meta = k.finish(self.lds_bytes, FUSED_HDR_BYTES + len(self.kinds) * ARG_BYTES)
+        lines_meta = k.finish(self.lds_bytes, FUSED_HDR_BYTES + len(self.kinds) * FUSED_BODY_BYTES)
         return lines_meta, {"vgpr_high_water": k.v.high, "sgpr_high_water": k.s.high, "lds_bytes_per_workgroup": self.lds_bytes,
                             "bodies": len(self.kinds)}
 
@@ -1482,9 +1562,15 @@ def fused_kernel():
 # the kernels of the code object: (experiments, points per experiment).  The Crumb set's 154 pairs with three experiments are 147 x (4, 4, 4),
 # 6 x (2, 2, 2) and 1 x (5, 5, 4)
 # ... and the 41 with four are 32 x (4, 4, 4, 1), 5 x (4, 4, 4, 2), 2 x (4, 4, 4, 3), (2, 2, 2, 1), (5, 5, 5, 1)
-# ... the 12 with five: 5 x (4, 4, 4, 1, 1), 5 x (4, 4, 4, 2, 1), (4, 4, 4, 4, 4), (5, 5, 4, 2, 2)
-HIER_KERNELS = [(3, (4, 4, 4)), (3, (2, 2, 2)), (3, (5, 5, 4)), (4, (4, 4, 4, 1)), (4, (4, 4, 4, 2)), (4, (4, 4, 4, 3)),
-                (4, (2, 2, 2, 1)), (4, (5, 5, 5, 1)), (5, (4, 4, 4, 1, 1)), (5, (4, 4, 4, 2, 1)), (5, (4, 4, 4, 4, 4)), (5, (5, 5, 4, 2, 2))]
+# ... the 12 with five: 5 x (4, 4, 4, 1, 1), 5 x (4, 4, 4, 2, 1), (4, 4, 4, 4, 4), (5, 5, 4, 2, 2); the 3 with six: 2 x (4, 4, 4, 1, 1, 1), (4, 4, 4, 4, 2, 1)
+# In the order of the fused kernel's bodies = the order of a run's block numbering: the bodies whose blocks take longest FIRST, so that in every
+# round of the queue their tasks are pulled first (a block's quanta are a serial chain: the long chains must not also start late)
+HIER_KERNELS = [(6, (4, 4, 4, 4, 2, 1)), (6, (4, 4, 4, 1, 1, 1)), (5, (4, 4, 4, 4, 4)), (5, (5, 5, 4, 2, 2)), (5, (4, 4, 4, 2, 1)), (5, (4, 4, 4, 1, 1)),
+                (4, (5, 5, 5, 1)), (4, (4, 4, 4, 3)), (4, (4, 4, 4, 2)), (4, (4, 4, 4, 1)), (4, (2, 2, 2, 1)),
+                (3, (5, 5, 4)), (3, (4, 4, 4)), (3, (2, 2, 2))]
+# (The bodies for six experiments first made a C4 step LONGER — 42.4 -> 47.2 ms: a block's 2 000 iterations are a serial chain, and at ~23 us per
+# iteration beside a second wavefront that chain outlasted the rest of the grid's work — until the long bodies got the instruction arbiter's
+# priority (BODY_PRIORITY) and the first places in the block numbering: 39 ms, and no kernel left beside the grid.  profiles/r05/c4_fused_launch.txt.)
 
 
 def main_kernel(ne=3, shape=(4, 4, 4)):
@@ -1497,7 +1583,7 @@ def main_kernel(ne=3, shape=(4, 4, 4)):
 
 # ... of which these also exist as kernels of their own (a launch group on its own: phf_hierarchical_advance_queued; s3h; the A/B and PMC runs);
 # the others are bodies of the fused kernel only — a group of such a shape launched by itself runs the hipcc kernel (the same numbers)
-STANDALONE = HIER_KERNELS[:6]
+STANDALONE = [(3, (4, 4, 4)), (3, (2, 2, 2)), (3, (5, 5, 4)), (4, (4, 4, 4, 1)), (4, (4, 4, 4, 2)), (4, (4, 4, 4, 3))]
 
 
 def main_kernels():
@@ -1511,7 +1597,7 @@ def main_kernels():
 
 
 def header_extra(kernels):
-    info = kernels[0][5]
+    info = [kd for kd in kernels if kd[3] == "phf_hier3_advance"][0][5]
     text = "#define PHF_ISA_HIER3_LDS_BYTES %d\n#define PHF_ISA_HIER3_VGPRS %d\n\n" % (info["lds_bytes_per_workgroup"], info["vgpr_high_water"])
     text += ("/* the hierarchical iteration's kernels: experiments, PHF_HIER_SHAPE code of the point shape (phf_hier_points.points_per_expt),\n"
              " * scratch_slots (doubles per lane of device-memory scratch a resident wavefront keeps part of its chains' state in), name */\n"
@@ -1522,16 +1608,23 @@ def header_extra(kernels):
         text += "    {%d, %d, %d, \"%s\"}, /* %s */\n" % (ne, code, kinfo["scratch_slots_per_wavefront"], name, " + ".join(str(n) for n in shape))
     text += "};\n\n"
     n = len(kernels)
+    from gen_hier_isa import ARGS
+    body_fields = [(name, ty) for name, ty in ARGS if ARG_OFF[name] < FUSED_BODY_BYTES]
     text += ("/* phf_hier_fused_advance: ONE persistent grid for every launch group of a run — a header + one argument block per body; body b is\n"
              " * phf_isa_hier_kernels[b]'s iteration, bounds[b] the first block of its group in the run's numbering (blocks of a body without a\n"
              " * group: bounds[b] = bounds[b + 1]; beyond the last body: total_blocks) */\n"
              "#define PHF_ISA_FUSED_BODIES %d\n"
+             "typedef struct phf_hier_body_args {\n%s} phf_hier_body_args;    /* phf_hier3_isa_args up to the prior */\n"
              "typedef struct phf_hier_fused_args {\n"
              "  const void* consts;\n  int32_t* queue;\n  double* scratch;\n  uint32_t t_begin, t_end;\n"
              "  uint32_t quantum, num_tasks, blocks_magic, rows_per_quantum;\n  int32_t total_blocks;\n  int32_t pad[3];\n  uint32_t bounds[16];\n"
-             "  phf_hier3_isa_args body[PHF_ISA_FUSED_BODIES];\n} phf_hier_fused_args;\n" % n)
-    for name in ("consts", "queue", "scratch", "t_begin", "t_end", "quantum", "num_tasks", "blocks_magic", "rows_per_quantum", "total_blocks", "bounds"):
+             "  double prior_loc[5], prior_inv_scale[5], prior_shape_m1[5];\n  double pad1;\n"
+             "  phf_hier_body_args body[PHF_ISA_FUSED_BODIES];\n} phf_hier_fused_args;\n"
+             % (n, "".join("  %s %s;\n" % (ty, name) for name, ty in body_fields)))
+    for name in ("consts", "queue", "scratch", "t_begin", "t_end", "quantum", "num_tasks", "blocks_magic", "rows_per_quantum", "total_blocks", "bounds",
+                 "prior_loc", "prior_inv_scale", "prior_shape_m1"):
         text += "_Static_assert(__builtin_offsetof(phf_hier_fused_args, %s) == %d, \"layout of %s\");\n" % (name, FUSED_HDR[name], name)
-    text += ("_Static_assert(__builtin_offsetof(phf_hier_fused_args, body) == %d && sizeof(phf_hier_fused_args) == %d, \"layout of the bodies' blocks\");\n\n"
-             % (FUSED_HDR_BYTES, FUSED_HDR_BYTES + n * ARG_BYTES))
+    text += ("_Static_assert(sizeof(phf_hier_body_args) == %d && __builtin_offsetof(phf_hier3_isa_args, prior_loc) == %d, \"a body's block\");\n"
+             "_Static_assert(__builtin_offsetof(phf_hier_fused_args, body) == %d && sizeof(phf_hier_fused_args) == %d, \"layout of the bodies' blocks\");\n\n"
+             % (FUSED_BODY_BYTES, FUSED_BODY_BYTES, FUSED_HDR_BYTES, FUSED_HDR_BYTES + n * FUSED_BODY_BYTES))
     return text
