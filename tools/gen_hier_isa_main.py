@@ -1448,6 +1448,7 @@ class FusedMain(Main):
         self.l_task, self.l_end = k.new_label("task"), k.new_label("end")
         self.s_qblock = self.s_wave                          # (the wavefront's number in its workgroup is spent after the prologue)
         k.label(self.l_task)
+        k.raw_rec("s_setprio 0")                             # (between tasks — pulling, polling — a wavefront does not compete with its partner)
         k.sop("s_mov_b64", EXEC, -1)
         q4 = k.sx(4)
         k.s_load(q4, g.kernarg, H["quantum"])                # quantum num_tasks blocks_magic rows_per_quantum
