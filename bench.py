@@ -22,7 +22,8 @@ lines and the thermodynamic-integration path launch — c5 with the on-device <l
 (`c3_model1`) — (`other_workloads`).
 c4 (and a hierarchical strong-scaling share) launches the groups the gfx950 code object has kernels for — every pair with three or four
 experiments — as ONE persistent grid per step (phf_hierarchical_advance_fused), Ne = 5 / 6 beside it on streams of their own;
-PHF_BENCH_HIER_FUSED=0 gives every group a launch and a stream of its own (the arrangement before ABI 7), =3 fuses the Ne = 3 groups only.
+PHF_BENCH_HIER_FUSED=0 gives every group a launch and a stream of its own (the arrangement before ABI 7), =3 fuses the Ne = 3 groups only — A/B
+modes: assembly launches side by side carry the hazard of profiles/r05/queue_progress_word_hazard.txt (the fault word is checked).
 RCCL is used outside the timed regions only: rank 0 reads and packs the data and broadcasts it, the per-problem
 acceptance summaries are gathered to rank 0.  Timing: barrier + synchronize on both sides, MAX over ranks.
 Rank 0 prints ONE JSON line."""

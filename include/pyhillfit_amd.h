@@ -263,6 +263,9 @@ int phf_hierarchical_advance(const phf_hier_points* pts, const phf_problems* pro
  *           ABI 7: a workspace of phf_hierarchical_queue_words(pts, prob) words — which the caller states with kernel_hint bit 6 —
  *           also holds the device-memory scratch in which the gfx950 build of the Ne = 4 iteration keeps the last rows of the proposal
  *           factor (21 KB per resident wavefront, at most 44 MB); without that statement such launches run the hipcc kernels. */
+/* CAUTION (profiles/r05/queue_progress_word_hazard.txt): do not run a queued launch of the gfx950 build BESIDE other launches of that build on the same
+ * GPU (several groups of one run, a stream each) — a wavefront has been seen to wait for a block's progress word until it gave up (PHF_ERR_DRAINED
+ * through the fault flag); several groups go through phf_hierarchical_advance_fused (one grid), or one after the other, or kernel_hint bit 4. */
 int phf_hierarchical_advance_queued(const phf_hier_points* pts, const phf_problems* prob, const phf_hier_prior* prior,
                                     const phf_mh_config* cfg, int64_t t_begin, int64_t t_end, double* state, double* rows,
                                     double* moments, int64_t moments_after, int32_t quantum, int32_t* queue, void* stream);

@@ -512,6 +512,13 @@ def run_hierarchical(pairs, args, device, rank=0, world=1):
             r["stream"] = fused_runs[0]["stream"]
     else:
         fused_runs = []
+    if fused is None and sum(1 for r in runs if (r["s"].n_expts, r["s"].points.packed.points_per_expt) in ISA_SHAPES) > 1:
+        # Several assembly-capable groups, each a launch of its own on its own stream: NOT side by side.  A queued assembly launch (a persistent
+        # grid whose blocks chain their quanta through a progress word) beside another assembly kernel has been seen to wait for a progress word
+        # that its XCD never showed it (tools/diag_drain.py: a poller read 1 for thirty seconds while the block went on to 14; the launch then
+        # drains and the sticky fault word raises) — the one fused grid is the way to run them together; without it the groups take the hipcc kernels
+        for r in runs:
+            r["s"].set_kernel_hint(lanes=r["s"].prob.kernel_hint & 3, isa=False)
     torch.cuda.synchronize(device)
     start = time.time()
     done = 0
