@@ -26,6 +26,12 @@ with tempfile.TemporaryDirectory() as tmp:
         H.HierarchicalSampler.init = init
     if os.environ.get("PHF_DIAG_222_HIPCC") == "1":         # the 2 + 2 + 2 group on the hipcc kernel
         H.GROUPED_SHAPES = {k_ for k_ in H.GROUPED_SHAPES if k_ != (3, 2)}
+    if os.environ.get("PHF_DIAG_SIDE_BY_SIDE", "1") == "1":     # undo run_hierarchical's avoidance: assembly launches side by side, as before
+        hint0 = H.HierarchicalSampler.set_kernel_hint
+
+        def set_hint(o, lanes=0, wps=0, isa=None):
+            return hint0(o, lanes=lanes, wps=wps, isa=None if isa is False and os.environ.get("PHF_DIAG_222_HIPCC") != "1" else isa)
+        H.HierarchicalSampler.set_kernel_hint = set_hint
     orig = H.HierarchicalSampler.check_queue
 
     def check(o):
