@@ -337,6 +337,28 @@ def test_hierarchical_cli_all_pairs_fused_launch_on_equals_off(gpu, tmp_path):
         assert filecmp.cmp(os.path.join(res["on"][0], rel), os.path.join(res["off"][0], rel), shallow=False), rel
 
 
+def test_hierarchical_cli_many_chains_without_the_fused_launch_takes_the_hipcc_kernels(gpu, tmp_path):
+    """--fused-launch off with enough chains for one lane per chain: several assembly-capable groups, a launch each — they must NOT run the gfx950
+    build side by side (profiles/r05/queue_progress_word_hazard.txt): every group on the hipcc kernel, no queue drained, and the same summaries as
+    the fused launch gives"""
+    from pyhillfit_amd import PyHillFit
+    from pyhillfit_amd import doseresponse as dr
+    from pyhillfit_amd import hierarchical as H
+    dr.setup(os.path.join(REPO, "data", "crumb_dataset.json"))
+    csv = str(tmp_path / "crumb_data.csv")
+    dr.table.to_csv(csv)
+    res = {}
+    for mode in ("off", "on"):
+        res[mode] = PyHillFit.main(["--data-file", csv, "-m", "2", "--hierarchical", "-a", "-i", "2000", "-t", "5", "--num-chains", "1024",
+                                    "--output-root", str(tmp_path / ("out_" + mode)), "--num-APs", "10", "--segment", "1000", "--fused-launch", mode])
+        assert H.last_kernel() == (1 if mode == "off" else 6), (mode, H.last_kernel())
+    on = {(b["drug"], b["channel"]): b for b in res["on"]}
+    assert len(res["off"]) == len(on) == 210
+    for a in res["off"]:
+        b = on[(a["drug"], a["channel"])]
+        assert a["pooled_mean"] == b["pooled_mean"] and a["pooled_sd"] == b["pooled_sd"] and a["acceptance"] == b["acceptance"], (a["drug"], a["channel"])
+
+
 def test_generic_ne_kernel_bit_identical_to_cpu_twin(gpu, oracle_pair):
     """pairs with more than 8 experiments (the reference's synthetic set: Ne = 50, dim 105, 200 points) run one wavefront per
     chain (state in LDS, lanes = experiments / factor rows): same bits as the twin across a launch cut, and the moments it
